@@ -1,0 +1,91 @@
+"""The CPU oracle (oracle/lime_oracle.py) against golden vectors captured from the imported
+reference (tools/make_goldens.py).  CPU only.  This is what pins the oracle."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases
+from helpers import load_golden, rel_err, synth_state_dict
+from oracle import lime_oracle as O
+
+TOL = 2e-5   # oracle vs reference: same fp32 math, different op order
+
+
+@pytest.fixture(scope='module', params=list(golden_cases.CASES))
+def case(request):
+    name = request.param
+    cfg, batch, c = golden_cases.build_case(name)
+    g = load_golden(name)
+    spec = json.loads(str(g['state_dict_spec']))
+    sd = synth_state_dict([(k, s) for k, s in spec if not k.endswith('.pe')])
+    taps = {}
+    logits = O.model_forward(sd, cfg, batch, eval_shape=c['eval_shape'], taps=taps)
+    return name, cfg, batch, g, taps, logits
+
+
+def test_logits(case):
+    name, cfg, batch, g, taps, logits = case
+    assert logits.shape == g['logits'].shape
+    assert rel_err(logits.numpy(), g['logits']) < TOL
+    # exact zeros from the saturated lifetime weight stay exact zeros, sign included
+    z = g['logits'] == 0
+    assert np.array_equal(np.signbit(logits.numpy()[z]), np.signbit(g['logits'][z]))
+    assert np.all(logits.numpy()[z] == 0)
+
+
+def test_bucket_indices_bit_exact(case):
+    name, cfg, batch, g, taps, _ = case
+    assert np.array_equal(taps['f_bucket'][0].numpy().reshape(g['cand_f_bucket'].shape), g['cand_f_bucket'])
+    assert np.array_equal(taps['l_bucket'][0].numpy().reshape(g['cand_l_bucket'].shape), g['cand_l_bucket'])
+    assert np.array_equal(taps['f_bucket'][1].numpy(), g['hist_f_bucket'])
+    assert np.array_equal(taps['l_bucket'][1].numpy(), g['hist_l_bucket'])
+
+
+def test_stages(case):
+    name, cfg, batch, g, taps, _ = case
+    r = g['hist_news_out'].shape[0]
+    pairs = [
+        (taps['news_out'][0], g['news_representation']),
+        (taps['news_out'][1][:r], g['hist_news_out']),
+        (taps['content'][0], g['cand_content']),
+        (taps['content'][1][:r], g['hist_content']),
+        (taps['freshness'][0], g['cand_freshness']),
+        (taps['gcn_feature'][:r], g['gcn_feature']),
+        (taps['user_representation'], g['user_representation']),
+    ]
+    if 'hist_refined' in g:
+        pairs += [(taps['hist_refined'][:r], g['hist_refined']), (taps['attn_weights_agg'], g['attn_weights_agg'])]
+    if 'cand_title_pooled' in g:
+        pairs += [(taps['title_pooled'][0], g['cand_title_pooled']), (taps['body_pooled'][0], g['cand_body_pooled'])]
+    for i, (a, b) in enumerate(pairs):
+        assert tuple(a.shape) == tuple(b.shape), i
+        assert rel_err(a.numpy(), b) < TOL, i
+
+
+def test_positional_table_matches_state_dict_shape():
+    g = load_golden('cfg1_crown')
+    spec = dict((k, s) for k, s in json.loads(str(g['state_dict_spec'])))
+    s = spec['news_encoder.base_news_encoder.title_pos_encoder.pe']
+    assert list(O.positional_encoding(s[1], s[2]).shape) == s[1:]
+
+
+def test_bucket_threshold_neighbours():
+    cuts = np.array(O.BUCKET_THRESHOLD_BITS, dtype=np.uint32)
+    below = torch.from_numpy((cuts - 1).view(np.float32).copy())
+    at = torch.from_numpy(cuts.view(np.float32).copy())
+    assert O.bucketize(below).tolist() == list(range(0, 9))
+    assert O.bucketize(at).tolist() == list(range(1, 10))
+    assert O.bucketize(torch.tensor([0.0, -3.0, 1.0, 3.4e38])).tolist() == [0, 0, 0, 9]
+
+
+def test_eval_path_equals_single_candidate_training_shape():
+    """the eval path is the N=1 call."""
+    cfg, batch, c = golden_cases.build_case('cfg1_crown_eval')
+    g = load_golden('cfg1_crown_eval')
+    sd = synth_state_dict([(k, s) for k, s in json.loads(str(g['state_dict_spec'])) if not k.endswith('.pe')])
+    a = O.model_forward(sd, cfg, batch, eval_shape=True)
+    b2 = type(batch)((k, (v.unsqueeze(1) if i >= 15 else v)) for i, (k, v) in enumerate(batch.items()))
+    b = O.model_forward(sd, cfg, b2, eval_shape=False)
+    assert torch.equal(a, b)
