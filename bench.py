@@ -1,0 +1,173 @@
+"""bench.py -- impressions scored / sec on MI355X for LIME's candidate-scoring path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2b|cfg2a|cfg1|cfg3shape]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one ``Model.forward`` (news encoder over the K candidates and H history news of every row,
+CROWN user encoder, dot product x remaining-lifetime weight) over one synthetic MIND-shaped batch
+that is already resident in HBM.  Default workload = BASELINE.json configs[1] with the reference's
+default body length: LIME-CROWN-CROWN, batch 32, history 50, title 32 + body 128, K = 1+4, 300-d, fp32.
+Impression rows are independent, so N GPUs score N batches with no data-path collective (weak scaling).
+
+Rank 0 prints ONE JSON line: metric/value/unit ..., plus
+  "roofline"     the dominant kernel (the 128x128 fp32-MFMA GEMM behind in_proj / linear1), algorithmic FLOPs per
+                 launch / average launch duration from HIP events recorded in the timed region on the launch stream,
+                 against the 157.3 TFLOP/s fp32 matrix peak of MI355X_MICROARCH.md;
+  "cpu_baseline" the CPU oracle (oracle/lime_oracle.py, a torch-CPU port of the reference forward) timed on this
+                 host's cores on the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (config overrides, B, N, description)
+    'cfg2b': (dict(), 32, 5, 'MIND-shape synthetic, LIME-CROWN-CROWN, batch=32, history=50, title_len=32, body_len=128, '
+                             'K=1+4, 300-d, fp32 (BASELINE.json configs[1], reference default body length)'),
+    'cfg2a': (dict(content_encoder='MHSA'), 32, 5, 'MIND-shape synthetic, LIME-MHSA-CROWN (title only), batch=32, history=50, '
+                                                   'title_len=32, K=1+4, 300-d, fp32'),
+    'cfg1': (dict(max_history_num=10, max_title_length=16, max_abstract_length=32, batch_size=8), 8, 2,
+             'MIND-small synthetic, batch=8, history=10, title_len=16, K=1+1 (BASELINE.json configs[0])'),
+    'cfg3shape': (dict(batch_size=256), 256, 5, 'MIND-shape synthetic, batch=256, history=50, title 32 + body 128, K=1+4, '
+                                                'fp32 arithmetic (configs[2] shape)'),
+}
+
+
+def flops_per_impression(cfg, N):
+    """Algorithmic FLOPs of one impression row (GEMM FLOPs = 2 m n k)."""
+    H, T, L = cfg.max_history_num, cfg.max_title_length, cfg.max_abstract_length
+
+    def seq(S):
+        return S * 1334400 + 1200 * S * S
+    tail = 6854800
+    if cfg.content_encoder == 'CROWN':
+        news = seq(T) + seq(L) + tail
+    else:   # MHSA, title only
+        news = T * 360000 + T * T * 800 + T * 160800 + T * 400 + 600000 + 480000
+    user = 50000 * (H + N) + 2400 * N * H + 960000 * H + 320800 * N + 320000
+    return (H + N) * news + user
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='cfg2b', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+        args.gpus = world
+    assert torch.cuda.is_available(), 'bench.py needs the MI355X (the product path has no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+
+    from lime_cikm25_amd import Model, make_config, ops, synth
+    overrides, B, N, desc = WORKLOADS[args.workload]
+    cfg = make_config(**overrides)
+    model = Model(cfg)
+    model.initialize()
+    synth.fill_state_dict(model, seed=1)
+    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
+    model = model.cuda()
+    model.eval()
+    model.training = True                        # [B, K] candidates; every child in eval mode
+    batch_cpu = synth.make_batch(cfg, B, N, seed=100 + rank)
+    batch = [v.cuda() for v in batch_cpu.values()]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        logits = model(*batch)
+    barrier()
+    ops.PROFILE = []                              # HIP events around the dominant kernel's launches, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logits = model(*batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if dist is not None:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(logits).all()
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        fimp = flops_per_impression(cfg, N)
+        # dominant kernel: gemm_f32_kernel<2,2,2,2,4,false> (128x128 tile, float4 staging)
+        dom = [(2.0 * m * n * k, s.elapsed_time(e) * 1e-3) for (variant, m, n, k, s, e) in prof if variant == 'g128v4']
+        roof = None
+        if dom:
+            fl, sec = sum(f for f, _ in dom), sum(t for _, t in dom)
+            ach = fl / sec / 1e12
+            traffic = None
+            tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+            if os.path.exists(tfile):
+                traffic = json.load(open(tfile)).get('gemm_f32_kernel<2,2,2,2,4,false>', {}).get('hbm_bytes_per_launch')
+            roof = {'bound': 'mfma', 'kernel': 'gemm_f32_kernel<2,2,2,2,4,false> (in_proj + linear1 of both encoders)',
+                    'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
+                    'launches': len(dom), 'avg_launch_us': round(sec / len(dom) * 1e6, 1),
+                    'flops_per_launch': fl / len(dom)}
+        out = {
+            'metric': 'impressions scored/sec', 'value': round(value, 2), 'unit': 'impressions/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': desc, 'batch_per_gpu': B, 'history': cfg.max_history_num, 'candidates': N,
+                       'title_len': cfg.max_title_length, 'body_len': cfg.max_abstract_length,
+                       'parallelism': 'rows sharded over %d GPU(s), no data-path collective' % world},
+            'roofline': roof,
+            'end_to_end': {'flops_per_impression': fimp, 'achieved_tflops': round(value * fimp / 1e12, 2),
+                           'frac_of_f32_mfma_peak': round(value * fimp / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import lime_oracle
+            ncore = os.cpu_count() or 1
+            torch.set_num_threads(ncore)
+            n_warm, n_timed = 1, 3
+            for _ in range(n_warm):
+                lime_oracle.model_forward(sd_cpu, cfg, batch_cpu)
+            c0 = time.perf_counter()
+            for _ in range(n_timed):
+                want = lime_oracle.model_forward(sd_cpu, cfg, batch_cpu)
+            cdt = time.perf_counter() - c0
+            err = float(((logits.cpu() - want).abs() / (want.abs() + want.abs()[want != 0].mean())).max())
+            out['cpu_baseline'] = {'value': round(B * n_timed / cdt, 2), 'unit': 'impressions/s', 'cores': torch.get_num_threads(),
+                                   'kind': 'port', 'sample': '%d forwards of the same %d-impression batch (torch CPU fp32 oracle, '
+                                   '%d warm-up)' % (n_timed, B, n_warm), 'max_rel_err_gpu_vs_cpu': err}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

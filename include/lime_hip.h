@@ -1,0 +1,197 @@
+/*
+ * lime_hip.h -- C ABI of liblime_hip.so: hand-written gfx950 (MI355X) kernels for LIME's
+ * candidate-scoring path.
+ *
+ * The reference (seongeunryu/lime-cikm25) has no FFI layer: its boundary is the Python nn.Module
+ * surface.  Every entry point below replaces a PyTorch op sequence of the
+ * reference and cites it (file:line into the reference repository).  The drop-in nn.Modules in
+ * lime_cikm25_amd/ bind these through ctypes; INTEGRATION.md shows the stub a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (row-major, fp32 unless stated);
+ *     the library never allocates, frees, copies to the host or synchronises;
+ *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and returns at once;
+ *   - return value: LIME_OK (0) or a negative lime_status; lime_last_error_string() describes the
+ *     last failure of the calling thread;
+ *   - calls are stateless and re-entrant; results are bitwise reproducible run to run (no atomics
+ *     in any reduction).
+ */
+#ifndef LIME_HIP_H
+#define LIME_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIME_ABI_VERSION 1
+
+typedef enum {
+    LIME_OK = 0,
+    LIME_ERR_BAD_ARG = -1,      /* null pointer, non-positive dimension, misaligned leading dimension */
+    LIME_ERR_UNSUPPORTED = -2,  /* shape outside what the kernels are built for */
+    LIME_ERR_LAUNCH = -3        /* hipGetLastError() after the launch was not hipSuccess */
+} lime_status;
+
+int lime_abi_version(void);
+const char* lime_last_error_string(void);
+
+/* activation applied after bias (+ residual) */
+enum { LIME_ACT_NONE = 0, LIME_ACT_RELU = 1, LIME_ACT_TANH = 2, LIME_ACT_SIGMOID = 3 };
+
+/*
+ * lime_linear_f32: C = epilogue(A . W^T + bias), exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ *
+ * Replaces every nn.Linear on the path, with the surrounding element-wise work fused:
+ *   in_proj / out_proj / linear1 / linear2 of the two TransformerEncoderLayers (newsEncoders.py:244-247,316,320),
+ *   intent_layers (newsEncoders.py:284-295), Attention.affine1 (layers.py:288), FreshnessEncoder.dense
+ *   (newsEncoders.py:82), LIME.project (newsEncoders.py:152-153), gate_proj + gated residual + LayerNorm
+ *   (layers.py:84-89), SAGEConv lin_l / lin_r (userEncoders.py:153), K / Q (userEncoders.py:161-162),
+ *   MultiHeadAttention W_Q/W_K/W_V (layers.py:224-226).
+ *
+ * A operand, row r (0 <= r < M), K columns:
+ *   a_ids == NULL : a[r * lda + k]
+ *   a_ids != NULL : a[a_ids[r] * lda + k] (+ a_pe[(r % a_period) * lda_pe + k] when a_pe != NULL)
+ *                   -- the word-embedding gather and the positional table of newsEncoders.py:311-312,827
+ *                      fused into the operand fetch; `a` is then the [V, K] table.
+ * W is [N, K] row-major with leading dimension ldw (the nn.Linear weight as stored).
+ * Epilogue, in this order, per output element (r, n):
+ *   v  = acc + bias[n]                                   (bias may be NULL)
+ *   v  = act(v)                                          (LIME_ACT_*)
+ *   v += residual(r, n)                                  (res may be NULL)
+ *        res_ids == NULL : res[(r / res_div) * ldr + n]   (res_div >= 1; > 1 broadcasts one row to res_div rows)
+ *        res_ids != NULL : res[res_ids[r] * ldr + n] (+ res_pe[(r % res_period) * ldr_pe + n])
+ *   gate != 0 (layers.py:84-89):  with s = gate_scale[r], x = res(r, n) taken BEFORE the add above,
+ *        g = sigmoid(s * acc + bias[n]);  v = g * (s * x) + (1 - g) * x   (act and the plain add are skipped)
+ *   ln_gamma != NULL : v = LayerNorm over the N columns of row r (eps = ln_eps), requires N <= 416
+ *   c[r * ldc + n] = v
+ * lda/ldw/ldr/ldc are in elements.
+ */
+typedef struct {
+    const float* a;       int64_t lda;
+    const int32_t* a_ids; const float* a_pe; int64_t lda_pe; int32_t a_period;
+    const float* w;       int64_t ldw;
+    const float* bias;
+    const float* res;     int64_t ldr;   int32_t res_div;
+    const int32_t* res_ids; const float* res_pe; int64_t ldr_pe; int32_t res_period;
+    const float* gate_scale; int32_t gate;
+    const float* ln_gamma; const float* ln_beta; float ln_eps;
+    float* c;             int64_t ldc;
+    int32_t M, N, K;
+    int32_t act;
+} lime_linear_args;
+
+int lime_linear_f32(const lime_linear_args* args, void* stream);
+
+/*
+ * lime_embed_pe_f32: out[r, :] = table[ids[r], :] + pe[(r % period), :]   (pe may be NULL)
+ * The stand-alone word-embedding gather (newsEncoders.py:311-312 + :827); the HBM-bound kernel of the
+ * path.  ids int32 [rows]; table [V, dim]; out [rows, ldo].
+ */
+int lime_embed_pe_f32(const int32_t* ids, const float* table, int64_t ld_table, const float* pe, int64_t ld_pe,
+                      int32_t period, float* out, int64_t ldo, int64_t rows, int32_t dim, void* stream);
+
+/*
+ * lime_token_attention_f32: softmax(Q K^T * scale [+ key mask]) V per (sequence, head), exact-fp32 MFMA.
+ * Replaces the attention core of nn.MultiheadAttention inside the TransformerEncoderLayers
+ * (newsEncoders.py:316,320; unmasked) and layers.MultiHeadAttention.forward (layers.py:227-237; key mask
+ * filled with -1e9).  q/k/v: row (seq * S + t), column (head * head_dim + d), leading dimension ld_qkv
+ * (the three may alias one packed [tokens, 3*E] buffer).  key_mask: uint8 [n_seq, S], 0 = masked, or NULL.
+ * out[(seq * S + t) * ldo + head * head_dim + d].   Requires S <= 512, head_dim <= 32.
+ */
+int lime_token_attention_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const uint8_t* key_mask,
+                             float* out, int64_t ldo, int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim,
+                             float scale, void* stream);
+
+/* lime_mean_pool_f32: out[s, :] = mean_t x[(s * S + t), :]   (newsEncoders.py:317,321; padding included) */
+int lime_mean_pool_f32(const float* x, int64_t ldx, float* out, int64_t ldo, int32_t n_seq, int32_t S, int32_t dim,
+                       void* stream);
+
+/*
+ * lime_bucketize_f32: b = min(trunc(log(max(x,1)) / log(86400) * (10/7)), 9)  (newsEncoders.py:53-58),
+ * evaluated by comparison against the nine fp32 cut points of the reference's own fp32 evaluation, so the
+ * indices are bit-exact without a device logf.  out int32 [n].  NaN -> 0, +inf -> 9 (the reference raises).
+ */
+int lime_bucketize_f32(const float* x, int32_t* out, int64_t n, void* stream);
+
+/*
+ * lime_topic_rep_f32: out[r, :] = category_affine(cat[cat_table[cat[r]], sub_table[sub[r]]])
+ * (newsEncoders.py:340-342 and userEncoders.py:103-105,115-117).  cat/sub int32 [rows]; tables [*, dc]/[*, ds];
+ * w [dout, dc + ds]; also writes the two raw embedding rows to emb_out[r, 0:dc+ds] when emb_out != NULL
+ * (feature_fusion, newsEncoders.py:221-225).
+ */
+int lime_topic_rep_f32(const int32_t* cat, const int32_t* sub, const float* cat_table, const float* sub_table,
+                       int32_t dc, int32_t ds, const float* w, const float* bias, int32_t dout, float* out, int64_t ldo,
+                       float* emb_out, int64_t ld_emb, int64_t rows, void* stream);
+
+/*
+ * lime_intent_fuse_f32: the tail of newsEncoders.CROWN.forward (:355-371).
+ *   intents   [2, M, k, D]  title rows then body rows (the relu'd intent embeddings, :288)
+ *   att_hidden[2, M, k, A]  tanh(affine1(intents)) (layers.py:288)
+ *   affine2_t / affine2_b [A]  (layers.py:290, no bias)
+ *   per news: alpha = softmax_k(att_hidden . affine2); x = sum_k alpha_k intents_k (layers.py:296-299), for title
+ *   and body; s = (cos(title, body) + 1) / 2 (:297-300); content[m] = [title(D), s * body(D)] written at
+ *   content[m * ldc + 0 .. 2D).
+ */
+int lime_intent_fuse_f32(const float* intents, const float* att_hidden, const float* affine2_t, const float* affine2_b,
+                         float* content, int64_t ldc, int64_t M, int32_t k, int32_t D, int32_t A, void* stream);
+
+/*
+ * lime_additive_pool_f32: layers.Attention.forward (layers.py:285-300) after affine1:
+ *   a[t] = hidden[s, t, :] . affine2;  masked_fill(mask == 0, -1e9);  alpha = softmax_t;  out[s] = sum_t alpha_t x[s, t, :]
+ * hidden [n_seq * S, A] (ld ldh), x [n_seq * S, D] (ldx), mask uint8 [n_seq, S] or NULL, out [n_seq, ldo].
+ */
+int lime_additive_pool_f32(const float* hidden, int64_t ldh, const float* affine2, int32_t A, const float* x, int64_t ldx,
+                           int32_t D, const uint8_t* mask, float* out, int64_t ldo, int32_t n_seq, int32_t S, void* stream);
+
+/*
+ * lime_cand_attn_weights_f32: the attention-weight part of CandidateAware_ClickedNewsAttention.forward
+ * (layers.py:70-81), one workgroup per row b.  qp = query_proj(cand_topic) [B, N, D] and kp = key_proj(hist_topic)
+ * [B, H, D] come from lime_linear_f32 (layers.py:66-67).  Per head (D / n_head columns, staged in LDS):
+ * scores = Q_h K_h^T / sqrt(D); masked_fill(mask == 0, -1e9); softmax over H (row max / sum by wave64 shuffles);
+ * then query weights qw = softmax_N(||Q_n||_2) (:79) and agg = softmax_H(sum_n qw_n sum_heads A) (:80-81).
+ * mask uint8 [B, H] (0 = padded history slot); agg out [B, H].  Requires N <= 128, H <= 512.
+ */
+int lime_cand_attn_weights_f32(const float* qp, const float* kp, const uint8_t* mask, float* agg, int32_t B, int32_t N,
+                               int32_t H, int32_t D, int32_t n_head, void* stream);
+
+/*
+ * lime_sage_mean_f32: m[b, :] = mean over the first n_src node slots of row b of cat[hist[b] (H rows),
+ * user_nodes (n_user rows)] -- the aggregation PyG's SAGEConv performs for the edge list of
+ * create_bipartite_graph (userEncoders.py:91-98,121,153).  Requires n_src <= H + n_user.
+ */
+int lime_sage_mean_f32(const float* hist, const float* user_nodes, float* out, int32_t B, int32_t H, int32_t n_user,
+                       int32_t n_src, int32_t D, void* stream);
+
+/*
+ * lime_interest_match_f32: userEncoders.py:163-169 + util.py:23-49 fused, one workgroup per row b:
+ *   a[n, h] = kp[b, h, :] . qp[b, n, :] * scale;  alpha = softmax_h (unmasked);  u[b, n, :] = sum_h alpha g[b, h, :]
+ *   base = u . cand[b, n, :];  w = sigmoid(alpha_s * r) (x beta_s where r < 0 when use_penalty; |r| when not)
+ *   logits[b, n] = use_weight ? base * w : base;   user_rep receives u.  Either of user_rep / logits may be NULL.
+ * kp [B, H, A], qp [B, N, A], g [B, H, D], cand [B, N, D], remaining [B, N].
+ */
+int lime_interest_match_f32(const float* kp, const float* qp, const float* g, const float* cand, const float* remaining,
+                            float* user_rep, float* logits, int32_t B, int32_t N, int32_t H, int32_t A, int32_t D,
+                            float scale, float alpha_s, float beta_s, int32_t use_weight, int32_t use_penalty,
+                            void* stream);
+
+/*
+ * lime_lifetime_score_f32: RemainingLifetimeWeighting.forward stand-alone (util.py:23-49):
+ * logits[r] = (user[r, :] . news[r, :]) * w(remaining[r]); rows = B * N.  Same weight rule as above.
+ */
+int lime_lifetime_score_f32(const float* user, const float* news, const float* remaining, float* logits, int64_t rows,
+                            int32_t D, float alpha_s, float beta_s, int32_t use_weight, int32_t use_penalty, void* stream);
+
+/* lime_row_scale_f32: out[r, :] = scale[r] * x[r, :]   (layers.py:84 when use_residual_connection is off) */
+int lime_row_scale_f32(const float* x, const float* scale, float* out, int64_t rows, int32_t D, void* stream);
+
+/* lime_gather_rows_f32: out[r, 0:dim) = table[idx[r], 0:dim)   (nn.Embedding lookups of small tables) */
+int lime_gather_rows_f32(const int32_t* idx, const float* table, int64_t ld_table, float* out, int64_t ldo, int64_t rows,
+                         int32_t dim, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIME_HIP_H */

@@ -1,0 +1,92 @@
+"""ctypes binding of liblime_hip.so (the C ABI declared in include/lime_hip.h).
+
+There is deliberately no fallback: if the shared library is missing or does not export a symbol,
+loading raises -- the product path never routes around the HIP kernels.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'liblime_hip.so')
+
+LIME_ACT = {None: 0, 'none': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3}
+
+
+class LinearArgs(Structure):
+    """Mirror of ``lime_linear_args`` (include/lime_hip.h)."""
+    _fields_ = [
+        ('a', c_void_p), ('lda', c_int64),
+        ('a_ids', c_void_p), ('a_pe', c_void_p), ('lda_pe', c_int64), ('a_period', c_int32),
+        ('w', c_void_p), ('ldw', c_int64),
+        ('bias', c_void_p),
+        ('res', c_void_p), ('ldr', c_int64), ('res_div', c_int32),
+        ('res_ids', c_void_p), ('res_pe', c_void_p), ('ldr_pe', c_int64), ('res_period', c_int32),
+        ('gate_scale', c_void_p), ('gate', c_int32),
+        ('ln_gamma', c_void_p), ('ln_beta', c_void_p), ('ln_eps', c_float),
+        ('c', c_void_p), ('ldc', c_int64),
+        ('M', c_int32), ('N', c_int32), ('K', c_int32),
+        ('act', c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/lime_hip.h declares
+SIGNATURES = {
+    'lime_abi_version': (c_int32, []),
+    'lime_last_error_string': (c_char_p, []),
+    'lime_linear_f32': (c_int32, [POINTER(LinearArgs), c_void_p]),
+    'lime_embed_pe_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int64,
+                                    c_int32, c_void_p]),
+    'lime_token_attention_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
+                                           c_int32, c_int32, c_int32, c_float, c_void_p]),
+    'lime_mean_pool_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
+    'lime_bucketize_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    'lime_topic_rep_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32,
+                                     c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p]),
+    'lime_intent_fuse_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32,
+                                       c_int32, c_void_p]),
+    'lime_additive_pool_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p,
+                                         c_void_p, c_int64, c_int32, c_int32, c_void_p]),
+    'lime_cand_attn_weights_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                             c_int32, c_void_p]),
+    'lime_sage_mean_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    'lime_interest_match_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                          c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_int32, c_int32,
+                                          c_void_p]),
+    'lime_lifetime_score_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float,
+                                          c_int32, c_int32, c_void_p]),
+    'lime_row_scale_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    'lime_gather_rows_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p]),
+}
+
+_lib = None
+
+
+class LimeHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load liblime_hip.so once; raises if it is missing (build it with __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LimeHipError('%s is missing: the HIP extension has not been built (run `python -c "import '
+                           '__graft_entry__ as g; g.build()"` at the repo root); there is no CPU fallback' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.lime_abi_version()
+    if got != 1:
+        raise LimeHipError('liblime_hip.so has ABI version %d, this binding expects 1' % got)
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().lime_last_error_string()
+        raise LimeHipError('%s failed with status %d: %s' % (what, status, msg.decode() if msg else ''))

@@ -1,0 +1,601 @@
+// The HBM/latency-bound kernels of the scoring path: embedding gathers, pooling, lifetime buckets,
+// the intent tail of the CROWN news encoder and the three user-side fused kernels (candidate-aware
+// attention weights, GraphSAGE mean, history-vs-candidate interest match + lifetime weighting).
+// All reductions are fixed-order (wave64 shuffles, then LDS across the four waves): results are
+// bitwise reproducible run to run.
+#include "common.h"
+
+namespace {
+
+// sum over the 256 threads of a workgroup; `red` is >= 4 floats of LDS; every thread gets the total
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();                       // protects `red` against the previous use
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// embedding gather (+ positional table)
+// ---------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void embed_pe_kernel(const int* __restrict__ ids, const float* __restrict__ table,
+                                                        long ld_table, const float* __restrict__ pe, long ld_pe, int period,
+                                                        float* __restrict__ out, long ldo, long rows, int dim) {
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    const int vpr = dim / VEC;                                  // vectors per row
+    const long total = rows * vpr;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / vpr;
+        const int c = (int)(e - r * vpr) * VEC;
+        vec_t v = *reinterpret_cast<const vec_t*>(table + (long)ids[r] * ld_table + c);
+        if (pe) v += *reinterpret_cast<const vec_t*>(pe + (r % period) * ld_pe + c);
+        *reinterpret_cast<vec_t*>(out + r * ldo + c) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_pe_scalar_kernel(const int* __restrict__ ids, const float* __restrict__ table,
+                                                               long ld_table, const float* __restrict__ pe, long ld_pe,
+                                                               int period, float* __restrict__ out, long ldo, long rows,
+                                                               int dim) {
+    const long total = rows * dim;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / dim;
+        const int c = (int)(e - r * dim);
+        float v = table[(long)ids[r] * ld_table + c];
+        if (pe) v += pe[(r % period) * ld_pe + c];
+        out[r * ldo + c] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mean over the tokens of a sequence: one workgroup per sequence, threads over the feature dim
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mean_pool_kernel(const float* __restrict__ x, long ldx, float* __restrict__ out,
+                                                         long ldo, int S, int dim) {
+    const long s = blockIdx.x;
+    const float inv = 1.0f / (float)S;
+    for (int d = threadIdx.x; d < dim; d += 256) {
+        const float* px = x + s * S * ldx + d;
+        float acc = 0.f;
+        for (int t = 0; t < S; ++t) acc += px[(long)t * ldx];
+        out[s * ldo + d] = acc * inv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// lifetime / freshness buckets: comparison against the fp32 cut points (see oracle/lime_oracle.py)
+// ---------------------------------------------------------------------------------------------------
+__constant__ unsigned c_bucket_cuts[9] = {0x45326B18u, 0x4AF8B232u, 0x50AD53E8u, 0x567199BDu, 0x5C2861F4u,
+                                          0x61EAB505u, 0x67A39429u, 0x6D6402D2u, 0x731EE960u};
+
+__global__ __launch_bounds__(256) void bucketize_kernel(const float* __restrict__ x, int* __restrict__ out, long n) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float v = x[e];
+        int b = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) b += (v >= __uint_as_float(c_bucket_cuts[k])) ? 1 : 0;   // NaN compares false
+        out[e] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const int* __restrict__ idx, const float* __restrict__ table,
+                                                           long ld_table, float* __restrict__ out, long ldo, long rows,
+                                                           int dim) {
+    const long total = rows * dim;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / dim;
+        const int c = (int)(e - r * dim);
+        out[r * ldo + c] = table[(long)idx[r] * ld_table + c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// topic representation: one 64-thread workgroup per news
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void topic_rep_kernel(const int* __restrict__ cat, const int* __restrict__ sub,
+                                                        const float* __restrict__ cat_table, const float* __restrict__ sub_table,
+                                                        int dc, int ds, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        int dout, float* __restrict__ out, long ldo, float* __restrict__ emb_out,
+                                                        long ld_emb) {
+    __shared__ float e[256];
+    const long r = blockIdx.x;
+    const int din = dc + ds;
+    const float* crow = cat_table + (long)cat[r] * dc;
+    const float* srow = sub_table + (long)sub[r] * ds;
+    for (int i = threadIdx.x; i < din; i += 64) {
+        const float v = (i < dc) ? crow[i] : srow[i - dc];
+        e[i] = v;
+        if (emb_out) emb_out[r * ld_emb + i] = v;
+    }
+    __syncthreads();
+    if (out) {
+        for (int o = threadIdx.x; o < dout; o += 64) {
+            const float* wr = w + (long)o * din;
+            float acc = 0.f;
+            for (int i = 0; i < din; ++i) acc += wr[i] * e[i];
+            out[r * ldo + o] = acc + (bias ? bias[o] : 0.f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// intent attention + cosine similarity + concat: one workgroup per news
+// ---------------------------------------------------------------------------------------------------
+constexpr int MAX_INTENT = 8;
+
+__global__ __launch_bounds__(256) void intent_fuse_kernel(const float* __restrict__ intents, const float* __restrict__ hidden,
+                                                           const float* __restrict__ aff2_t, const float* __restrict__ aff2_b,
+                                                           float* __restrict__ content, long ldc, long M, int k, int D, int A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][D] pooled vectors, then 4 floats of scratch
+    float* pooled = sm;
+    float* red = sm + 2 * D;
+    const long m = blockIdx.x;
+    for (int tb = 0; tb < 2; ++tb) {
+        const float* aff2 = tb == 0 ? aff2_t : aff2_b;
+        const float* hid = hidden + ((long)tb * M + m) * k * A;
+        const float* itn = intents + ((long)tb * M + m) * k * D;
+        float a[MAX_INTENT];
+        float mx = -INFINITY;
+        for (int kk = 0; kk < k; ++kk) {
+            float part = 0.f;
+            for (int j = threadIdx.x; j < A; j += 256) part += hid[kk * A + j] * aff2[j];
+            a[kk] = block_sum(part, red);
+            mx = fmaxf(mx, a[kk]);
+        }
+        float den = 0.f;
+        for (int kk = 0; kk < k; ++kk) {
+            a[kk] = expf(a[kk] - mx);
+            den += a[kk];
+        }
+        const float inv = 1.0f / den;
+        for (int d = threadIdx.x; d < D; d += 256) {
+            float x = 0.f;
+            for (int kk = 0; kk < k; ++kk) x += (a[kk] * inv) * itn[kk * D + d];
+            pooled[tb * D + d] = x;
+        }
+    }
+    __syncthreads();
+    float dot = 0.f, n1 = 0.f, n2 = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const float t = pooled[d], b = pooled[D + d];
+        dot += t * b;
+        n1 += t * t;
+        n2 += b * b;
+    }
+    dot = block_sum(dot, red);
+    n1 = block_sum(n1, red);
+    n2 = block_sum(n2, red);
+    // F.cosine_similarity(eps = 1e-8): each norm is clamped from below
+    const float cosv = dot / (fmaxf(sqrtf(n1), 1e-8f) * fmaxf(sqrtf(n2), 1e-8f));
+    const float s = (cosv + 1.0f) * 0.5f;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        content[m * ldc + d] = pooled[d];
+        content[m * ldc + D + d] = s * pooled[D + d];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// additive attention pooling over the tokens of a sequence (MHSA news encoder): one workgroup / sequence
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void additive_pool_kernel(const float* __restrict__ hidden, long ldh,
+                                                             const float* __restrict__ aff2, int A, const float* __restrict__ x,
+                                                             long ldx, int D, const unsigned char* __restrict__ mask,
+                                                             float* __restrict__ out, long ldo, int S) {
+    __shared__ float alpha[512];
+    __shared__ float red[4];
+    const long s = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = wave; t < S; t += 4) {
+        const float* h = hidden + (s * S + t) * ldh;
+        float part = 0.f;
+        for (int j = lane; j < A; j += 64) part += h[j] * aff2[j];
+        part = wave_sum(part);
+        if (lane == 0) alpha[t] = (mask && mask[s * S + t] == 0) ? -1e9f : part;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int t = threadIdx.x; t < S; t += 256) mx = fmaxf(mx, alpha[t]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float part = 0.f;
+    for (int t = threadIdx.x; t < S; t += 256) {
+        const float e = expf(alpha[t] - mx);
+        alpha[t] = e;
+        part += e;
+    }
+    const float inv = 1.0f / block_sum(part, red);
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float acc = 0.f;
+        for (int t = 0; t < S; ++t) acc += (alpha[t] * inv) * x[(s * S + t) * ldx + d];
+        out[s * ldo + d] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// candidate-aware attention weights: one workgroup per impression row
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cand_attn_weights_kernel(const float* __restrict__ qp, const float* __restrict__ kp,
+                                                                 const unsigned char* __restrict__ mask, float* __restrict__ agg,
+                                                                 int N, int H, int D, int n_head) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int hd = D / n_head;
+    const int hdp = hd + 1;                        // odd pitch: conflict-free column walks
+    float* Qh = sm;                                // [N][hdp]   this head's query tile
+    float* Kh = Qh + N * hdp;                      // [H][hdp]   this head's key tile
+    float* asum = Kh + H * hdp;                    // [N][H]     sum over heads of the softmaxed weights
+    float* qn2 = asum + N * H;                     // [N]        squared norm of the full query
+    float* red = qn2 + N;                          // [4]
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_scale = 1.0f / sqrtf((float)D);
+    for (int e = threadIdx.x; e < N * H; e += 256) asum[e] = 0.f;
+    for (int e = threadIdx.x; e < N; e += 256) qn2[e] = 0.f;
+    for (int head = 0; head < n_head; ++head) {
+        __syncthreads();
+        // per-head K / Q tiles, coalesced along the head dim
+        for (int e = threadIdx.x; e < N * hd; e += 256) {
+            const int n = e / hd, j = e - n * hd;
+            Qh[n * hdp + j] = qp[((long)b * N + n) * D + head * hd + j];
+        }
+        for (int e = threadIdx.x; e < H * hd; e += 256) {
+            const int h = e / hd, j = e - h * hd;
+            Kh[h * hdp + j] = kp[((long)b * H + h) * D + head * hd + j];
+        }
+        __syncthreads();
+        if (threadIdx.x < N) {
+            float q2 = 0.f;
+            for (int j = 0; j < hd; ++j) q2 += Qh[threadIdx.x * hdp + j] * Qh[threadIdx.x * hdp + j];
+            qn2[threadIdx.x] += q2;
+        }
+        // one wave per query row; keys across the 64 lanes; row max / sum by wave shuffles
+        for (int n = wave; n < N; n += 4) {
+            float sc[8];                                            // H <= 512 -> at most 8 keys per lane
+            float mx = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int h = c * 64 + lane;
+                float v = -INFINITY;
+                if (h < H) {
+                    float dot = 0.f;
+                    for (int j = 0; j < hd; ++j) dot += Qh[n * hdp + j] * Kh[h * hdp + j];
+                    v = dot * inv_scale;
+                    if (mask[(long)b * H + h] == 0) v = -1e9f;       // layers.py:72
+                }
+                sc[c] = v;
+                mx = fmaxf(mx, v);
+            }
+            mx = wave_max(mx);
+            float den = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                sc[c] = (c * 64 + lane < H) ? expf(sc[c] - mx) : 0.f;
+                den += sc[c];
+            }
+            const float inv = 1.0f / wave_sum(den);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int h = c * 64 + lane;
+                if (h < H) asum[n * H + h] += sc[c] * inv;            // this wave owns row n: no race
+            }
+        }
+    }
+    __syncthreads();
+    // query weights: softmax over the candidates of ||Q_n||_2 (layers.py:79); N <= 128
+    float* qw = Qh;                                                    // reuse
+    {
+        float mx = -INFINITY;
+        for (int n = 0; n < N; ++n) mx = fmaxf(mx, sqrtf(qn2[n]));
+        float den = 0.f;
+        for (int n = 0; n < N; ++n) den += expf(sqrtf(qn2[n]) - mx);
+        __syncthreads();
+        for (int n = threadIdx.x; n < N; n += 256) qw[n] = expf(sqrtf(qn2[n]) - mx) / den;
+    }
+    __syncthreads();
+    // agg = softmax_H(sum_n qw_n * asum[n][h])  (layers.py:80-81)
+    float* v = Kh;                                                     // reuse, H floats
+    float mx = -INFINITY;
+    for (int h = threadIdx.x; h < H; h += 256) {
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) acc += asum[n * H + h] * qw[n];
+        v[h] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float part = 0.f;
+    for (int h = threadIdx.x; h < H; h += 256) {
+        const float e = expf(v[h] - mx);
+        v[h] = e;
+        part += e;
+    }
+    const float inv = 1.0f / block_sum(part, red);
+    for (int h = threadIdx.x; h < H; h += 256) agg[(long)b * H + h] = v[h] * inv;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GraphSAGE mean over the first n_src node slots of cat[hist[b], user_nodes]
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sage_mean_kernel(const float* __restrict__ hist, const float* __restrict__ user_nodes,
+                                                         float* __restrict__ out, int H, int n_src, int D) {
+    const long b = blockIdx.x;
+    const float inv = 1.0f / (float)n_src;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float acc = 0.f;
+        for (int u = 0; u < n_src; ++u) acc += (u < H) ? hist[(b * H + u) * D + d] : user_nodes[(long)(u - H) * D + d];
+        out[b * D + d] = acc * inv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// history-vs-candidate attention + dot-product interest match + remaining-lifetime weight:
+// one workgroup per impression row
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void interest_match_kernel(const float* __restrict__ kp, const float* __restrict__ qp,
+                                                              const float* __restrict__ g, const float* __restrict__ cand,
+                                                              const float* __restrict__ remaining, float* __restrict__ user_rep,
+                                                              float* __restrict__ logits, int N, int H, int A, int D, float scale,
+                                                              float alpha_s, float beta_s, int use_weight, int use_penalty) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Qs = sm;                     // [N][A]  candidate queries of this row
+    float* al = Qs + N * A;             // [N][H]  attention logits, then weights
+    float* red = al + N * H;            // [4]
+    const long b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < N * A; e += 256) Qs[e] = qp[b * N * A + e];
+    __syncthreads();
+    // a[n][h] = kp[b,h,:] . qp[b,n,:] * scale: a wave streams one key row (coalesced), lanes over A
+    for (int h = wave; h < H; h += 4) {
+        const float* krow = kp + (b * H + h) * A;
+        for (int n = 0; n < N; ++n) {
+            float part = 0.f;
+            for (int j = lane; j < A; j += 64) part += krow[j] * Qs[n * A + j];
+            part = wave_sum(part);
+            if (lane == 0) al[n * H + h] = part * scale;
+        }
+    }
+    __syncthreads();
+    // softmax over the history (unmasked, userEncoders.py:164): one wave per candidate
+    for (int n = wave; n < N; n += 4) {
+        float mx = -INFINITY;
+        for (int h = lane; h < H; h += 64) mx = fmaxf(mx, al[n * H + h]);
+        mx = wave_max(mx);
+        float den = 0.f;
+        for (int h = lane; h < H; h += 64) {
+            const float e = expf(al[n * H + h] - mx);
+            al[n * H + h] = e;
+            den += e;
+        }
+        const float inv = 1.0f / wave_sum(den);
+        for (int h = lane; h < H; h += 64) al[n * H + h] *= inv;
+    }
+    __syncthreads();
+    // u[n] = sum_h alpha[n][h] g[b,h,:];  base[n] = u[n] . cand[b,n,:]
+    for (int n = 0; n < N; ++n) {
+        float part = 0.f;
+        for (int d = threadIdx.x; d < D; d += 256) {
+            float u = 0.f;
+            for (int h = 0; h < H; ++h) u += al[n * H + h] * g[(b * H + h) * D + d];
+            if (user_rep) user_rep[(b * N + n) * D + d] = u;
+            part += u * cand[(b * N + n) * D + d];
+        }
+        const float base = block_sum(part, red);
+        if (threadIdx.x == 0 && logits) {
+            float out = base;
+            if (use_weight) {
+                const float r = remaining[b * N + n];
+                float w;
+                if (use_penalty) {
+                    // util.py:40-43: positive_mask * w + negative_mask * beta * w
+                    w = lime_sigmoid(alpha_s * r);
+                    w = (r >= 0.f ? 1.f : 0.f) * w + (r < 0.f ? 1.f : 0.f) * beta_s * w;
+                } else {
+                    w = lime_sigmoid(alpha_s * fabsf(r));
+                }
+                out = base * w;
+            }
+            logits[b * N + n] = out;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void lifetime_score_kernel(const float* __restrict__ user, const float* __restrict__ news,
+                                                             const float* __restrict__ remaining, float* __restrict__ logits,
+                                                             long rows, int D, float alpha_s, float beta_s, int use_weight,
+                                                             int use_penalty) {
+    // one wave per (row, candidate): lanes over the embedding dim, fixed-order shuffle reduction
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float part = 0.f;
+    for (int d = lane; d < D; d += 64) part += user[r * D + d] * news[r * D + d];
+    const float base = wave_sum(part);
+    if (lane == 0) {
+        float out = base;
+        if (use_weight) {
+            const float rl = remaining[r];
+            float w;
+            if (use_penalty) {
+                w = lime_sigmoid(alpha_s * rl);
+                w = (rl >= 0.f ? 1.f : 0.f) * w + (rl < 0.f ? 1.f : 0.f) * beta_s * w;
+            } else {
+                w = lime_sigmoid(alpha_s * fabsf(rl));
+            }
+            out = base * w;
+        }
+        logits[r] = out;
+    }
+}
+
+__global__ __launch_bounds__(256) void row_scale_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                         float* __restrict__ out, long rows, int D) {
+    const long total = rows * D;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) out[e] = x[e] * scale[e / D];
+}
+
+inline unsigned grid_for(long total, int per_block, unsigned cap = 2048) {
+    long b = (total + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+extern "C" int lime_embed_pe_f32(const int32_t* ids, const float* table, int64_t ld_table, const float* pe, int64_t ld_pe,
+                                 int32_t period, float* out, int64_t ldo, int64_t rows, int32_t dim, void* stream) {
+    LIME_REQUIRE(ids && table && out, LIME_ERR_BAD_ARG, "lime_embed_pe_f32: NULL pointer");
+    LIME_REQUIRE(rows >= 0 && dim > 0 && ld_table >= dim && ldo >= dim, LIME_ERR_BAD_ARG, "lime_embed_pe_f32: bad dims");
+    LIME_REQUIRE(!pe || (period > 0 && ld_pe >= dim), LIME_ERR_BAD_ARG, "lime_embed_pe_f32: pe needs period > 0, ld_pe >= dim");
+    if (rows == 0) return LIME_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool v4 = dim % 4 == 0 && ld_table % 4 == 0 && ldo % 4 == 0 && (!pe || ld_pe % 4 == 0) &&
+                    ((uintptr_t)table % 16 == 0) && ((uintptr_t)out % 16 == 0) && (!pe || (uintptr_t)pe % 16 == 0);
+    if (v4)
+        hipLaunchKernelGGL((embed_pe_kernel<4>), dim3(grid_for(rows * (dim / 4), 256, 8192)), dim3(256), 0, s, ids, table,
+                           (long)ld_table, pe, (long)ld_pe, period, out, (long)ldo, (long)rows, dim);
+    else
+        hipLaunchKernelGGL(embed_pe_scalar_kernel, dim3(grid_for(rows * dim, 256, 8192)), dim3(256), 0, s, ids, table,
+                           (long)ld_table, pe, (long)ld_pe, period, out, (long)ldo, (long)rows, dim);
+    return lime_check_launch("lime_embed_pe_f32");
+}
+
+extern "C" int lime_mean_pool_f32(const float* x, int64_t ldx, float* out, int64_t ldo, int32_t n_seq, int32_t S, int32_t dim,
+                                  void* stream) {
+    LIME_REQUIRE(x && out, LIME_ERR_BAD_ARG, "lime_mean_pool_f32: NULL pointer");
+    LIME_REQUIRE(n_seq >= 0 && S > 0 && dim > 0 && ldx >= dim && ldo >= dim, LIME_ERR_BAD_ARG, "lime_mean_pool_f32: bad dims");
+    if (n_seq == 0) return LIME_OK;
+    hipLaunchKernelGGL(mean_pool_kernel, dim3((unsigned)n_seq), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, out, (long)ldo, S,
+                       dim);
+    return lime_check_launch("lime_mean_pool_f32");
+}
+
+extern "C" int lime_bucketize_f32(const float* x, int32_t* out, int64_t n, void* stream) {
+    LIME_REQUIRE(x && out, LIME_ERR_BAD_ARG, "lime_bucketize_f32: NULL pointer");
+    LIME_REQUIRE(n >= 0, LIME_ERR_BAD_ARG, "lime_bucketize_f32: negative count");
+    if (n == 0) return LIME_OK;
+    hipLaunchKernelGGL(bucketize_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, (long)n);
+    return lime_check_launch("lime_bucketize_f32");
+}
+
+extern "C" int lime_gather_rows_f32(const int32_t* idx, const float* table, int64_t ld_table, float* out, int64_t ldo,
+                                    int64_t rows, int32_t dim, void* stream) {
+    LIME_REQUIRE(idx && table && out, LIME_ERR_BAD_ARG, "lime_gather_rows_f32: NULL pointer");
+    LIME_REQUIRE(rows >= 0 && dim > 0 && ld_table >= dim && ldo >= dim, LIME_ERR_BAD_ARG, "lime_gather_rows_f32: bad dims");
+    if (rows == 0) return LIME_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(rows * dim, 256)), dim3(256), 0, (hipStream_t)stream, idx, table,
+                       (long)ld_table, out, (long)ldo, (long)rows, dim);
+    return lime_check_launch("lime_gather_rows_f32");
+}
+
+extern "C" int lime_topic_rep_f32(const int32_t* cat, const int32_t* sub, const float* cat_table, const float* sub_table,
+                                  int32_t dc, int32_t ds, const float* w, const float* bias, int32_t dout, float* out,
+                                  int64_t ldo, float* emb_out, int64_t ld_emb, int64_t rows, void* stream) {
+    LIME_REQUIRE(cat && sub && cat_table && sub_table, LIME_ERR_BAD_ARG, "lime_topic_rep_f32: NULL pointer");
+    LIME_REQUIRE(out || emb_out, LIME_ERR_BAD_ARG, "lime_topic_rep_f32: nothing to write");
+    LIME_REQUIRE(!out || (w && dout > 0 && ldo >= dout), LIME_ERR_BAD_ARG, "lime_topic_rep_f32: out needs w, dout, ldo");
+    LIME_REQUIRE(dc > 0 && ds > 0 && dc + ds <= 256, LIME_ERR_UNSUPPORTED, "lime_topic_rep_f32: dc + ds must be in (0, 256]");
+    LIME_REQUIRE(!emb_out || ld_emb >= dc + ds, LIME_ERR_BAD_ARG, "lime_topic_rep_f32: ld_emb too small");
+    if (rows <= 0) return rows == 0 ? LIME_OK : LIME_ERR_BAD_ARG;
+    hipLaunchKernelGGL(topic_rep_kernel, dim3((unsigned)rows), dim3(64), 0, (hipStream_t)stream, cat, sub, cat_table, sub_table, dc,
+                       ds, w, bias, dout, out, (long)ldo, emb_out, (long)ld_emb);
+    return lime_check_launch("lime_topic_rep_f32");
+}
+
+extern "C" int lime_intent_fuse_f32(const float* intents, const float* att_hidden, const float* affine2_t,
+                                    const float* affine2_b, float* content, int64_t ldc, int64_t M, int32_t k, int32_t D,
+                                    int32_t A, void* stream) {
+    LIME_REQUIRE(intents && att_hidden && affine2_t && affine2_b && content, LIME_ERR_BAD_ARG, "lime_intent_fuse_f32: NULL pointer");
+    LIME_REQUIRE(M >= 0 && k > 0 && D > 0 && A > 0 && ldc >= 2 * (int64_t)D, LIME_ERR_BAD_ARG, "lime_intent_fuse_f32: bad dims");
+    LIME_REQUIRE(k <= MAX_INTENT && D <= 4096, LIME_ERR_UNSUPPORTED, "lime_intent_fuse_f32: k <= 8 and D <= 4096 only");
+    if (M == 0) return LIME_OK;
+    const size_t lds = (size_t)(2 * D + 4) * sizeof(float);
+    hipLaunchKernelGGL(intent_fuse_kernel, dim3((unsigned)M), dim3(256), lds, (hipStream_t)stream, intents, att_hidden, affine2_t,
+                       affine2_b, content, (long)ldc, (long)M, k, D, A);
+    return lime_check_launch("lime_intent_fuse_f32");
+}
+
+extern "C" int lime_additive_pool_f32(const float* hidden, int64_t ldh, const float* affine2, int32_t A, const float* x,
+                                      int64_t ldx, int32_t D, const uint8_t* mask, float* out, int64_t ldo, int32_t n_seq,
+                                      int32_t S, void* stream) {
+    LIME_REQUIRE(hidden && affine2 && x && out, LIME_ERR_BAD_ARG, "lime_additive_pool_f32: NULL pointer");
+    LIME_REQUIRE(n_seq >= 0 && S > 0 && A > 0 && D > 0 && ldh >= A && ldx >= D && ldo >= D, LIME_ERR_BAD_ARG,
+                 "lime_additive_pool_f32: bad dims");
+    LIME_REQUIRE(S <= 512, LIME_ERR_UNSUPPORTED, "lime_additive_pool_f32: S %d > 512", S);
+    if (n_seq == 0) return LIME_OK;
+    hipLaunchKernelGGL(additive_pool_kernel, dim3((unsigned)n_seq), dim3(256), 0, (hipStream_t)stream, hidden, (long)ldh, affine2, A,
+                       x, (long)ldx, D, mask, out, (long)ldo, S);
+    return lime_check_launch("lime_additive_pool_f32");
+}
+
+extern "C" int lime_cand_attn_weights_f32(const float* qp, const float* kp, const uint8_t* mask, float* agg, int32_t B,
+                                          int32_t N, int32_t H, int32_t D, int32_t n_head, void* stream) {
+    LIME_REQUIRE(qp && kp && mask && agg, LIME_ERR_BAD_ARG, "lime_cand_attn_weights_f32: NULL pointer");
+    LIME_REQUIRE(B >= 0 && N > 0 && H > 0 && D > 0 && n_head > 0 && D % n_head == 0, LIME_ERR_BAD_ARG,
+                 "lime_cand_attn_weights_f32: bad dims B=%d N=%d H=%d D=%d heads=%d", B, N, H, D, n_head);
+    LIME_REQUIRE(N <= 128 && H <= 512, LIME_ERR_UNSUPPORTED, "lime_cand_attn_weights_f32: N <= 128 and H <= 512 only");
+    if (B == 0) return LIME_OK;
+    const int hdp = D / n_head + 1;
+    const size_t lds = (size_t)((N + H) * hdp + N * H + N + 4) * sizeof(float);
+    LIME_REQUIRE(lds <= 160 * 1024, LIME_ERR_UNSUPPORTED, "lime_cand_attn_weights_f32: %zu B of LDS needed", lds);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)cand_attn_weights_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(cand_attn_weights_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, qp, kp, mask, agg, N, H, D,
+                       n_head);
+    return lime_check_launch("lime_cand_attn_weights_f32");
+}
+
+extern "C" int lime_sage_mean_f32(const float* hist, const float* user_nodes, float* out, int32_t B, int32_t H, int32_t n_user,
+                                  int32_t n_src, int32_t D, void* stream) {
+    LIME_REQUIRE(hist && user_nodes && out, LIME_ERR_BAD_ARG, "lime_sage_mean_f32: NULL pointer");
+    LIME_REQUIRE(B >= 0 && H > 0 && n_user >= 0 && D > 0 && n_src > 0, LIME_ERR_BAD_ARG, "lime_sage_mean_f32: bad dims");
+    LIME_REQUIRE(n_src <= H + n_user, LIME_ERR_BAD_ARG,
+                 "lime_sage_mean_f32: n_src %d exceeds the %d node slots (the reference raises an index error here)", n_src,
+                 H + n_user);
+    if (B == 0) return LIME_OK;
+    hipLaunchKernelGGL(sage_mean_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, hist, user_nodes, out, H, n_src, D);
+    return lime_check_launch("lime_sage_mean_f32");
+}
+
+extern "C" int lime_interest_match_f32(const float* kp, const float* qp, const float* g, const float* cand,
+                                       const float* remaining, float* user_rep, float* logits, int32_t B, int32_t N, int32_t H,
+                                       int32_t A, int32_t D, float scale, float alpha_s, float beta_s, int32_t use_weight,
+                                       int32_t use_penalty, void* stream) {
+    LIME_REQUIRE(kp && qp && g && cand && (logits || user_rep), LIME_ERR_BAD_ARG, "lime_interest_match_f32: NULL pointer");
+    LIME_REQUIRE(!(use_weight && logits) || remaining, LIME_ERR_BAD_ARG, "lime_interest_match_f32: remaining is NULL");
+    LIME_REQUIRE(B >= 0 && N > 0 && H > 0 && A > 0 && D > 0, LIME_ERR_BAD_ARG, "lime_interest_match_f32: bad dims");
+    if (B == 0) return LIME_OK;
+    const size_t lds = (size_t)(N * A + N * H + 4) * sizeof(float);
+    LIME_REQUIRE(lds <= 160 * 1024, LIME_ERR_UNSUPPORTED, "lime_interest_match_f32: %zu B of LDS needed (N=%d)", lds, N);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)interest_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(interest_match_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, kp, qp, g, cand, remaining,
+                       user_rep, logits, N, H, A, D, scale, alpha_s, beta_s, use_weight, use_penalty);
+    return lime_check_launch("lime_interest_match_f32");
+}
+
+extern "C" int lime_lifetime_score_f32(const float* user, const float* news, const float* remaining, float* logits, int64_t rows,
+                                       int32_t D, float alpha_s, float beta_s, int32_t use_weight, int32_t use_penalty,
+                                       void* stream) {
+    LIME_REQUIRE(user && news && logits, LIME_ERR_BAD_ARG, "lime_lifetime_score_f32: NULL pointer");
+    LIME_REQUIRE(!use_weight || remaining, LIME_ERR_BAD_ARG, "lime_lifetime_score_f32: remaining is NULL");
+    LIME_REQUIRE(rows >= 0 && D > 0, LIME_ERR_BAD_ARG, "lime_lifetime_score_f32: bad dims");
+    if (rows == 0) return LIME_OK;
+    hipLaunchKernelGGL(lifetime_score_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, user, news,
+                       remaining, logits, (long)rows, D, alpha_s, beta_s, use_weight, use_penalty);
+    return lime_check_launch("lime_lifetime_score_f32");
+}
+
+extern "C" int lime_row_scale_f32(const float* x, const float* scale, float* out, int64_t rows, int32_t D, void* stream) {
+    LIME_REQUIRE(x && scale && out, LIME_ERR_BAD_ARG, "lime_row_scale_f32: NULL pointer");
+    LIME_REQUIRE(rows >= 0 && D > 0, LIME_ERR_BAD_ARG, "lime_row_scale_f32: bad dims");
+    if (rows == 0) return LIME_OK;
+    hipLaunchKernelGGL(row_scale_kernel, dim3(grid_for(rows * D, 256)), dim3(256), 0, (hipStream_t)stream, x, scale, out, (long)rows,
+                       D);
+    return lime_check_launch("lime_row_scale_f32");
+}

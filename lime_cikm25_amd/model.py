@@ -1,0 +1,72 @@
+"""Drop-in ``Model`` for the LIME-{CROWN,MHSA}-CROWN scoring path (reference model.py:11-187)."""
+import torch
+import torch.nn as nn
+
+from . import newsEncoders, userEncoders
+from .util import RemainingLifetimeWeighting
+
+
+class Model(nn.Module):
+    """Same constructor, attributes (``model_name``, ``config``, ``news_encoder``, ``user_encoder``,
+    ``news_embedding_dim``), ``initialize()`` and 26-tensor ``forward`` as the reference's Model
+    (model.py:12-187); ``state_dict()`` has the reference's key set.  ``forward`` returns logits [B, N].
+
+    Scoring only: the forward pass runs entirely in hand-written HIP kernels and does not record an
+    autograd graph (the training step is SURVEY.md section 8f row 2).  Candidates and history are encoded in one pass
+    over the news-encoder kernels (the reference encodes them in two calls, model.py:171 and userEncoders.py:110).
+    """
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        if config.news_encoder != 'LIME':
+            raise NotImplementedError('news_encoder %r: the MI355X path covers LIME (config.py:25)' % config.news_encoder)
+        if config.content_encoder == 'CROWN':
+            base_encoder = newsEncoders.CROWN(config)
+        elif config.content_encoder == 'MHSA':
+            base_encoder = newsEncoders.MHSA(config)
+        else:
+            raise NotImplementedError('content_encoder %r is a baseline outside the scoring path' % config.content_encoder)
+        self.news_encoder = newsEncoders.LIME(config=config, base_news_encoder=base_encoder)
+        if config.user_encoder != 'CROWN':
+            raise NotImplementedError('user_encoder %r is a baseline outside the scoring path' % config.user_encoder)
+        self.user_encoder = userEncoders.CROWN(self.news_encoder, config)
+        self.model_name = f"{config.news_encoder}-{config.content_encoder}-{config.user_encoder}"
+        self.news_embedding_dim = self.news_encoder.news_embedding_dim
+        self.dropout = nn.Dropout(p=config.dropout_rate)
+        self.use_user_embedding = False
+        self.click_predictor = config.click_predictor
+        if self.click_predictor != 'dot_product':
+            raise NotImplementedError('click_predictor %r: LIME uses dot_product (config.py:109)' % self.click_predictor)
+        self.remaining_lifetime_weighting = RemainingLifetimeWeighting(config)
+
+    def initialize(self):
+        self.news_encoder.initialize()
+        self.user_encoder.initialize()
+        self.remaining_lifetime_weighting.initialize()
+
+    def forward(self, user_ID, user_category, user_subCategory, user_title_text, user_title_mask, user_title_entity,
+                user_content_text, user_content_mask, user_content_entity, user_freshness, user_user_topic_lifetime,
+                user_history_mask, user_history_graph, user_history_category_mask, user_history_category_indices, news_category,
+                news_subCategory, news_title_text, news_title_mask, news_title_entity, news_content_text, news_content_mask,
+                news_content_entity, news_freshness, news_user_topic_lifetime, remaining_lifetime):
+        if not self.training:                                                    # model.py:158-169
+            news_category = news_category.unsqueeze(1)
+            news_subCategory = news_subCategory.unsqueeze(1)
+            news_title_text = news_title_text.unsqueeze(1)
+            news_title_mask = news_title_mask.unsqueeze(1)
+            news_content_text = news_content_text.unsqueeze(1)
+            news_freshness = news_freshness.unsqueeze(1)
+            news_user_topic_lifetime = news_user_topic_lifetime.unsqueeze(1)
+            remaining_lifetime = remaining_lifetime.unsqueeze(1)
+        with torch.no_grad():
+            news_representation, history_embedding = self.news_encoder.encode_many([
+                (news_title_text, news_title_mask, news_content_text, news_category, news_subCategory, news_freshness,
+                 news_user_topic_lifetime),                                      # model.py:171-173
+                (user_title_text, user_title_mask, user_content_text, user_category, user_subCategory, user_freshness,
+                 user_user_topic_lifetime)])                                     # userEncoders.py:110-112
+            _, logits = self.user_encoder.match(history_embedding, news_category, news_subCategory, user_category,
+                                                user_subCategory, user_history_mask, news_representation,
+                                                remaining_lifetime=remaining_lifetime.float(),
+                                                weighting=self.remaining_lifetime_weighting)   # model.py:174-181
+        return logits

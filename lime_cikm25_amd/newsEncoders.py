@@ -1,0 +1,408 @@
+"""Drop-in news encoders of the scoring path: FreshnessEncoder, LIME, CROWN and MHSA
+(reference newsEncoders.py:38-161, 167-373, 566-595, 806-828).
+
+The modules keep the reference's attribute and parameter names, so ``state_dict()`` has the same
+183 keys and reference checkpoints load.  Standard torch containers
+(nn.Linear, nn.Embedding, nn.TransformerEncoder ...) are used as *parameter holders* with their
+constructor-default initialisation, exactly as the reference leaves them; their ``forward`` is never
+called.  All arithmetic runs in hand-written HIP kernels (lime_cikm25_amd.ops -> liblime_hip.so):
+
+  word gather + positional table      fused into the A-operand fetch of the in_proj GEMM
+  in_proj / out_proj / FFN            exact-fp32 MFMA GEMM; bias, ReLU, residual and LayerNorm in the epilogue
+  token attention                     one wave per 32 query rows, scores held in MFMA accumulators
+  mean pool / intent tail / buckets   small fixed-order kernels
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.nn import TransformerEncoder, TransformerEncoderLayer
+
+from . import ops
+from .layers import Attention, MultiHeadAttention
+
+# tokens encoded per pass of the token encoder: bounds the activation workspace (9.2 KB / token)
+MAX_TOKENS_PER_PASS = 4 * 1024 * 1024
+
+
+def _no_train_dropout(module, p):
+    if module.training and p > 0:
+        raise NotImplementedError('training-mode dropout is not implemented: the HIP path covers scoring '
+                                  '(eval-mode children, or dropout_rate = 0); see SURVEY.md section 8f row 2')
+
+
+def _i32(t):
+    return t if t.dtype == torch.int32 else t.to(torch.int32)
+
+
+class FreshnessEncoder(nn.Module):
+    """newsEncoders.py:38-83.  hidden = content dim always: ``fusion_method == 'add' or 'gated'`` is truthy (:42-45)."""
+
+    def __init__(self, config, base_news_encoder):
+        super().__init__()
+        embedding_dim = config.freshness_embedding_dim
+        hidden_dim = base_news_encoder.news_embedding_dim
+        self.num_buckets = config.num_buckets
+        if self.num_buckets != 10:
+            raise NotImplementedError('bit-exact bucket cut points are derived for num_buckets = 10 (config.py:59)')
+        self.freshness_embedding = nn.Embedding(self.num_buckets, embedding_dim)
+        self.lifetime_embedding = nn.Embedding(self.num_buckets, embedding_dim)
+        self.dense = nn.Linear(embedding_dim * 2, hidden_dim)
+        self.activation = nn.Tanh()
+
+    def bucketize(self, x):
+        """int64 like the reference (newsEncoders.py:53-58); computed by threshold comparison on the device."""
+        return ops.bucketize(x.float()).long()
+
+    def encode_flat(self, freshness, lifetime, out):
+        """freshness / lifetime: [M] fp32; out: [M, hidden] (may be a view of a wider buffer)."""
+        M = freshness.numel()
+        E = self.freshness_embedding.embedding_dim
+        fb = ops.bucketize(freshness)
+        lb = ops.bucketize(lifetime)
+        cat = torch.empty((M, 2 * E), dtype=torch.float32, device=out.device)
+        ops.gather_rows(fb, self.freshness_embedding.weight, cat[:, :E])
+        ops.gather_rows(lb, self.lifetime_embedding.weight, cat[:, E:])
+        return ops.linear(cat, self.dense.weight, self.dense.bias, act='tanh', out=out)
+
+    def forward(self, news_freshness, news_user_topic_lifetime):
+        if news_freshness.dim() == 1:
+            news_freshness = news_freshness.unsqueeze(1)
+        if news_user_topic_lifetime.dim() == 1:
+            news_user_topic_lifetime = news_user_topic_lifetime.unsqueeze(1)
+        if news_freshness.shape != news_user_topic_lifetime.shape:
+            news_user_topic_lifetime = news_user_topic_lifetime.expand_as(news_freshness)
+        B, n = news_freshness.shape
+        out = torch.empty((B * n, self.dense.out_features), dtype=torch.float32, device=news_freshness.device)
+        self.encode_flat(news_freshness.float().contiguous().view(-1), news_user_topic_lifetime.float().contiguous().view(-1), out)
+        return out.view(B, n, -1)
+
+
+class LIME(nn.Module):
+    """newsEncoders.py:87-161 with fusion_method = 'concat' (the default and the scoring path)."""
+
+    def __init__(self, config, base_news_encoder):
+        super().__init__()
+        self.final_dim = config.lime_output_dim
+        self.category_embedding = nn.Embedding(config.category_num, config.category_embedding_dim)
+        self.category_embedding.weight.requires_grad = False
+        self.subCategory_embedding = nn.Embedding(config.subCategory_num, config.subCategory_embedding_dim)
+        self.subCategory_embedding.weight.requires_grad = False
+        self.category_affine = nn.Linear(config.category_embedding_dim + config.subCategory_embedding_dim,
+                                         config.category_embedding_dim)
+        self.base_news_encoder = base_news_encoder
+        self.freshness_encoder = FreshnessEncoder(config, base_news_encoder)
+        self.fusion_method = config.fusion_method
+        if self.fusion_method != 'concat':
+            raise NotImplementedError("fusion_method %r: only 'concat' is on the scoring path (config.py:55)" % self.fusion_method)
+        self.auxiliary_loss = getattr(base_news_encoder, 'auxiliary_loss', None)      # newsEncoders.py:100-103
+        content_dim = self.base_news_encoder.news_embedding_dim
+        freshness_dim = content_dim                                                   # newsEncoders.py:106-107
+        self.output_dim = content_dim + freshness_dim
+        if self.final_dim:
+            self.project = nn.Linear(self.output_dim, self.final_dim)
+            self.output_dim = self.final_dim
+        else:
+            self.project = nn.Identity()
+        self.news_embedding_dim = self.output_dim
+
+    def initialize(self):
+        if hasattr(self.base_news_encoder, 'initialize'):
+            self.base_news_encoder.initialize()
+        nn.init.xavier_uniform_(self.freshness_encoder.dense.weight)
+        nn.init.zeros_(self.freshness_encoder.dense.bias)
+        nn.init.uniform_(self.category_embedding.weight, -0.1, 0.1)
+        nn.init.uniform_(self.subCategory_embedding.weight, -0.1, 0.1)
+        nn.init.xavier_uniform_(self.category_affine.weight)
+        nn.init.zeros_(self.category_affine.bias)
+
+    def encode_flat(self, title_text, title_mask, content_text, category, subCategory, freshness, lifetime):
+        """Flat batch of M news -> [M, output_dim].  title_text [M, T], content_text [M, L] int32; the rest [M]."""
+        M = title_text.shape[0]
+        cdim = self.base_news_encoder.news_embedding_dim
+        fused = torch.empty((M, 2 * cdim), dtype=torch.float32, device=title_text.device)
+        self.base_news_encoder.encode_flat(title_text, title_mask, content_text, category, subCategory, fused[:, :cdim])
+        self.freshness_encoder.encode_flat(freshness, lifetime, fused[:, cdim:])
+        if isinstance(self.project, nn.Identity):
+            return fused
+        return ops.linear(fused, self.project.weight, self.project.bias)             # newsEncoders.py:152-153
+
+    def encode_many(self, groups):
+        """Encode several [B, n, ...] groups (candidates, history) in ONE pass over the kernels.
+
+        Each group: (title_text, title_mask, content_text, category, subCategory, freshness, lifetime).
+        Returns one [B, n, output_dim] tensor per group.
+        """
+        shapes, flat = [], [[] for _ in range(7)]
+        for (tt, tm, ct, cat, sub, fr, lt) in groups:
+            B, n = tt.shape[0], tt.shape[1]
+            shapes.append((B, n))
+            if fr.dim() == 1:
+                fr = fr.unsqueeze(1)
+            if lt.dim() == 1:
+                lt = lt.unsqueeze(1)
+            if lt.shape != fr.shape:
+                lt = lt.expand_as(fr)
+            for dst, t in zip(flat, (_i32(tt).reshape(B * n, -1), tm.reshape(B * n, -1), _i32(ct).reshape(B * n, -1),
+                                     _i32(cat).reshape(-1), _i32(sub).reshape(-1), fr.float().reshape(-1), lt.float().reshape(-1))):
+                dst.append(t)
+        cat_all = [t[0].contiguous() if len(t) == 1 else torch.cat(t, dim=0) for t in flat]
+        out = self.encode_flat(*cat_all)
+        res, r0 = [], 0
+        for (B, n) in shapes:
+            res.append(out[r0:r0 + B * n].view(B, n, -1))
+            r0 += B * n
+        return res
+
+    def forward(self, title_text, title_mask, title_entity, content_text, content_mask, content_entity, category, subCategory,
+                user_embedding, news_freshness, news_user_topic_lifetime):
+        return self.encode_many([(title_text, title_mask, content_text, category, subCategory, news_freshness,
+                                  news_user_topic_lifetime)])[0]
+
+
+class NewsEncoder(nn.Module):
+    """newsEncoders.py:167-225: shared tables.  The word table is filled by the caller (``load_state_dict`` or
+    ``word_embedding.weight.data.copy_``); the reference unpickles it from the cwd at :173-174."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.word_embedding_dim = config.word_embedding_dim
+        self.category_num = config.category_num
+        self.word_embedding = nn.Embedding(num_embeddings=config.vocabulary_size, embedding_dim=self.word_embedding_dim)
+        self.category_embedding = nn.Embedding(num_embeddings=config.category_num, embedding_dim=config.category_embedding_dim)
+        self.category_embedding.weight.requires_grad = False
+        self.subCategory_embedding = nn.Embedding(num_embeddings=config.subCategory_num,
+                                                  embedding_dim=config.subCategory_embedding_dim)
+        self.subCategory_embedding.weight.requires_grad = False
+        self.dropout_rate = config.dropout_rate
+        self.dropout = nn.Dropout(p=config.dropout_rate, inplace=True)
+        self.dropout_ = nn.Dropout(p=config.dropout_rate, inplace=False)
+        self.auxiliary_loss = None
+        self.affine = nn.Linear(config.word_embedding_dim, config.word_embedding_dim, bias=True)   # unused upstream too
+
+    def initialize(self):
+        nn.init.uniform_(self.category_embedding.weight, -0.1, 0.1)
+        nn.init.uniform_(self.subCategory_embedding.weight, -0.1, 0.1)
+        nn.init.zeros_(self.subCategory_embedding.weight[0])
+        nn.init.xavier_uniform_(self.affine.weight)
+        nn.init.zeros_(self.affine.bias)
+
+    def forward(self, title_text, title_mask, title_entity, content_text, content_mask, content_entity, category, subCategory,
+                user_embedding, news_freshness, news_user_topic_lifetime):
+        B, n = title_text.shape[0], title_text.shape[1]
+        out = torch.empty((B * n, self.news_embedding_dim), dtype=torch.float32, device=title_text.device)
+        self.encode_flat(_i32(title_text).reshape(B * n, -1).contiguous(), title_mask.reshape(B * n, -1).contiguous(),
+                         _i32(content_text).reshape(B * n, -1).contiguous(), _i32(category).reshape(-1).contiguous(),
+                         _i32(subCategory).reshape(-1).contiguous(), out)
+        return out.view(B, n, -1)
+
+
+class PositionalEncoding(nn.Module):
+    """newsEncoders.py:806-828: the sinusoid table, a registered buffer (part of the state_dict)."""
+
+    def __init__(self, d_model, dropout=0.1, max_len=5000):
+        super().__init__()
+        self.dropout = nn.Dropout(p=dropout)
+        position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+        pe = torch.zeros(max_len, d_model)
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer('pe', pe.unsqueeze(0))
+
+    def table(self):
+        return self.pe[0]
+
+
+class _MAB(nn.Module):
+    """Parameter holder for newsEncoders.py:395-422 (never called on the scoring path)."""
+
+    def __init__(self, dim_Q, dim_K, dim_V, num_heads, ln=False):
+        super().__init__()
+        self.fc_q = nn.Linear(dim_Q, dim_V)
+        self.fc_k = nn.Linear(dim_K, dim_V)
+        self.fc_v = nn.Linear(dim_K, dim_V)
+        if ln:
+            self.ln0 = nn.LayerNorm(dim_V)
+            self.ln1 = nn.LayerNorm(dim_V)
+        self.fc_o = nn.Linear(dim_V, dim_V)
+
+
+class ISAB(nn.Module):
+    """Parameter holder: the reference constructs ISAB (newsEncoders.py:250-254) and never calls it (:325-333 are
+    commented out), but its 25 tensors are part of the checkpoint."""
+
+    def __init__(self, dim_in, dim_out, num_heads, num_inds, ln=False):
+        super().__init__()
+        self.I = nn.Parameter(torch.Tensor(1, num_inds, dim_out))
+        nn.init.xavier_uniform_(self.I)
+        self.mab0 = _MAB(dim_out, dim_in, dim_out, num_heads, ln=ln)
+        self.mab1 = _MAB(dim_in, dim_out, dim_out, num_heads, ln=ln)
+
+
+class CategoryPredictor(nn.Module):
+    """Parameter holder for newsEncoders.py:375-393: under LIME the auxiliary loss is dead."""
+
+    def __init__(self, title_embedding, category_num):
+        super().__init__()
+        self.fc = nn.Linear(title_embedding, category_num)
+
+
+def encode_tokens(ids, table, pe, transformer, nhead):
+    """Word gather + positional table + the post-LN encoder layer(s) of newsEncoders.py:311-320.
+
+    ids: [M, S] int32 (every id must be in [0, V): unchecked, as on nn.Embedding's device path);
+    returns the layer output [M * S, E].  Five launches per layer, activations stay fp32.
+    """
+    M, S = ids.shape
+    E = table.shape[1]
+    hd = E // nhead
+    flat = ids.reshape(-1)
+    x = None
+    for li, layer in enumerate(transformer.layers):
+        sa = layer.self_attn
+        if li == 0:
+            qkv = ops.linear(table, sa.in_proj_weight, sa.in_proj_bias, a_ids=flat, a_pe=pe, a_period=S)
+        else:
+            qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias)
+        attn = ops.token_attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], M, S, nhead, hd, 1.0 / math.sqrt(hd))
+        ln1 = (layer.norm1.weight, layer.norm1.bias)
+        if li == 0:
+            x1 = ops.linear(attn, sa.out_proj.weight, sa.out_proj.bias, res=table, res_ids=flat, res_pe=pe, res_period=S,
+                            ln=ln1, ln_eps=layer.norm1.eps)
+        else:
+            x1 = ops.linear(attn, sa.out_proj.weight, sa.out_proj.bias, res=x, ln=ln1, ln_eps=layer.norm1.eps)
+        h = ops.linear(x1, layer.linear1.weight, layer.linear1.bias, act='relu')
+        x = ops.linear(h, layer.linear2.weight, layer.linear2.bias, res=x1, ln=(layer.norm2.weight, layer.norm2.bias),
+                       ln_eps=layer.norm2.eps)
+    if transformer.norm is not None:
+        raise NotImplementedError('a final encoder norm is not used by the reference (newsEncoders.py:245,247)')
+    return x
+
+
+class CROWN(NewsEncoder):
+    """newsEncoders.py:228-373: title/body transformer encoders, mean pooling, category-aware k-intent
+    disentanglement, intent attention, title-body similarity, feature fusion.  -> [B, n, 900]."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.max_title_length = config.max_title_length
+        self.max_body_length = config.max_abstract_length
+        self.max_history_num = config.max_history_num
+        self.category_embedding_dim = config.category_embedding_dim
+        self.intent_embedding_dim = config.intent_embedding_dim
+        self.category_embedding = nn.Embedding(config.category_num, config.category_embedding_dim)     # trainable again (:237)
+        self.news_embedding_dim = config.intent_embedding_dim * 2 + config.category_embedding_dim + config.subCategory_embedding_dim
+        self.head_num = config.head_num
+        self.title_pos_encoder = PositionalEncoding(config.word_embedding_dim, config.dropout_rate, config.max_title_length)
+        self.body_pos_encoder = PositionalEncoding(config.word_embedding_dim, config.dropout_rate, config.max_abstract_length)
+        title_encoder_layers = TransformerEncoderLayer(config.word_embedding_dim, config.head_num, config.feedforward_dim,
+                                                       config.dropout_rate, batch_first=True)
+        self.title_transformer = TransformerEncoder(title_encoder_layers, config.num_layers)
+        body_encoder_layers = TransformerEncoderLayer(config.word_embedding_dim, config.head_num, config.feedforward_dim,
+                                                      config.dropout_rate, batch_first=True)
+        self.body_transformer = TransformerEncoder(body_encoder_layers, config.num_layers)
+        self.ISAB = ISAB(dim_in=config.word_embedding_dim, dim_out=config.word_embedding_dim, num_heads=config.isab_num_heads,
+                         num_inds=config.isab_num_inds, ln=True)
+        self.category_affine = nn.Linear(config.category_embedding_dim + config.subCategory_embedding_dim,
+                                         config.category_embedding_dim)
+        self.intent_num = config.intent_num
+        self.alpha = config.alpha
+        self.title_intent_attention = Attention(config.intent_embedding_dim, config.attention_dim)
+        self.body_intent_attention = Attention(config.intent_embedding_dim, config.attention_dim)
+        self.intent_layers = nn.ModuleList([nn.Linear(config.word_embedding_dim + config.category_embedding_dim,
+                                                      config.intent_embedding_dim, bias=True) for _ in range(self.intent_num)])
+        self.category_predictor = CategoryPredictor(config.intent_embedding_dim, config.category_num)
+
+    def initialize(self):
+        super().initialize()
+        self.title_intent_attention.initialize()
+        self.body_intent_attention.initialize()
+        nn.init.xavier_uniform_(self.category_affine.weight)
+        nn.init.zeros_(self.category_affine.bias)
+        for intent_layer in self.intent_layers:
+            nn.init.xavier_uniform_(intent_layer.weight)
+            nn.init.zeros_(intent_layer.bias)
+        nn.init.uniform_(self.category_embedding.weight, -0.1, 0.1)
+
+    def encode_flat(self, title_text, title_mask, content_text, category, subCategory, out):
+        """M news -> out [M, 900] (out may be a column slice of a wider buffer).  The token masks are computed and never
+        used by the reference (:307-308); title_mask is accepted and ignored."""
+        _no_train_dropout(self, self.dropout_rate)
+        M, T = title_text.shape
+        L = content_text.shape[1]
+        if T != self.max_title_length or L != self.max_body_length:
+            raise ValueError('token tensors must be [*, %d] / [*, %d]' % (self.max_title_length, self.max_body_length))
+        E, Dc, D = self.word_embedding_dim, self.category_embedding_dim, self.intent_embedding_dim
+        k = self.intent_num
+        dev = title_text.device
+        table = self.word_embedding.weight
+        kin = E + Dc
+        ldx = (kin + 3) // 4 * 4                                   # 352: keeps the rows 16-byte aligned
+        # rows [0, M): [title_pooled | category_rep], rows [M, 2M): [body_pooled | category_rep]   (:343-344)
+        xin = torch.empty((2 * M, ldx), dtype=torch.float32, device=dev)
+        for half, (ids, pos, tr, S) in enumerate(((title_text, self.title_pos_encoder, self.title_transformer, T),
+                                                  (content_text, self.body_pos_encoder, self.body_transformer, L))):
+            step = max(1, MAX_TOKENS_PER_PASS // S)
+            for m0 in range(0, M, step):
+                m1 = min(M, m0 + step)
+                y = encode_tokens(ids[m0:m1], table, pos.table(), tr, self.head_num)                 # :311-320
+                ops.mean_pool(y, m1 - m0, S, out=xin[half * M + m0:half * M + m1, :E])                # :317,:321
+        # category representation (:340-342) and the raw category / subCategory rows of feature_fusion (:221-225)
+        sub_table = self.subCategory_embedding.weight
+        ops.topic_rep(category, subCategory, self.category_embedding.weight, sub_table, self.category_affine.weight,
+                      self.category_affine.bias, out=xin[:M, E:kin], emb_out=out[:, 2 * D:2 * D + Dc + sub_table.shape[1]])
+        ops.topic_rep(category, subCategory, self.category_embedding.weight, sub_table, self.category_affine.weight,
+                      self.category_affine.bias, out=xin[M:, E:kin])
+        # k intent layers (:284-295): [2M, 350] x [400, 350]^T each, ReLU fused, written side by side
+        intents = torch.empty((2 * M, k * D), dtype=torch.float32, device=dev)
+        for i, lin in enumerate(self.intent_layers):
+            ops.linear(xin[:, :kin], lin.weight, lin.bias, act='relu', out=intents[:, i * D:(i + 1) * D])
+        # intent attention (:355-356): tanh(affine1) on the GEMM, the rest in the fuse kernel
+        A = self.title_intent_attention.affine1.out_features
+        hidden = torch.empty((2 * M * k, A), dtype=torch.float32, device=dev)
+        iv = intents.view(2 * M * k, D)
+        for half, att in enumerate((self.title_intent_attention, self.body_intent_attention)):
+            ops.linear(iv[half * M * k:(half + 1) * M * k], att.affine1.weight, att.affine1.bias, act='tanh',
+                       out=hidden[half * M * k:(half + 1) * M * k])
+        ops.intent_fuse(iv, hidden, self.title_intent_attention.affine2.weight.view(-1),
+                        self.body_intent_attention.affine2.weight.view(-1), out, M, k, D, A)          # :355-371
+        return out
+
+
+class MHSA(NewsEncoder):
+    """newsEncoders.py:566-595: title-only multi-head self-attention + additive attention.  -> [B, n, 300]."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.max_sentence_length = config.max_title_length
+        self.feature_dim = config.head_num * config.head_dim
+        self.multiheadAttention = MultiHeadAttention(config.head_num, config.word_embedding_dim, config.max_title_length,
+                                                     config.max_title_length, config.head_dim, config.head_dim)
+        self.attention = Attention(config.head_num * config.head_dim, config.attention_dim)
+        self.news_embedding_dim = config.head_num * config.head_dim + config.category_embedding_dim + config.subCategory_embedding_dim
+        self.category_embedding = nn.Embedding(config.category_num, config.category_embedding_dim)
+
+    def initialize(self):
+        super().initialize()
+        self.multiheadAttention.initialize()
+        self.attention.initialize()
+        nn.init.uniform_(self.category_embedding.weight, -0.1, 0.1)
+
+    def encode_flat(self, title_text, title_mask, content_text, category, subCategory, out):
+        _no_train_dropout(self, self.dropout_rate)
+        M, T = title_text.shape
+        F = self.feature_dim
+        mask = title_mask.contiguous()
+        mha = self.multiheadAttention
+        step = max(1, MAX_TOKENS_PER_PASS // T)
+        for m0 in range(0, M, step):
+            m1 = min(M, m0 + step)
+            qkv = mha.project(table=self.word_embedding.weight, ids=title_text[m0:m1].reshape(-1))     # :588 + layers.py:224-226
+            c = mha.attend(qkv, m1 - m0, T, mask[m0:m1])                                                # layers.py:227-237
+            hidden = ops.linear(c, self.attention.affine1.weight, self.attention.affine1.bias, act='tanh')
+            ops.additive_pool(hidden, self.attention.affine2.weight.view(-1), c, m1 - m0, T, mask=mask[m0:m1],
+                              out=out[m0:m1, :F])                                                       # :592
+        ops.topic_rep(category, subCategory, self.category_embedding.weight, self.subCategory_embedding.weight,
+                      emb_out=out[:, F:])                                                               # :594
+        return out

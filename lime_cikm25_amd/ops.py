@@ -1,0 +1,347 @@
+"""Tensor-level wrappers over the C ABI (include/lime_hip.h): shape/dtype/device checks on the host,
+then one call into liblime_hip.so on torch's current stream.  PyTorch is used here for device memory
+and streams only -- every wrapper launches hand-written HIP kernels and nothing else.
+
+2-D operands may be row-strided views (``stride(1) == 1``); the row stride is passed as the leading
+dimension, so slices like ``qkv[:, 300:600]`` or ``fused[:, 900:]`` cost nothing.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import LinearArgs, LIME_ACT, check
+
+
+# bench.py sets this to a list to collect (variant, M, N, K, start_event, end_event) per lime_linear_f32 launch:
+# HIP events recorded on the launch stream right around the launch (never used otherwise)
+PROFILE = None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _linear_variant(M, N, K, ln, a, w, a_pe):
+    """Which gemm_f32_kernel instantiation lime_linear_f32 dispatches to (mirrors csrc/gemm_f32.hip)."""
+    vec = 4
+    def ok(t, v):
+        return t is None or (t.data_ptr() % (4 * v) == 0 and _ld(t) % v == 0)
+    while vec > 1 and not (K % vec == 0 and ok(a, vec) and ok(w, vec) and ok(a_pe, vec)):
+        vec //= 2
+    if ln:
+        tile = 'row10' if N <= 320 else 'row13'
+    else:
+        tile = 'g128' if M >= 4096 else 'g64'
+    return '%sv%d' % (tile, vec)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _mat(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError('%s must be a CUDA tensor (the HIP path has no CPU fallback)' % name)
+    if t.dtype != dtype:
+        raise TypeError('%s must be %s, got %s' % (name, dtype, t.dtype))
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1) or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        raise ValueError('%s must be 2-D with unit column stride, got shape %s strides %s' % (name, tuple(t.shape), t.stride()))
+    return t
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def _vec(t, name, n=None, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise TypeError('%s must be a contiguous CUDA %s tensor' % (name, dtype))
+    if n is not None and t.numel() != n:
+        raise ValueError('%s must have %d elements, got %d' % (name, n, t.numel()))
+    return t
+
+
+def _mask_u8(mask, name):
+    """bool/uint8 mask -> uint8 view (zero-copy)."""
+    if mask is None:
+        return None
+    if mask.dtype == torch.bool:
+        mask = mask.contiguous().view(torch.uint8)
+    return _vec(mask, name, dtype=torch.uint8)
+
+
+def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=0, res=None, res_div=1, res_ids=None,
+           res_pe=None, res_period=0, gate_scale=None, ln=None, ln_eps=1e-5):
+    """C = epilogue(A . W^T + bias) -- see ``lime_linear_f32`` in include/lime_hip.h.
+
+    a: [M, K] (or the [V, K] table when a_ids is given, M = len(a_ids)); w: [N, K]; out: [M, N] (may be a view).
+    ln: (gamma, beta) for the fused LayerNorm; gate_scale: [M] for the gated-residual epilogue.
+    """
+    lib = _lib.load()
+    _mat(a, 'a')
+    _mat(w, 'w')
+    N, K = w.shape
+    if a.shape[1] != K:
+        raise ValueError('a has %d columns, w has K=%d' % (a.shape[1], K))
+    if a_ids is not None:
+        _vec(a_ids, 'a_ids', dtype=torch.int32)
+        M = a_ids.numel()
+    else:
+        M = a.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _mat(out, 'out')
+    if tuple(out.shape) != (M, N):
+        raise ValueError('out must be [%d, %d], got %s' % (M, N, tuple(out.shape)))
+    args = LinearArgs()
+    args.a, args.lda = a.data_ptr(), _ld(a)
+    args.a_ids = a_ids.data_ptr() if a_ids is not None else None
+    if a_pe is not None:
+        _mat(a_pe, 'a_pe')
+        if a_pe.shape[1] != K or a_pe.shape[0] < a_period or a_period <= 0:
+            raise ValueError('a_pe must be [>=a_period, K]')
+        args.a_pe, args.lda_pe, args.a_period = a_pe.data_ptr(), _ld(a_pe), a_period
+    args.w, args.ldw = w.data_ptr(), _ld(w)
+    args.bias = _vec(bias, 'bias', N).data_ptr() if bias is not None else None
+    if res is not None:
+        _mat(res, 'res')
+        if res.shape[1] != N:
+            raise ValueError('res must have N=%d columns' % N)
+        args.res, args.ldr, args.res_div = res.data_ptr(), _ld(res), res_div
+        if res_ids is not None:
+            _vec(res_ids, 'res_ids', M, dtype=torch.int32)
+            args.res_ids = res_ids.data_ptr()
+            if res_pe is not None:
+                _mat(res_pe, 'res_pe')
+                if res_pe.shape[1] != N or res_pe.shape[0] < res_period or res_period <= 0:
+                    raise ValueError('res_pe must be [>=res_period, N]')
+                args.res_pe, args.ldr_pe, args.res_period = res_pe.data_ptr(), _ld(res_pe), res_period
+        elif res.shape[0] * res_div < M:
+            raise ValueError('res has %d rows, needs >= %d' % (res.shape[0], (M + res_div - 1) // res_div))
+    if gate_scale is not None:
+        args.gate_scale, args.gate = _vec(gate_scale, 'gate_scale', M).data_ptr(), 1
+    if ln is not None:
+        args.ln_gamma = _vec(ln[0], 'ln gamma', N).data_ptr()
+        args.ln_beta = _vec(ln[1], 'ln beta', N).data_ptr()
+        args.ln_eps = ln_eps
+    args.c, args.ldc = out.data_ptr(), _ld(out)
+    args.M, args.N, args.K = M, N, K
+    args.act = LIME_ACT[act]
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.lime_linear_f32(ctypes.byref(args), _stream()), 'lime_linear_f32')
+        e1.record()
+        PROFILE.append((_linear_variant(M, N, K, ln is not None, a, w, a_pe), M, N, K, e0, e1))
+        return out
+    check(lib.lime_linear_f32(ctypes.byref(args), _stream()), 'lime_linear_f32')
+    return out
+
+
+def embed_pe(ids, table, pe=None, period=0, out=None):
+    """out[r] = table[ids[r]] + pe[r % period]; ids int32 [rows]."""
+    lib = _lib.load()
+    _vec(ids, 'ids', dtype=torch.int32)
+    _mat(table, 'table')
+    rows, dim = ids.numel(), table.shape[1]
+    if out is None:
+        out = torch.empty((rows, dim), dtype=torch.float32, device=table.device)
+    _mat(out, 'out')
+    if pe is not None:
+        _mat(pe, 'pe')
+    check(lib.lime_embed_pe_f32(_p(ids), _p(table), _ld(table), _p(pe), _ld(pe) if pe is not None else 0, period, _p(out),
+                                _ld(out), rows, dim, _stream()), 'lime_embed_pe_f32')
+    return out
+
+
+def token_attention(q, k, v, n_seq, S, n_head, head_dim, scale, key_mask=None, out=None):
+    """softmax(Q K^T * scale [+mask]) V per (sequence, head); q/k/v: [n_seq*S, n_head*head_dim] views of one pitch."""
+    lib = _lib.load()
+    for t, n in ((q, 'q'), (k, 'k'), (v, 'v')):
+        _mat(t, n)
+        if tuple(t.shape) != (n_seq * S, n_head * head_dim):
+            raise ValueError('%s must be [%d, %d]' % (n, n_seq * S, n_head * head_dim))
+    if not (_ld(q) == _ld(k) == _ld(v)):
+        raise ValueError('q, k and v must share one leading dimension')
+    if out is None:
+        out = torch.empty((n_seq * S, n_head * head_dim), dtype=torch.float32, device=q.device)
+    _mat(out, 'out')
+    m = _mask_u8(key_mask, 'key_mask')
+    if m is not None and m.numel() != n_seq * S:
+        raise ValueError('key_mask must have n_seq * S elements')
+    check(lib.lime_token_attention_f32(_p(q), _p(k), _p(v), _ld(q), _p(m), _p(out), _ld(out), n_seq, S, n_head, head_dim,
+                                       scale, _stream()), 'lime_token_attention_f32')
+    return out
+
+
+def mean_pool(x, n_seq, S, out=None):
+    lib = _lib.load()
+    _mat(x, 'x')
+    if x.shape[0] != n_seq * S:
+        raise ValueError('x must have n_seq * S rows')
+    dim = x.shape[1]
+    if out is None:
+        out = torch.empty((n_seq, dim), dtype=torch.float32, device=x.device)
+    _mat(out, 'out')
+    check(lib.lime_mean_pool_f32(_p(x), _ld(x), _p(out), _ld(out), n_seq, S, dim, _stream()), 'lime_mean_pool_f32')
+    return out
+
+
+def bucketize(x):
+    """int32 lifetime buckets (newsEncoders.py:53-58), bit-exact by threshold comparison."""
+    lib = _lib.load()
+    x = _vec(x.contiguous(), 'x')
+    out = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+    check(lib.lime_bucketize_f32(_p(x), _p(out), x.numel(), _stream()), 'lime_bucketize_f32')
+    return out
+
+
+def gather_rows(idx, table, out):
+    lib = _lib.load()
+    _vec(idx, 'idx', dtype=torch.int32)
+    _mat(table, 'table')
+    _mat(out, 'out')
+    if out.shape[0] != idx.numel() or out.shape[1] != table.shape[1]:
+        raise ValueError('out must be [len(idx), table.shape[1]]')
+    check(lib.lime_gather_rows_f32(_p(idx), _p(table), _ld(table), _p(out), _ld(out), idx.numel(), table.shape[1], _stream()),
+          'lime_gather_rows_f32')
+    return out
+
+
+def topic_rep(cat, sub, cat_table, sub_table, w=None, bias=None, out=None, emb_out=None):
+    """category_affine(cat[cat_emb, sub_emb]) into ``out`` and/or the raw embedding pair into ``emb_out``."""
+    lib = _lib.load()
+    _vec(cat, 'cat', dtype=torch.int32)
+    _vec(sub, 'sub', cat.numel(), dtype=torch.int32)
+    _mat(cat_table, 'cat_table')
+    _mat(sub_table, 'sub_table')
+    if not (cat_table.is_contiguous() and sub_table.is_contiguous()):
+        raise ValueError('embedding tables must be contiguous')
+    rows, dc, ds = cat.numel(), cat_table.shape[1], sub_table.shape[1]
+    dout = 0
+    if w is not None:
+        _mat(w, 'w')
+        if not w.is_contiguous() or w.shape[1] != dc + ds:
+            raise ValueError('w must be contiguous [dout, dc + ds]')
+        dout = w.shape[0]
+        if out is None:
+            out = torch.empty((rows, dout), dtype=torch.float32, device=cat.device)
+        _mat(out, 'out')
+        if tuple(out.shape) != (rows, dout):
+            raise ValueError('out must be [rows, dout]')
+        _vec(bias, 'bias', dout)
+    if emb_out is not None:
+        _mat(emb_out, 'emb_out')
+        if tuple(emb_out.shape) != (rows, dc + ds):
+            raise ValueError('emb_out must be [rows, dc + ds]')
+    check(lib.lime_topic_rep_f32(_p(cat), _p(sub), _p(cat_table), _p(sub_table), dc, ds, _p(w), _p(bias), dout,
+                                 _p(out) if w is not None else None, _ld(out) if w is not None else 0, _p(emb_out),
+                                 _ld(emb_out) if emb_out is not None else 0, rows, _stream()), 'lime_topic_rep_f32')
+    return out
+
+
+def intent_fuse(intents, att_hidden, affine2_t, affine2_b, content, M, k, D, A):
+    """intents [2*M*k, D], att_hidden [2*M*k, A] contiguous; writes content[:, :2D] (content may be a view)."""
+    lib = _lib.load()
+    _mat(intents, 'intents')
+    _mat(att_hidden, 'att_hidden')
+    if not (intents.is_contiguous() and att_hidden.is_contiguous()):
+        raise ValueError('intents / att_hidden must be contiguous')
+    if tuple(intents.shape) != (2 * M * k, D) or tuple(att_hidden.shape) != (2 * M * k, A):
+        raise ValueError('intents / att_hidden have the wrong shape')
+    _mat(content, 'content')
+    if content.shape[0] != M or content.shape[1] < 2 * D:
+        raise ValueError('content must be [M, >= 2D]')
+    check(lib.lime_intent_fuse_f32(_p(intents), _p(att_hidden), _p(_vec(affine2_t, 'affine2_t', A)),
+                                   _p(_vec(affine2_b, 'affine2_b', A)), _p(content), _ld(content), M, k, D, A, _stream()),
+          'lime_intent_fuse_f32')
+    return content
+
+
+def additive_pool(hidden, affine2, x, n_seq, S, mask=None, out=None):
+    lib = _lib.load()
+    _mat(hidden, 'hidden')
+    _mat(x, 'x')
+    A, D = hidden.shape[1], x.shape[1]
+    if hidden.shape[0] != n_seq * S or x.shape[0] != n_seq * S:
+        raise ValueError('hidden and x must have n_seq * S rows')
+    if out is None:
+        out = torch.empty((n_seq, D), dtype=torch.float32, device=x.device)
+    _mat(out, 'out')
+    m = _mask_u8(mask, 'mask')
+    check(lib.lime_additive_pool_f32(_p(hidden), _ld(hidden), _p(_vec(affine2, 'affine2', A)), A, _p(x), _ld(x), D, _p(m),
+                                     _p(out), _ld(out), n_seq, S, _stream()), 'lime_additive_pool_f32')
+    return out
+
+
+def cand_attn_weights(qp, kp, mask, B, N, H, D, n_head):
+    lib = _lib.load()
+    _vec(qp, 'qp', B * N * D)
+    _vec(kp, 'kp', B * H * D)
+    m = _mask_u8(mask, 'mask')
+    if m.numel() != B * H:
+        raise ValueError('mask must be [B, H]')
+    agg = torch.empty((B, H), dtype=torch.float32, device=qp.device)
+    check(lib.lime_cand_attn_weights_f32(_p(qp), _p(kp), _p(m), _p(agg), B, N, H, D, n_head, _stream()),
+          'lime_cand_attn_weights_f32')
+    return agg
+
+
+def sage_mean(hist, user_nodes, B, H, n_src, D):
+    lib = _lib.load()
+    _vec(hist, 'hist', B * H * D)
+    _vec(user_nodes, 'user_nodes')
+    n_user = user_nodes.numel() // D
+    out = torch.empty((B, D), dtype=torch.float32, device=hist.device)
+    check(lib.lime_sage_mean_f32(_p(hist), _p(user_nodes), _p(out), B, H, n_user, n_src, D, _stream()), 'lime_sage_mean_f32')
+    return out
+
+
+def interest_match(kp, qp, g, cand, remaining, B, N, H, A, D, scale, alpha, beta, use_weight, use_penalty, want_logits=True,
+                   want_user=True):
+    lib = _lib.load()
+    _vec(kp, 'kp', B * H * A)
+    _vec(qp, 'qp', B * N * A)
+    _vec(g, 'g', B * H * D)
+    _vec(cand, 'cand', B * N * D)
+    if want_logits and use_weight:
+        remaining = _vec(remaining.contiguous(), 'remaining', B * N)
+    user = torch.empty((B, N, D), dtype=torch.float32, device=kp.device) if want_user else None
+    logits = torch.empty((B, N), dtype=torch.float32, device=kp.device) if want_logits else None
+    check(lib.lime_interest_match_f32(_p(kp), _p(qp), _p(g), _p(cand), _p(remaining) if want_logits and use_weight else None,
+                                      _p(user), _p(logits), B, N, H, A, D, scale, alpha, beta, int(use_weight),
+                                      int(use_penalty), _stream()), 'lime_interest_match_f32')
+    return user, logits
+
+
+def lifetime_score(user, news, remaining, alpha, beta, use_weight, use_penalty):
+    lib = _lib.load()
+    D = user.shape[-1]
+    user = _vec(user.contiguous(), 'user')
+    news = _vec(news.contiguous(), 'news', user.numel())
+    rows = user.numel() // D
+    if use_weight:
+        remaining = _vec(remaining.contiguous(), 'remaining', rows)
+    logits = torch.empty(user.shape[:-1], dtype=torch.float32, device=user.device)
+    check(lib.lime_lifetime_score_f32(_p(user), _p(news), _p(remaining) if use_weight else None, _p(logits), rows, D, alpha,
+                                      beta, int(use_weight), int(use_penalty), _stream()), 'lime_lifetime_score_f32')
+    return logits
+
+
+def row_scale(x, scale):
+    lib = _lib.load()
+    D = x.shape[-1]
+    x = _vec(x.contiguous(), 'x')
+    rows = x.numel() // D
+    scale = _vec(scale.contiguous(), 'scale', rows)
+    out = torch.empty_like(x)
+    check(lib.lime_row_scale_f32(_p(x), _p(scale), _p(out), rows, D, _stream()), 'lime_row_scale_f32')
+    return out
+
+
+def inv_sqrt(x):
+    return 1.0 / math.sqrt(float(x))

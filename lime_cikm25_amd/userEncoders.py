@@ -1,0 +1,147 @@
+"""Drop-in CROWN user encoder of the scoring path (reference userEncoders.py:16-175)."""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .layers import CandidateAware_ClickedNewsAttention
+
+
+class SAGEConv(nn.Module):
+    """Parameter holder with PyG's SAGEConv names: ``lin_l`` (bias) on the aggregate, ``lin_r`` (no bias) on the root."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.lin_l = nn.Linear(in_channels, out_channels, bias=True)
+        self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
+
+
+class GraphSAGE(nn.Module):
+    """``torch_geometric.nn.GraphSAGE(in, hidden, num_layers=1, out_channels=...)`` as the reference constructs it
+    (userEncoders.py:54-58): one SAGEConv, nothing after it.  PyG is an absent, un-versioned dependency; the
+    aggregation is restated from its documented semantics (parity unpinned at this boundary)."""
+
+    def __init__(self, in_channels, hidden_channels, num_layers, out_channels=None, dropout=0.0):
+        super().__init__()
+        if num_layers != 1:
+            raise NotImplementedError('the reference uses num_layers = 1 (userEncoders.py:56)')
+        self.convs = nn.ModuleList([SAGEConv(in_channels, out_channels or hidden_channels)])
+
+    def forward_closed_form(self, hist, user_nodes, n_src):
+        """hist [B, H, D] (node slots 0..H-1 of every row), user_nodes [n_user, D] (slots H..), n_src = rows per forward.
+
+        create_bipartite_graph (userEncoders.py:91-98) yields edges (u -> i) for u < n_src, i < H applied along the node
+        axis of each row, so  out[b, i] = lin_l(mean_{u < n_src} X[b, u]) + lin_r(X[b, i])  for the H history slots that
+        survive the slice at :157.
+        """
+        B, H, D = hist.shape
+        conv = self.convs[0]
+        flat = hist.reshape(B * H, D)
+        m = ops.sage_mean(flat, user_nodes.contiguous(), B, H, n_src, D)
+        l = ops.linear(m, conv.lin_l.weight, conv.lin_l.bias)
+        g = ops.linear(flat, conv.lin_r.weight, None, res=l, res_div=H)
+        return g.view(B, H, D)
+
+
+class _NoParams(nn.Module):
+    """LightGCN / LGConv are constructed and never called by the reference (userEncoders.py:59-62); they hold no
+    checkpoint entries."""
+
+
+class UserEncoder(nn.Module):
+    def __init__(self, news_encoder, config):
+        super().__init__()
+        self.news_embedding_dim = news_encoder.news_embedding_dim
+        self.news_encoder = news_encoder
+        self.device = torch.device('cuda')
+        self.auxiliary_loss = None
+        self.word_embedding_dim = config.word_embedding_dim
+        self.batch_size = config.batch_size
+
+
+class CROWN(UserEncoder):
+    """userEncoders.py:49-175: history encoding -> candidate-aware clicked-news attention -> GraphSAGE step ->
+    history-vs-candidate attention.  ``forward`` keeps the reference's 18-argument signature."""
+
+    def __init__(self, news_encoder, config):
+        super().__init__(news_encoder, config)
+        self.attention_dim = config.attention_dim
+        self.graph_sage = GraphSAGE(in_channels=self.news_embedding_dim, hidden_channels=self.news_embedding_dim, num_layers=1,
+                                    out_channels=self.news_embedding_dim, dropout=config.dropout_rate)
+        self.lightgcn = _NoParams()
+        self.lgconv = _NoParams()
+        self.user_node_embedding = nn.Parameter(torch.zeros([config.batch_size, self.news_embedding_dim]))
+        self.K = nn.Linear(self.news_embedding_dim, self.attention_dim, bias=False)
+        self.Q = nn.Linear(self.news_embedding_dim, self.attention_dim, bias=True)
+        self.max_history_num = config.max_history_num
+        self.attention_scalar = math.sqrt(float(self.attention_dim))
+        self.affine = nn.Linear(self.news_embedding_dim, self.news_embedding_dim, bias=True)      # unused upstream (:171)
+        self.dropout_rate = config.dropout_rate
+        self.dropout = nn.Dropout(p=config.dropout_rate, inplace=True)
+        self.dropout_ = nn.Dropout(p=config.dropout_rate, inplace=False)
+        self.use_candidate_aware_attn = config.use_candidate_ware_clicked_news_attention
+        if self.use_candidate_aware_attn:
+            self.candidate_aware_attn = CandidateAware_ClickedNewsAttention(config, news_encoder)
+
+    def initialize(self):
+        nn.init.zeros_(self.user_node_embedding)
+        nn.init.xavier_uniform_(self.K.weight)
+        nn.init.xavier_uniform_(self.Q.weight)
+        nn.init.zeros_(self.Q.bias)
+        nn.init.xavier_uniform_(self.affine.weight, gain=nn.init.calculate_gain('relu'))
+        nn.init.zeros_(self.affine.bias)
+        if self.use_candidate_aware_attn:
+            self.candidate_aware_attn.initialize()
+
+    def _topic(self, category, subCategory):
+        """userEncoders.py:103-105 / :115-117: LIME's own frozen tables + category_affine."""
+        ne = self.news_encoder
+        shape = category.shape
+        cat = category.reshape(-1)
+        sub = subCategory.reshape(-1)
+        cat = cat if cat.dtype == torch.int32 else cat.to(torch.int32)
+        sub = sub if sub.dtype == torch.int32 else sub.to(torch.int32)
+        rep = ops.topic_rep(cat.contiguous(), sub.contiguous(), ne.category_embedding.weight, ne.subCategory_embedding.weight,
+                            ne.category_affine.weight, ne.category_affine.bias)
+        return rep.view(*shape, -1)
+
+    def match(self, history_embedding, category, subCategory, user_category, user_subCategory, user_history_mask,
+              candidate_news_representation, remaining_lifetime=None, weighting=None):
+        """Everything after the history has been encoded (userEncoders.py:103-105, :114-169).
+
+        Returns (user_representation [B, N, D], logits [B, N] or None).  With ``weighting`` (the model's
+        RemainingLifetimeWeighting) the dot-product match and the lifetime weight are fused into the last kernel.
+        """
+        if self.training and self.dropout_rate > 0:
+            raise NotImplementedError('training-mode dropout on user_node_embedding (userEncoders.py:121) is not implemented')
+        B, H, D = history_embedding.shape
+        N = candidate_news_representation.shape[1]
+        cand = candidate_news_representation.contiguous()
+        if self.use_candidate_aware_attn:
+            cand_topic = self._topic(category, subCategory)
+            hist_topic = self._topic(user_category, user_subCategory)
+            history_embedding, _ = self.candidate_aware_attn(history_embedding, hist_topic, cand_topic, mask=user_history_mask)
+        g = self.graph_sage.forward_closed_form(history_embedding, self.user_node_embedding, n_src=B)       # :121,:151-157
+        kp = ops.linear(g.view(B * H, D), self.K.weight, None)                                               # :161
+        qp = ops.linear(cand.view(B * N, D), self.Q.weight, self.Q.bias)                                     # :162
+        w = weighting
+        user, logits = ops.interest_match(
+            kp, qp, g.reshape(-1), cand.reshape(-1), remaining_lifetime, B, N, H, self.attention_dim, D,
+            1.0 / self.attention_scalar,
+            w.alpha if w is not None else 0.0, w.beta if w is not None else 0.0,
+            bool(w.use_remaining_lifetime_weighting) if w is not None else False,
+            bool(w.use_expired_penalty) if w is not None else False,
+            want_logits=w is not None, want_user=True)
+        return user, logits
+
+    def forward(self, user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask,
+                user_content_entity, category, subCategory, user_category, user_subCategory, user_history_mask,
+                user_history_graph, user_history_category_mask, user_history_category_indices, user_embedding,
+                candidate_news_representation, user_freshness, user_user_topic_lifetime):
+        history_embedding = self.news_encoder(user_title_text, user_title_mask, user_title_entity, user_content_text,
+                                              user_content_mask, user_content_entity, user_category, user_subCategory,
+                                              user_embedding, user_freshness, user_user_topic_lifetime)        # :110-112
+        user, _ = self.match(history_embedding, category, subCategory, user_category, user_subCategory, user_history_mask,
+                             candidate_news_representation)
+        return user

@@ -1,0 +1,68 @@
+"""The C-ABI shared library: loads, exports every symbol include/lime_hip.h declares, rejects bad
+arguments before touching the GPU.  No compute calls here (CPU only)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from lime_cikm25_amd import _lib
+from lime_cikm25_amd.build import build_library
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    build_library()
+    return _lib.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'lime_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(lime_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_and_binding_agree(lib):
+    names = declared_symbols()
+    assert len(names) >= 15
+    assert sorted(_lib.SIGNATURES) == names
+    for n in names:
+        assert getattr(lib, n) is not None
+
+
+def test_abi_version(lib):
+    assert lib.lime_abi_version() == 1
+
+
+def test_linear_args_layout_matches_header():
+    # 8-byte pointers / int64 with natural alignment: the ctypes mirror must have the C struct's size
+    assert ctypes.sizeof(_lib.LinearArgs) == 200
+    assert (_lib.LinearArgs.c.offset, _lib.LinearArgs.act.offset, _lib.LinearArgs.ln_eps.offset) == (168, 196, 160)
+
+
+def test_bad_arguments_are_rejected_without_a_launch(lib):
+    assert lib.lime_linear_f32(None, None) == -1
+    assert b'NULL' in lib.lime_last_error_string()
+    a = _lib.LinearArgs()
+    assert lib.lime_linear_f32(ctypes.byref(a), None) == -1
+    assert lib.lime_bucketize_f32(None, None, 4, None) == -1
+    assert lib.lime_token_attention_f32(None, None, None, 0, None, None, 0, 1, 1, 1, 1, 1.0, None) == -1
+    assert lib.lime_sage_mean_f32(None, None, None, 1, 1, 1, 1, 1, None) == -1
+    with pytest.raises(_lib.LimeHipError):
+        _lib.check(-1, 'x')
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_lib.LimeHipError):
+        _lib.load()
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from lime_cikm25_amd import ops
+    with pytest.raises(TypeError):
+        ops.linear(torch.zeros(4, 8), torch.zeros(3, 8))

@@ -1,0 +1,317 @@
+"""Per-kernel parity on the MI355X: every C-ABI entry point against the CPU oracle's functions (or
+a plain fp32 torch-CPU statement where the oracle has no finer-grained function), on seeded inputs.
+Integer results (buckets) must be bit-exact; fp32 results within 1e-3 relative (observed ~1e-6)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err
+from oracle import lime_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3          # the north star's tolerance; the assertions below also print what was observed
+TIGHT = 2e-5        # what exact-fp32 kernels are expected to reach against an fp32 CPU evaluation
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'these tests need the GPU'
+    from lime_cikm25_amd import ops as _ops
+    from lime_cikm25_amd import _lib
+    _lib.load()
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def dev(t):
+    return None if t is None else t.cuda()
+
+
+def check(got, want, tol=TIGHT, what=''):
+    got = got.detach().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert torch.isfinite(got).all(), what
+    e = rel_err(got.numpy(), want.numpy())
+    assert e < tol, '%s: rel err %.3e' % (what, e)
+    return e
+
+
+# ---------------------------------------------------------------------------------------------------
+# lime_linear_f32
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K', [
+    (1, 1, 4), (7, 5, 3), (33, 50, 100), (64, 64, 32), (100, 400, 50), (130, 300, 300), (257, 900, 300), (96, 400, 350),
+    (200, 512, 300), (150, 300, 512), (50, 900, 1000), (77, 400, 1800), (4096, 128, 64), (4100, 900, 300), (5000, 70, 31),
+])
+@pytest.mark.parametrize('act', [None, 'relu', 'tanh', 'sigmoid'])
+def test_linear_plain(ops, M, N, K, act):
+    if act in ('tanh', 'sigmoid') and M > 300:
+        pytest.skip('activation variants covered on the small shapes')
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3)
+    want = a @ w.t() + b
+    want = {'relu': torch.relu, 'tanh': torch.tanh, 'sigmoid': torch.sigmoid, None: lambda x: x}[act](want)
+    got = ops.linear(dev(a), dev(w), dev(b), act=act)
+    check(got, want, what='linear %s' % ((M, N, K, act),))
+
+
+def test_linear_strided_views_and_no_bias(ops):
+    M, N, K = 300, 200, 128
+    big_a, big_w, big_c = rnd(M, K + 40, seed=4), rnd(N, K + 8, seed=5), torch.zeros(M, N + 100)
+    a, w = big_a[:, 8:8 + K], big_w[:, 4:4 + K]
+    want = a @ w.t()
+    ca, cw, cc = dev(big_a), dev(big_w), dev(big_c)
+    ops.linear(ca[:, 8:8 + K], cw[:, 4:4 + K], None, out=cc[:, 60:60 + N])
+    out = cc.cpu()
+    check(out[:, 60:60 + N], want, what='strided')
+    assert (out[:, :60] == 0).all() and (out[:, 60 + N:] == 0).all()
+
+
+@pytest.mark.parametrize('M,S', [(40, 8), (64, 32), (4200, 128)])
+def test_linear_gather_operand_and_residual(ops, M, S):
+    V, E, N = 500, 300, 300
+    rows = M
+    ids = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(6), dtype=torch.int32)
+    table, pe = rnd(V, E, seed=7), rnd(S, E, seed=8)
+    w, b = rnd(N, E, seed=9, scale=0.06), rnd(N, seed=10)
+    x = table[ids.long()] + pe[torch.arange(rows) % S]
+    got = ops.linear(dev(table), dev(w), dev(b), a_ids=dev(ids), a_pe=dev(pe), a_period=S)
+    check(got, x @ w.t() + b, what='gather A')
+    attn = rnd(rows, E, seed=11)
+    g, be = rnd(N, seed=12) + 1.5, rnd(N, seed=13)
+    want = O.layer_norm(x + attn @ w.t() + b, g, be)
+    got = ops.linear(dev(attn), dev(w), dev(b), res=dev(table), res_ids=dev(ids), res_pe=dev(pe), res_period=S,
+                     ln=(dev(g), dev(be)))
+    check(got, want, what='gather residual + LN')
+
+
+@pytest.mark.parametrize('M,N,K', [(70, 300, 512), (129, 400, 400), (5000, 300, 300), (10, 37, 20), (300, 416, 64), (64, 320, 8)])
+def test_linear_residual_layernorm(ops, M, N, K):
+    a, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3), rnd(M, N, seed=4)
+    g, be = rnd(N, seed=5) + 1.5, rnd(N, seed=6)
+    want = O.layer_norm(r + a @ w.t() + b, g, be)
+    got = ops.linear(dev(a), dev(w), dev(b), res=dev(r), ln=(dev(g), dev(be)))
+    check(got, want, what='res + LN')
+    want2 = O.layer_norm(torch.relu(a @ w.t() + b), g, be)
+    check(ops.linear(dev(a), dev(w), dev(b), act='relu', ln=(dev(g), dev(be))), want2, what='relu + LN')
+
+
+def test_linear_broadcast_residual(ops):
+    B, H, D = 7, 13, 400
+    a, w, l = rnd(B * H, D, seed=1), rnd(D, D, seed=2, scale=0.05), rnd(B, D, seed=3)
+    want = a @ w.t() + l.repeat_interleave(H, dim=0)
+    check(ops.linear(dev(a), dev(w), None, res=dev(l), res_div=H), want, what='res_div')
+
+
+def test_linear_gated_residual_layernorm(ops):
+    """layers.py:84-89 as one epilogue."""
+    R, D = 130, 400
+    x, w, b = rnd(R, D, seed=1), rnd(D, D, seed=2, scale=0.05), rnd(D, seed=3)
+    s = torch.rand(R, generator=torch.Generator().manual_seed(4))
+    g, be = rnd(D, seed=5) + 1.5, rnd(D, seed=6)
+    wc = s[:, None] * x
+    gate = torch.sigmoid(wc @ w.t() + b)
+    want = O.layer_norm(gate * wc + (1 - gate) * x, g, be)
+    got = ops.linear(dev(x), dev(w), dev(b), res=dev(x), gate_scale=dev(s), ln=(dev(g), dev(be)))
+    check(got, want, what='gate')
+
+
+def test_linear_rejects_bad_shapes(ops):
+    from lime_cikm25_amd._lib import LimeHipError
+    a, w = dev(rnd(8, 16)), dev(rnd(4, 16))
+    with pytest.raises(ValueError):
+        ops.linear(a, dev(rnd(4, 12)))
+    with pytest.raises(LimeHipError):
+        ops.linear(dev(rnd(8, 500)), dev(rnd(500, 500)), ln=(dev(rnd(500)), dev(rnd(500))))      # LN needs N <= 416
+
+
+# ---------------------------------------------------------------------------------------------------
+# token attention
+# ---------------------------------------------------------------------------------------------------
+def attn_ref(qkv, n_seq, S, h, hd, scale, mask=None):
+    E = h * hd
+    q, k, v = [t.view(n_seq, S, h, hd).transpose(1, 2) for t in qkv.split(E, dim=1)]
+    a = (q * scale) @ k.transpose(-2, -1)
+    if mask is not None:
+        a = a.masked_fill(mask.view(n_seq, 1, 1, S) == 0, -1e9)
+    return (torch.softmax(a, dim=-1) @ v).transpose(1, 2).reshape(n_seq * S, E)
+
+
+@pytest.mark.parametrize('S', [1, 8, 16, 31, 32, 33, 64, 96, 100, 128, 160, 256, 512])
+@pytest.mark.parametrize('h,hd', [(10, 30), (10, 20), (3, 32)])
+def test_token_attention(ops, S, h, hd):
+    n_seq = 5 if S <= 128 else 2
+    E = h * hd
+    qkv = rnd(n_seq * S, 3 * E, seed=S, scale=2.0)
+    scale = 1.0 / math.sqrt(hd)
+    d = dev(qkv)
+    got = ops.token_attention(d[:, :E], d[:, E:2 * E], d[:, 2 * E:], n_seq, S, h, hd, scale)
+    check(got, attn_ref(qkv, n_seq, S, h, hd, scale), what='attn S=%d' % S)
+
+
+@pytest.mark.parametrize('S', [16, 32, 48])
+def test_token_attention_key_mask(ops, S):
+    n_seq, h, hd = 6, 10, 20
+    E = h * hd
+    qkv = rnd(n_seq * S, 3 * E, seed=S + 1, scale=2.0)
+    lens = torch.tensor([1, S, S // 2, 3, S - 1, 0])          # a fully masked row softmaxes to uniform, as in the reference
+    mask = torch.arange(S)[None, :] < lens[:, None]
+    d = dev(qkv)
+    got = ops.token_attention(d[:, :E], d[:, E:2 * E], d[:, 2 * E:], n_seq, S, h, hd, 1 / math.sqrt(hd), key_mask=dev(mask))
+    check(got, attn_ref(qkv, n_seq, S, h, hd, 1 / math.sqrt(hd), mask), what='masked attn')
+
+
+def test_encoder_layer_matches_oracle(ops):
+    """The five-launch encoder layer against oracle.encoder_layer (newsEncoders.py:244-247,311-321)."""
+    from lime_cikm25_amd import newsEncoders
+    M, S, E, V = 9, 32, 300, 700
+    tr = torch.nn.TransformerEncoder(torch.nn.TransformerEncoderLayer(E, 10, 512, 0.0, batch_first=True), 1)
+    for i, (name, p) in enumerate(tr.named_parameters()):
+        p.data = rnd(*p.shape, seed=100 + i, scale=0.08 if p.dim() == 2 else 0.3)
+        if 'norm' in name and name.endswith('weight'):
+            p.data += 1.2
+    ids = torch.randint(0, V, (M, S), generator=torch.Generator().manual_seed(1), dtype=torch.int32)
+    table, pe = rnd(V, E, seed=2, scale=0.6), O.positional_encoding(S, E)
+    sd = {'l.' + k: v for k, v in tr.layers[0].state_dict().items()}
+    want = O.encoder_layer(table[ids.long()] + pe, sd, 'l.', 10).reshape(M * S, E)
+    got = newsEncoders.encode_tokens(dev(ids), dev(table), dev(pe), tr.cuda(), 10)
+    check(got, want, what='encoder layer')
+    pooled = ops.mean_pool(got, M, S)
+    check(pooled, want.view(M, S, E).mean(dim=1), what='mean pool')
+
+
+# ---------------------------------------------------------------------------------------------------
+# small kernels
+# ---------------------------------------------------------------------------------------------------
+def test_embed_pe(ops):
+    V, E, S, rows = 900, 300, 32, 32 * 41
+    ids = torch.randint(0, V, (rows,), generator=torch.Generator().manual_seed(1), dtype=torch.int32)
+    table, pe = rnd(V, E, seed=2), rnd(S, E, seed=3)
+    want = table[ids.long()] + pe[torch.arange(rows) % S]
+    got = ops.embed_pe(dev(ids), dev(table), dev(pe), S).cpu()
+    assert torch.equal(got, want)                                       # one add: bit-exact
+    assert torch.equal(ops.embed_pe(dev(ids), dev(table)).cpu(), table[ids.long()])
+    t2 = rnd(V, 50, seed=4)                                             # dim % 4 != 0 -> scalar path
+    assert torch.equal(ops.embed_pe(dev(ids), dev(t2)).cpu(), t2[ids.long()])
+
+
+def test_bucketize_bit_exact(ops):
+    cuts = np.array(O.BUCKET_THRESHOLD_BITS, dtype=np.uint32)
+    edge = np.concatenate([(cuts - 2), (cuts - 1), cuts, (cuts + 1)]).view(np.float32)
+    rng = np.random.default_rng(0)
+    x = np.concatenate([edge, np.exp(rng.uniform(-3, np.log(3e38), 200000)).astype(np.float32),
+                        np.array([0.0, -1.0, 1.0, 0.99999, np.inf, np.nan, 3.4e38, 86400.0], dtype=np.float32)])
+    xt = torch.from_numpy(x)
+    got = ops.bucketize(dev(xt)).cpu()
+    assert got.dtype == torch.int32
+    assert torch.equal(got.long(), O.bucketize(xt))
+    assert got[len(edge) + 200000 + 4].item() == 9 and got[len(edge) + 200000 + 5].item() == 0      # +inf, NaN
+
+
+def test_topic_rep(ops):
+    rows, C, SC, dc = 77, 18, 270, 50
+    g = torch.Generator().manual_seed(1)
+    cat = torch.randint(0, C, (rows,), generator=g, dtype=torch.int32)
+    sub = torch.randint(0, SC, (rows,), generator=g, dtype=torch.int32)
+    ct, st, w, b = rnd(C, dc, seed=2), rnd(SC, dc, seed=3), rnd(dc, 2 * dc, seed=4, scale=0.2), rnd(dc, seed=5)
+    e = torch.cat([ct[cat.long()], st[sub.long()]], dim=1)
+    emb = torch.zeros(rows, 130).cuda()
+    got = ops.topic_rep(dev(cat), dev(sub), dev(ct), dev(st), dev(w), dev(b), emb_out=emb[:, 20:120])
+    check(got, e @ w.t() + b, what='topic rep')
+    assert torch.equal(emb.cpu()[:, 20:120], e)
+
+
+def test_intent_fuse(ops):
+    M, k, D, A = 37, 3, 400, 400
+    intents, hidden = torch.relu(rnd(2 * M * k, D, seed=1)), torch.tanh(rnd(2 * M * k, A, seed=2, scale=2))
+    a2t, a2b = rnd(A, seed=3, scale=0.3), rnd(A, seed=4, scale=0.3)
+    iv, hv = intents.view(2, M, k, D), hidden.view(2, M, k, A)
+    pooled = []
+    for tb, a2 in ((0, a2t), (1, a2b)):
+        alpha = torch.softmax(hv[tb] @ a2, dim=1)
+        pooled.append((alpha.unsqueeze(-1) * iv[tb]).sum(dim=1))
+    s = (torch.nn.functional.cosine_similarity(pooled[0], pooled[1], dim=1) + 1) / 2
+    want = torch.cat([pooled[0], s[:, None] * pooled[1]], dim=1)
+    content = torch.zeros(M, 900).cuda()
+    ops.intent_fuse(dev(intents), dev(hidden), dev(a2t), dev(a2b), content, M, k, D, A)
+    check(content.cpu()[:, :800], want, what='intent fuse')
+    assert (content.cpu()[:, 800:] == 0).all()
+
+
+def test_additive_pool(ops):
+    n_seq, S, A, D = 11, 32, 400, 200
+    hidden, x, a2 = torch.tanh(rnd(n_seq * S, A, seed=1, scale=2)), rnd(n_seq * S, D, seed=2), rnd(A, seed=3, scale=0.3)
+    lens = torch.tensor([1, 32, 5, 0, 17, 32, 31, 2, 9, 12, 30])
+    mask = torch.arange(S)[None, :] < lens[:, None]
+    a = (hidden @ a2).view(n_seq, S).masked_fill(mask == 0, -1e9)
+    want = torch.bmm(torch.softmax(a, dim=1).unsqueeze(1), x.view(n_seq, S, D)).squeeze(1)
+    check(ops.additive_pool(dev(hidden), dev(a2), dev(x), n_seq, S, mask=dev(mask)), want, what='additive pool')
+
+
+@pytest.mark.parametrize('B,N,H', [(5, 5, 50), (3, 1, 10), (4, 2, 70), (2, 20, 130)])
+def test_cand_attn_weights(ops, B, N, H):
+    D, heads = 400, 10
+    qp, kp = rnd(B * N, D, seed=1, scale=3), rnd(B * H, D, seed=2, scale=3)
+    lens = torch.randint(0, H + 1, (B,), generator=torch.Generator().manual_seed(3))
+    lens[0] = 0
+    mask = torch.arange(H)[None, :] < lens[:, None]
+    Q = qp.view(B, N, heads, D // heads).transpose(1, 2)
+    K = kp.view(B, H, heads, D // heads).transpose(1, 2)
+    s = (Q @ K.transpose(-2, -1) / D ** 0.5).masked_fill(mask.view(B, 1, 1, H) == 0, -1e9)
+    a = torch.softmax(s, dim=-1)
+    qw = torch.softmax(torch.norm(qp.view(B, N, D), dim=-1), dim=1)
+    want = torch.softmax((a.sum(dim=1) * qw.unsqueeze(-1)).sum(dim=1), dim=-1)
+    check(ops.cand_attn_weights(dev(qp), dev(kp), dev(mask), B, N, H, D, heads), want, what='cand attn weights')
+
+
+@pytest.mark.parametrize('B,H,n_user,n_src', [(4, 10, 4, 4), (6, 4, 6, 6), (3, 6, 8, 3), (5, 5, 5, 10)])
+def test_sage_mean(ops, B, H, n_user, n_src):
+    D = 400
+    hist, un = rnd(B * H, D, seed=1), rnd(n_user, D, seed=2)
+    X = torch.cat([hist.view(B, H, D), un.unsqueeze(0).expand(B, -1, -1)], dim=1)
+    check(ops.sage_mean(dev(hist), dev(un), B, H, n_src, D), X[:, :n_src].mean(dim=1), what='sage mean')
+
+
+def test_sage_mean_rejects_too_many_sources(ops):
+    from lime_cikm25_amd._lib import LimeHipError
+    with pytest.raises(LimeHipError):
+        ops.sage_mean(dev(rnd(2 * 3, 8)), dev(rnd(2, 8)), 2, 3, 6, 8)
+
+
+@pytest.mark.parametrize('B,N,H', [(6, 5, 50), (4, 1, 10), (3, 7, 33)])
+@pytest.mark.parametrize('penalty', [True, False])
+def test_interest_match(ops, B, N, H, penalty):
+    A = D = 400
+    kp, qp, g, cand = rnd(B * H, A, seed=1), rnd(B * N, A, seed=2), rnd(B * H, D, seed=3), rnd(B * N, D, seed=4)
+    rem = torch.tensor([0.0, -0.0, 0.5, -0.5, 3.0, -3.0, 40.0, -40.0, 1e5, -1e5, 7.0, -2.0]).repeat(10)[:B * N].view(B, N)
+    a = torch.einsum('bha,bna->bnh', kp.view(B, H, A), qp.view(B, N, A)) / math.sqrt(A)
+    user = torch.softmax(a, dim=-1) @ g.view(B, H, D)
+    cfg = type('C', (), dict(use_remaining_lifetime_weighting=True, use_expired_penalty=penalty, sigmoid_scaling_alpha=0.3,
+                             penalty_scaling_beta=0.3))
+    want = O.remaining_lifetime_weighting(cfg, user, cand.view(B, N, D), rem)
+    u, l = ops.interest_match(dev(kp), dev(qp), dev(g), dev(cand), dev(rem), B, N, H, A, D, 1 / math.sqrt(A), 0.3, 0.3, True,
+                              penalty)
+    check(u, user, what='user rep')
+    check(l, want, what='logits')
+    z = want == 0
+    assert torch.equal(torch.signbit(l.cpu()[z]), torch.signbit(want[z]))          # exact +-0
+    l2 = ops.lifetime_score(dev(user), dev(cand.view(B, N, D)), dev(rem), 0.3, 0.3, True, penalty)
+    check(l2, want, what='lifetime score')
+    l3 = ops.lifetime_score(dev(user), dev(cand.view(B, N, D)), None, 0.3, 0.3, False, penalty)
+    check(l3, (user * cand.view(B, N, D)).sum(-1), what='plain dot')
+
+
+def test_row_scale_and_gather_rows(ops):
+    x, s = rnd(50, 400, seed=1), rnd(50, seed=2)
+    assert torch.equal(ops.row_scale(dev(x), dev(s)).cpu(), x * s[:, None])
+    table = rnd(10, 500, seed=3)
+    idx = torch.randint(0, 10, (64,), generator=torch.Generator().manual_seed(4), dtype=torch.int32)
+    out = torch.zeros(64, 1000).cuda()
+    ops.gather_rows(dev(idx), dev(table), out[:, 500:])
+    assert torch.equal(out.cpu()[:, 500:], table[idx.long()])
