@@ -150,7 +150,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import lime_oracle
-            ncore = os.cpu_count() or 1
+            # the GPU box gives one GPU's share of the host: 16 cores (more threads only oversubscribe)
+            ncore = min(len(os.sched_getaffinity(0)), 16)
             torch.set_num_threads(ncore)
             n_warm, n_timed = 1, 3
             for _ in range(n_warm):
