@@ -47,8 +47,7 @@ enum { LIME_ACT_NONE = 0, LIME_ACT_RELU = 1, LIME_ACT_TANH = 2, LIME_ACT_SIGMOID
  * Replaces every nn.Linear on the path, with the surrounding element-wise work fused:
  *   in_proj / out_proj / linear1 / linear2 of the two TransformerEncoderLayers (newsEncoders.py:244-247,316,320),
  *   intent_layers (newsEncoders.py:284-295), Attention.affine1 (layers.py:288), FreshnessEncoder.dense
- *   (newsEncoders.py:82), LIME.project (newsEncoders.py:152-153), gate_proj + gated residual + LayerNorm
- *   (layers.py:84-89), SAGEConv lin_l / lin_r (userEncoders.py:153), K / Q (userEncoders.py:161-162),
+ *   (newsEncoders.py:82), LIME.project (newsEncoders.py:152-153), gate_proj (layers.py:87), SAGEConv lin_l / lin_r (userEncoders.py:153), K / Q (userEncoders.py:161-162),
  *   MultiHeadAttention W_Q/W_K/W_V (layers.py:224-226).
  *
  * A operand, row r (0 <= r < M), K columns:
@@ -63,9 +62,8 @@ enum { LIME_ACT_NONE = 0, LIME_ACT_RELU = 1, LIME_ACT_TANH = 2, LIME_ACT_SIGMOID
  *   v += residual(r, n)                                  (res may be NULL)
  *        res_ids == NULL : res[(r / res_div) * ldr + n]   (res_div >= 1; > 1 broadcasts one row to res_div rows)
  *        res_ids != NULL : res[res_ids[r] * ldr + n] (+ res_pe[(r % res_period) * ldr_pe + n])
- *   gate != 0 (layers.py:84-89):  with s = gate_scale[r], x = res(r, n) taken BEFORE the add above,
- *        g = sigmoid(s * acc + bias[n]);  v = g * (s * x) + (1 - g) * x   (act and the plain add are skipped)
- *   ln_gamma != NULL : v = LayerNorm over the N columns of row r (eps = ln_eps), requires N <= 416
+ *   ln_gamma != NULL : v = LayerNorm over the N columns of row r (eps = ln_eps); requires N <= 320 and either no
+ *        activation (residual allowed) or ReLU without residual
  *   c[r * ldc + n] = v
  * lda/ldw/ldr/ldc are in elements.
  */
@@ -76,7 +74,6 @@ typedef struct {
     const float* bias;
     const float* res;     int64_t ldr;   int32_t res_div;
     const int32_t* res_ids; const float* res_pe; int64_t ldr_pe; int32_t res_period;
-    const float* gate_scale; int32_t gate;
     const float* ln_gamma; const float* ln_beta; float ln_eps;
     float* c;             int64_t ldc;
     int32_t M, N, K;
@@ -156,6 +153,15 @@ int lime_additive_pool_f32(const float* hidden, int64_t ldh, const float* affine
  */
 int lime_cand_attn_weights_f32(const float* qp, const float* kp, const uint8_t* mask, float* agg, int32_t B, int32_t N,
                                int32_t H, int32_t D, int32_t n_head, void* stream);
+
+/*
+ * lime_gate_ln_f32: the gated residual + LayerNorm of CandidateAware_ClickedNewsAttention (layers.py:84-89), one
+ * workgroup per history row.  y = gate_proj.weight . x (no bias, from lime_linear_f32), s = agg[row]:
+ *   g = sigmoid(s * y + bias);  v = g * (s * x) + (1 - g) * x;  out = LayerNorm(v) * gamma + beta
+ * (gate_proj(s * x) = s * (W x) + b: the row scale commutes with the projection).  x, y, out: [rows, D] contiguous.
+ */
+int lime_gate_ln_f32(const float* y, const float* x, const float* scale, const float* bias, const float* gamma,
+                     const float* beta, float eps, float* out, int64_t rows, int32_t D, void* stream);
 
 /*
  * lime_sage_mean_f32: m[b, :] = mean over the first n_src node slots of row b of cat[hist[b] (H rows),

@@ -22,7 +22,6 @@ class LinearArgs(Structure):
         ('bias', c_void_p),
         ('res', c_void_p), ('ldr', c_int64), ('res_div', c_int32),
         ('res_ids', c_void_p), ('res_pe', c_void_p), ('ldr_pe', c_int64), ('res_period', c_int32),
-        ('gate_scale', c_void_p), ('gate', c_int32),
         ('ln_gamma', c_void_p), ('ln_beta', c_void_p), ('ln_eps', c_float),
         ('c', c_void_p), ('ldc', c_int64),
         ('M', c_int32), ('N', c_int32), ('K', c_int32),
@@ -49,6 +48,8 @@ SIGNATURES = {
                                          c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     'lime_cand_attn_weights_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                              c_int32, c_void_p]),
+    'lime_gate_ln_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64,
+                                   c_int32, c_void_p]),
     'lime_sage_mean_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'lime_interest_match_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                           c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_int32, c_int32,

@@ -4,19 +4,27 @@
 // of reference call sites).  Design, MI355X-first:
 //   * v_mfma_f32_32x32x2_f32 (64 cycles / SIMD, bit-exact fp32 fma chain) -- the path's tolerance is
 //     1e-3 against an fp32 CPU forward, and gfx950 has no xf32/TF32 mode, so the fp32 roof is the
-//     157 TFLOP/s matrix rate, 16x below bf16.  At that rate one ds_read_b128 feeds four MFMAs, so the
-//     kernel is paced by MFMA issue as long as operands arrive: LDS double buffer, global->register
-//     prefetch of chunk t+1 issued before the MFMAs of chunk t, one barrier per 32-deep K chunk.
+//     157 TFLOP/s matrix rate, 16x below bf16.  At that rate one ds_read_b128 feeds four MFMAs and
+//     LDS / L2 bandwidth are far from binding; what binds is keeping the MFMA pipe issued.
+//   * the K loops of this path are short (K = 300 ... 512: 10 ... 16 chunks of 32), so a one-tile-per-
+//     workgroup kernel spends a third of its life in prologue / epilogue latency (measured: 65 TF).
+//     The kernel is therefore PERSISTENT: a workgroup walks output tiles t, t + G, t + 2G ... as one
+//     continuous stream of K chunks -- the global->register prefetch of the next chunk (which may
+//     belong to the next tile) is always issued before the MFMAs of the current one, the epilogue's
+//     stores retire under the next tile's MFMAs, and the residual operand is loaded straight into
+//     the accumulators at the tile boundary instead of being fetched row by row in the epilogue.
 //   * both operands are K-contiguous row-major ([rows][K]: activations and nn.Linear weights as
 //     stored), staged as [rows][36] fp32 so that a wave's ds_read_b128 (16-lane groups, 64 banks) is
 //     conflict free; lane (i, h) fetches k = 8s+4h .. 8s+4h+3 and the four MFMAs of step s pair the
-//     same k on both operands (the MFMA's k index is only a summation label).
+//     same k on both operands (the MFMA's k index is only a summation label).  Fragments of step
+//     s + 1 are read while the MFMAs of step s execute.
 //   * the word-embedding gather + positional table is fused into the A fetch (and into the residual
 //     of the out_proj epilogue), bias / ReLU / tanh / residual / gated residual / LayerNorm into the
 //     epilogue, so the encoder layer's activations cross HBM once per GEMM, not once per op.
-//   * 1-D grid, XCD-aware bijective remap: an XCD walks whole row panels, so the N-tiles that re-read
-//     one A panel hit the same 4 MiB L2.
+//   * XCD-aware bijective remap of the workgroup id: an XCD walks whole row panels, so the N-tiles that
+//     re-read one A panel hit the same 4 MiB L2.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -27,10 +35,10 @@ struct GemmP {
     const float* a; long lda; const int* a_ids; const float* a_pe; long lda_pe; int a_period;
     const float* w; long ldw; const float* bias;
     const float* res; long ldr; int res_div; const int* res_ids; const float* res_pe; long ldr_pe; int res_period;
-    const float* gate_scale; int gate;
     const float* ln_g; const float* ln_b; float ln_eps;
     float* c; long ldc; int M, N, K; int act;
     int n_row_blocks, n_col_blocks;
+    int res_in_acc;      // residual is loaded into the accumulators at the tile boundary (plain add, no act, no gate)
 };
 
 template <int VEC> struct VecT;
@@ -52,215 +60,434 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-// TM x TN MFMA tiles (32x32) per wave, WM x WN waves per workgroup (WM * WN == 4).
-// ROWFULL: the workgroup spans every output column (WN == 1, n_col_blocks == 1) -> LayerNorm in the epilogue.
-template <int TM, int TN, int WM, int WN, int VEC, bool ROWFULL>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
+// ---- buffer addressing ----------------------------------------------------------------------------------
+// Every global access goes through a buffer descriptor: a wave-uniform base (SGPRs) plus a 32-bit lane offset,
+// so a row costs one VGPR instead of a 64-bit pointer pair, and an out-of-range offset reads as zero / drops
+// the store in hardware -- rows beyond M, columns beyond N and k beyond K need no select and no branch.
+constexpr unsigned OOB = 0x80000000u;          // >= num_records of every descriptor below
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFF0, 0x00020000);
+}
+template <int VEC>
+__device__ __forceinline__ typename VecT<VEC>::T buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    if constexpr (VEC == 4) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    else if constexpr (VEC == 2) return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
+// TM x TN MFMA tiles (32x32) per wave, WM x WN waves per workgroup (4 or 8 waves).
+// LN:  a tile spans every output column (n_col_blocks == 1) and the epilogue applies LayerNorm; with WN > 1 the row
+//      statistics are combined across the WN waves that share a row through a small LDS exchange.
+// PE:  the A operand is a gather with a positional table added (a_ids and a_pe both set).
+// ACT / RES: compile-time epilogue of the big tiles (activation none / ReLU; residual preloaded into the accumulators),
+//      so that the accumulator array only ever sees straight-line code.
+// GENERIC: small tiles -- activation, residual placement and gate are run-time switches (cheap at 16 accumulators).
+template <int TM, int TN, int WM, int WN, int VEC, bool LN, bool PE, int ACT, bool RES, bool GENERIC>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 1) void gemm_f32_kernel(const GemmP p) {
+    constexpr int NT = WM * WN * 64;       // threads per workgroup
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int TPR = BK / VEC;          // threads per staged row
-    constexpr int RPP = 256 / TPR;         // rows per staging pass
+    constexpr int RPP = NT / TPR;          // rows per staging pass
     constexpr int APASS = BM / RPP, WPASS = BN / RPP;
-    static_assert(WM * WN == 4, "four waves per workgroup");
+    static_assert(WM * WN == 4 || WM * WN == 8, "four or eight waves per workgroup");
     static_assert(BM % RPP == 0 && BN % RPP == 0, "staging passes must tile the block");
     typedef typename VecT<VEC>::T vec_t;
 
     __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
     __shared__ __attribute__((aligned(16))) float Ws[2][BN * LDK];
+    __shared__ float red_sum[(LN && WN > 1) ? WN * BM : 1];     // LayerNorm partials of the WN waves sharing a row
+    __shared__ float red_sq[(LN && WN > 1) ? WN * BM : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int logical = xcd_remap(blockIdx.x, p.n_row_blocks * p.n_col_blocks);
-    const int row_blk = logical / p.n_col_blocks, col_blk = logical - row_blk * p.n_col_blocks;
-    const long row0 = (long)row_blk * BM;
-    const int col0 = col_blk * BN;
+    const int ntiles = p.n_row_blocks * p.n_col_blocks;
+    const int nwg = gridDim.x;
+    const int first = xcd_remap(blockIdx.x, nwg);
+    if (first >= ntiles) return;
+    const int nchunk = (p.K + BK - 1) / BK;
+    const int tail_steps = ((p.K - (nchunk - 1) * BK) + 7) / 8;      // k8 steps of a tile's last chunk (1..4)
+    const int lda4 = (int)p.lda * 4, ldw4 = (int)p.ldw * 4, ldc4 = (int)p.ldc * 4, ldr4 = (int)p.ldr * 4;
+    const bool gather = p.a_ids != nullptr;
 
-    // ---- staging set-up: this thread's rows and k offset inside a chunk ---------------------------
+    auto tile_rc = [&](int tile, long& row0, int& col0) {
+        const int rb = tile / p.n_col_blocks;
+        row0 = (long)rb * BM;
+        col0 = (tile - rb * p.n_col_blocks) * BN;
+    };
+
+    // ---- loader state: the tile whose chunks are being fetched -----------------------------------
+    // Loads carry no arithmetic, so they stay in flight under the MFMAs; the positional add happens when the
+    // registers are committed to LDS.
     const int srow = tid / TPR, sk = (tid % TPR) * VEC;
-    const float* arow[APASS];
-    const float* aperow[APASS];
-#pragma unroll
-    for (int i = 0; i < APASS; ++i) {
-        const long r = row0 + srow + i * RPP;
-        arow[i] = nullptr;
-        aperow[i] = nullptr;
-        if (r < p.M) {
-            if (p.a_ids) {
-                arow[i] = p.a + (long)p.a_ids[r] * p.lda;
-                if (p.a_pe) aperow[i] = p.a_pe + (long)(r % p.a_period) * p.lda_pe;
-            } else {
-                arow[i] = p.a + r * p.lda;
-            }
-        }
-    }
-    const float* wrow[WPASS];
-#pragma unroll
-    for (int i = 0; i < WPASS; ++i) {
-        const int n = col0 + srow + i * RPP;
-        wrow[i] = (n < p.N) ? p.w + (long)n * p.ldw : nullptr;
-    }
-
-    vec_t areg[APASS], wreg[WPASS];
-    auto fetch = [&](int k0) {
-        const int k = k0 + sk;
-        const bool kin = k < p.K;
+    __amdgpu_buffer_rsrc_t rs_a, rs_w;
+    const __amdgpu_buffer_rsrc_t rs_pe = make_rsrc(p.a_pe ? p.a_pe : p.a);
+    unsigned a_voff[APASS];                // byte offset of this lane's row (pass i) inside rs_a, k = sk; OOB if the row is out of range
+    unsigned pe_voff[PE ? APASS : 1];
+    unsigned w_voff[WPASS];
+    int ids_next[APASS];                   // gather ids of the tile after the loader's, fetched one tile ahead
+    auto prefetch_ids = [&](int tile) {
+        if (!gather) return;
+        long row0; int col0;
+        tile_rc(tile < ntiles ? tile : first, row0, col0);
 #pragma unroll
         for (int i = 0; i < APASS; ++i) {
-            vec_t v = vzero<VEC>();
-            if (kin && arow[i]) {
-                v = *reinterpret_cast<const vec_t*>(arow[i] + k);
-                if (aperow[i]) v += *reinterpret_cast<const vec_t*>(aperow[i] + k);
-            }
-            areg[i] = v;
+            const long r = row0 + srow + i * RPP;
+            ids_next[i] = p.a_ids[r < p.M ? r : 0];
+        }
+    };
+    auto loader_set_tile = [&](int tile) {          // uses ids_next for the gather rows
+        long row0; int col0;
+        tile_rc(tile, row0, col0);
+        rs_a = make_rsrc(gather ? p.a : p.a + row0 * p.lda);
+        rs_w = make_rsrc(p.w + (long)col0 * p.ldw);
+        const long rows_left = p.M - row0;
+        const int cols_left = p.N - col0;
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            const int lr = srow + i * RPP;
+            const bool ok = lr < rows_left;
+            const unsigned off = gather ? (unsigned)ids_next[i] * (unsigned)lda4 : (unsigned)(lr * lda4);
+            a_voff[i] = ok ? off + sk * 4 : OOB;
+            if constexpr (PE) pe_voff[i] = ok ? (unsigned)((row0 + lr) % p.a_period) * (unsigned)((int)p.lda_pe * 4) + sk * 4 : OOB;
         }
 #pragma unroll
         for (int i = 0; i < WPASS; ++i) {
-            vec_t v = vzero<VEC>();
-            if (kin && wrow[i]) v = *reinterpret_cast<const vec_t*>(wrow[i] + k);
-            wreg[i] = v;
+            const int ln = srow + i * RPP;
+            w_voff[i] = (ln < cols_left) ? (unsigned)(ln * ldw4) + sk * 4 : OOB;
         }
     };
-    auto stash = [&](int buf) {
+
+    vec_t areg[APASS], wreg[WPASS], pereg[PE ? APASS : 1];
+    auto issue = [&](int k0) {
+        const bool kin = (k0 + sk) < p.K;           // only the tail chunk of a tile has lanes beyond K
+        const int soff = k0 * 4;
 #pragma unroll
-        for (int i = 0; i < APASS; ++i)
-            *reinterpret_cast<vec_t*>(&As[buf][(srow + i * RPP) * LDK + sk]) = areg[i];
+        for (int i = 0; i < APASS; ++i) {
+            areg[i] = buf_load<VEC>(rs_a, kin ? a_voff[i] : OOB, soff);
+            if constexpr (PE) pereg[i] = buf_load<VEC>(rs_pe, kin ? pe_voff[i] : OOB, soff);
+        }
 #pragma unroll
-        for (int i = 0; i < WPASS; ++i)
-            *reinterpret_cast<vec_t*>(&Ws[buf][(srow + i * RPP) * LDK + sk]) = wreg[i];
+        for (int i = 0; i < WPASS; ++i) wreg[i] = buf_load<VEC>(rs_w, kin ? w_voff[i] : OOB, soff);
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < APASS; ++i) {
+            vec_t v = areg[i];
+            if constexpr (PE) v += pereg[i];
+            *reinterpret_cast<vec_t*>(&As[buf][(srow + i * RPP) * LDK + sk]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < WPASS; ++i) *reinterpret_cast<vec_t*>(&Ws[buf][(srow + i * RPP) * LDK + sk]) = wreg[i];
     };
 
-    // ---- main loop ---------------------------------------------------------------------------------
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
+    // ---- compute state -------------------------------------------------------------------------------
     const int wrow0 = (wave / WN) * TM * 32, wcol0 = (wave % WN) * TN * 32;
     const int fi = lane & 31, fh = lane >> 5;
     const int a_off = (wrow0 + fi) * LDK + fh * 4;
     const int w_off = (wcol0 + fi) * LDK + fh * 4;
+    f32x16 acc[TM][TN];
 
-    const int nchunk = (p.K + BK - 1) / BK;
-    fetch(0);
-    stash(0);
-    __syncthreads();
-    for (int t = 0; t < nchunk; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nchunk) fetch((t + 1) * BK);               // in flight under the MFMAs below
-        const int kleft = p.K - t * BK;
-        const int nstep = kleft >= BK ? BK / 8 : (kleft + 7) / 8;   // zero-filled tail beyond K
-        const float* Ab = &As[buf][a_off];
-        const float* Wb = &Ws[buf][w_off];
-#pragma unroll
-        for (int s = 0; s < BK / 8; ++s) {
-            if (s < nstep) {
-                f32x4 af[TM], wf[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + s * 8);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const f32x4*>(Wb + j * 32 * LDK + s * 8);
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][u], wf[j][u], acc[i][j], 0, 0, 0);
+    // C layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // Residual operand of output element (i, r, j): lane part of the byte offset + wave-uniform part.
+    const __amdgpu_buffer_rsrc_t rs_rpe = make_rsrc(p.res_pe ? p.res_pe : p.a);
+    auto residual = [&](long row0, int col0, int i, int r, int j, __amdgpu_buffer_rsrc_t rs_res, unsigned ro, unsigned po) {
+        const int col = wcol0 + j * 32 + fi;                        // column inside the tile
+        const bool cin = col0 + col < p.N;
+        float x = buf_load1(rs_res, (cin && ro != OOB) ? ro + col * 4 : OOB, col0 * 4);
+        if (p.res_pe) x += buf_load1(rs_rpe, (cin && ro != OOB) ? po + col * 4 : OOB, col0 * 4);
+        return x;
+    };
+    // row part of the residual offset (and of the positional table) for accumulator register r of MFMA tile i
+    auto residual_row = [&](long row0, int i, int r, unsigned& ro, unsigned& po) {
+        const int lrow = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const long row = row0 + lrow;
+        ro = OOB; po = 0;
+        if (row < p.M) {
+            if (p.res_ids) {
+                ro = (unsigned)p.res_ids[row] * (unsigned)ldr4;
+                if (p.res_pe) po = (unsigned)(row % p.res_period) * (unsigned)((int)p.ldr_pe * 4);
+            } else {
+                ro = (unsigned)((row / p.res_div - row0 / p.res_div) * ldr4);
             }
         }
-        if (t + 1 < nchunk) stash(buf ^ 1);
-        __syncthreads();
-    }
+    };
+    auto residual_rsrc = [&](long row0) {
+        return make_rsrc(p.res_ids ? p.res : p.res + (row0 / p.res_div) * p.ldr);
+    };
 
-    // ---- epilogue ----------------------------------------------------------------------------------
-    // C layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const bool has_res = p.res != nullptr;
+    // Accumulator init of a tile: zero, or the residual operand itself (plain residual add).
+    auto acc_init = [&](int tile) {
+        const bool use_res = GENERIC ? (p.res_in_acc != 0) : RES;
+        if (!use_res) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long row = row0 + wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            const bool rin = row < p.M;
-            const float* rrow = nullptr;
-            const float* rperow = nullptr;
-            float gs = 1.f;
-            if (rin && has_res) {
-                if (p.res_ids) {
-                    rrow = p.res + (long)p.res_ids[row] * p.ldr;
-                    if (p.res_pe) rperow = p.res_pe + (long)(row % p.res_period) * p.ldr_pe;
-                } else {
-                    rrow = p.res + (row / p.res_div) * p.ldr;
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            return;
+        }
+        long row0; int col0;
+        tile_rc(tile, row0, col0);
+        const __amdgpu_buffer_rsrc_t rs_res = residual_rsrc(row0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                unsigned ro, po;
+                residual_row(row0, i, r, ro, po);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j][r] = residual(row0, col0, i, r, j, rs_res, ro, po);
+            }
+        }
+    };
+
+    // one k8 step: TM + TN fragment reads, then 4 * TM * TN MFMAs
+    auto k8_step = [&](const float* Ab, const float* Wb, int s) {
+        f32x4 af[TM], wf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + s * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const f32x4*>(Wb + j * 32 * LDK + s * 8);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][u], wf[j][u], acc[i][j], 0, 0, 0);
+    };
+
+    // bias / act / LayerNorm / store of the finished tile.  Rows / columns outside the matrix are neutralised by a
+    // select (LayerNorm sums) or by the buffer range check (loads, stores), never by a per-element branch.
+    auto epilogue = [&](int tile) {
+        long row0; int col0;
+        tile_rc(tile, row0, col0);
+        float bias[TN], lng[LN ? TN : 1], lnb[LN ? TN : 1];
+        bool cin[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = col0 + wcol0 + j * 32 + fi;
+            cin[j] = col < p.N;
+            bias[j] = (p.bias && cin[j]) ? p.bias[col] : 0.f;
+            if constexpr (LN) {
+                lng[j] = cin[j] ? p.ln_g[col] : 0.f;
+                lnb[j] = cin[j] ? p.ln_b[col] : 0.f;
+            }
+        }
+        const int wn = wave % WN;
+        const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(p.c + row0 * p.ldc);
+        const unsigned c_lane = (unsigned)((wrow0 + 4 * fh) * ldc4 + (wcol0 + fi) * 4);
+        const long rows_left = p.M - row0;
+
+        if constexpr (!LN) {
+            // row by row: activation (+ late residual) and store; nothing is written back to the accumulators
+            const bool late_res = GENERIC && p.res != nullptr && !p.res_in_acc;
+            const __amdgpu_buffer_rsrc_t rs_res = residual_rsrc(row0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
+                    const bool rin = (wrow0 + 4 * fh + rr) < rows_left;
+                    unsigned ro = OOB, po = 0;
+                    if (late_res) residual_row(row0, i, r, ro, po);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        float v = acc[i][j][r] + bias[j];
+                        if constexpr (GENERIC) {
+                            v = apply_act(v, p.act);
+                            if (late_res) v += residual(row0, col0, i, r, j, rs_res, ro, po);
+                        } else if constexpr (ACT == LIME_ACT_RELU) {
+                            v = fmaxf(v, 0.f);
+                        }
+                        buf_store1(v, rs_c, (rin && cin[j]) ? c_lane : OOB, rr * ldc4 + (col0 + j * 32) * 4);
+                    }
                 }
             }
-            if (rin && p.gate) gs = p.gate_scale[row];
-            float vals[TN];
+        } else {
+            // LayerNorm over the row: two passes, like the reference's (x - mean)^2; values stay in the accumulators
+            const float inv_n = 1.0f / (float)p.N;
+            float stat[TM][16];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = col0 + wcol0 + j * 32 + fi;
-                const bool cin = col < p.N;
-                float v = 0.f;
-                if (rin && cin) {
-                    float x = 0.f;
-                    if (rrow) {
-                        x = rrow[col];
-                        if (rperow) x += rperow[col];
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        float v = acc[i][j][r] + bias[j];
+                        if constexpr (ACT == LIME_ACT_RELU) v = fmaxf(v, 0.f);
+                        v = cin[j] ? v : 0.f;
+                        acc[i][j][r] = v;
+                        sum += v;
                     }
-                    const float b = p.bias ? p.bias[col] : 0.f;
-                    if (p.gate) {
-                        const float g = lime_sigmoid(gs * acc[i][j][r] + b);
-                        const float wc = gs * x;
-                        v = g * wc + (1.f - g) * x;
+                    sum = wave_half_sum(sum);
+                    if constexpr (WN > 1) {
+                        const int lrow = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                        if (fi == 0) red_sum[wn * BM + lrow] = sum;
                     } else {
-                        v = apply_act(acc[i][j][r] + b, p.act) + x;
+                        stat[i][r] = sum * inv_n;
                     }
                 }
-                vals[j] = v;
             }
-            if constexpr (ROWFULL) {
-                if (p.ln_g) {
-                    float s = 0.f;
+            if constexpr (WN > 1) {
+                __syncthreads();
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) s += vals[j];
-                    const float mean = wave_half_sum(s) / (float)p.N;
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int lrow = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                        float tot = 0.f;
+#pragma unroll
+                        for (int w = 0; w < WN; ++w) tot += red_sum[w * BM + lrow];
+                        stat[i][r] = tot * inv_n;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
                     float q = 0.f;
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        const int col = col0 + wcol0 + j * 32 + fi;
-                        const float d = (col < p.N) ? vals[j] - mean : 0.f;
-                        vals[j] = d;
+                        const float d = cin[j] ? acc[i][j][r] - stat[i][r] : 0.f;
+                        acc[i][j][r] = d;
                         q += d * d;
                     }
-                    const float rstd = 1.0f / sqrtf(wave_half_sum(q) / (float)p.N + p.ln_eps);
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const int col = col0 + wcol0 + j * 32 + fi;
-                        if (col < p.N) vals[j] = vals[j] * rstd * p.ln_g[col] + p.ln_b[col];
+                    q = wave_half_sum(q);
+                    if constexpr (WN > 1) {
+                        const int lrow = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                        if (fi == 0) red_sq[wn * BM + lrow] = q;
+                    } else {
+                        stat[i][r] = 1.0f / sqrtf(q * inv_n + p.ln_eps);
                     }
                 }
             }
-            if (rin) {
+            if constexpr (WN > 1) {
+                __syncthreads();
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int col = col0 + wcol0 + j * 32 + fi;
-                    if (col < p.N) p.c[row * p.ldc + col] = vals[j];
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int lrow = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                        float tot = 0.f;
+#pragma unroll
+                        for (int w = 0; w < WN; ++w) tot += red_sq[w * BM + lrow];
+                        stat[i][r] = 1.0f / sqrtf(tot * inv_n + p.ln_eps);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
+                    const bool rin = (wrow0 + 4 * fh + rr) < rows_left;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        buf_store1(acc[i][j][r] * stat[i][r] * lng[j] + lnb[j], rs_c, (rin && cin[j]) ? c_lane : OOB,
+                                   rr * ldc4 + (col0 + j * 32) * 4);
                 }
             }
         }
+    };
+
+    // ---- the chunk stream ----------------------------------------------------------------------------
+    // Outer loop over this workgroup's tiles, inner loop over a tile's full chunks, the (possibly partial) last chunk
+    // peeled: the accumulators only ever flow through straight-line code and plain loops -- any if-merge that
+    // touches them makes hipcc copy the whole 64..80-register array at the merge point.
+    prefetch_ids(first);
+    loader_set_tile(first);
+    prefetch_ids(first + nwg);
+    issue(0);
+    commit(0);
+    __syncthreads();
+    int buf = 0;
+    for (int tile = first; tile < ntiles; tile += nwg) {
+        const bool more = tile + nwg < ntiles;
+        acc_init(tile);
+        for (int t = 0; t + 1 < nchunk; ++t) {
+            issue((t + 1) * BK);
+            __builtin_amdgcn_sched_barrier(0);        // keep the prefetch ABOVE the MFMAs (hipcc otherwise sinks it to its use)
+            const float* Ab = &As[buf][a_off];
+            const float* Wb = &Ws[buf][w_off];
+#pragma unroll
+            for (int s = 0; s < BK / 8; ++s) k8_step(Ab, Wb, s);
+            __builtin_amdgcn_sched_barrier(0);        // ... and its waits + LDS writes BELOW them
+            commit(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        // last chunk of the tile: the loader moves on to the next tile first
+        if (more) {
+            loader_set_tile(tile + nwg);
+            prefetch_ids(tile + 2 * nwg);
+            issue(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float* Ab = &As[buf][a_off];
+            const float* Wb = &Ws[buf][w_off];
+            for (int s = 0; s < tail_steps; ++s) k8_step(Ab, Wb, s);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        epilogue(tile);
+        if (more) commit(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
     }
 }
 
-template <int TM, int TN, int WM, int WN, bool ROWFULL>
-int launch_cfg(const GemmP& p0, int vec, hipStream_t stream) {
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+template <int TM, int TN, int WM, int WN, int VEC, bool LN, bool PE, int ACT, bool RES, bool GENERIC>
+int launch_one(const GemmP& p0, int wg_per_cu, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     GemmP p = p0;
     p.n_row_blocks = (p.M + BM - 1) / BM;
     p.n_col_blocks = (p.N + BN - 1) / BN;
-    const dim3 grid((unsigned)(p.n_row_blocks * p.n_col_blocks)), block(256);
-    if (vec == 4) hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, WM, WN, 4, ROWFULL>), grid, block, 0, stream, p);
-    else if (vec == 2) hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, WM, WN, 2, ROWFULL>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, WM, WN, 1, ROWFULL>), grid, block, 0, stream, p);
+    const long ntiles = (long)p.n_row_blocks * p.n_col_blocks;
+    long nwg = (long)num_cus() * wg_per_cu;
+    if (nwg > ntiles) nwg = ntiles;
+    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, WM, WN, VEC, LN, PE, ACT, RES, GENERIC>), dim3((unsigned)nwg), dim3(WM * WN * 64), 0,
+                       stream, p);
     return lime_check_launch("lime_linear_f32");
+}
+
+// big tiles (eight waves, 128 x TN*64): compile-time epilogue
+template <int TN, bool LN, int ACT, bool RES>
+int launch_big(const GemmP& p, int vec, hipStream_t s) {
+    const bool pe = p.a_pe != nullptr;
+    if (vec == 4) return pe ? launch_one<1, TN, 4, 2, 4, LN, true, ACT, RES, false>(p, 1, s) : launch_one<1, TN, 4, 2, 4, LN, false, ACT, RES, false>(p, 1, s);
+    if (vec == 2) return pe ? launch_one<1, TN, 4, 2, 2, LN, true, ACT, RES, false>(p, 1, s) : launch_one<1, TN, 4, 2, 2, LN, false, ACT, RES, false>(p, 1, s);
+    return pe ? launch_one<1, TN, 4, 2, 1, LN, true, ACT, RES, false>(p, 1, s) : launch_one<1, TN, 4, 2, 1, LN, false, ACT, RES, false>(p, 1, s);
+}
+
+// small tiles (four waves, 64 x 64): everything at run time
+int launch_small(const GemmP& p, int vec, hipStream_t s) {
+    const bool pe = p.a_pe != nullptr;
+    if (vec == 4) return pe ? launch_one<1, 1, 2, 2, 4, false, true, 0, false, true>(p, 4, s) : launch_one<1, 1, 2, 2, 4, false, false, 0, false, true>(p, 4, s);
+    if (vec == 2) return pe ? launch_one<1, 1, 2, 2, 2, false, true, 0, false, true>(p, 4, s) : launch_one<1, 1, 2, 2, 2, false, false, 0, false, true>(p, 4, s);
+    return pe ? launch_one<1, 1, 2, 2, 1, false, true, 0, false, true>(p, 4, s) : launch_one<1, 1, 2, 2, 1, false, false, 0, false, true>(p, 4, s);
 }
 
 inline bool aligned(const void* ptr, long ld, int vec) {
@@ -283,8 +510,6 @@ extern "C" int lime_linear_f32(const lime_linear_args* a, void* stream) {
     LIME_REQUIRE(!a->res || a->ldr >= a->N, LIME_ERR_BAD_ARG, "lime_linear_f32: ldr smaller than N");
     LIME_REQUIRE(!a->res_pe || (a->res_ids && a->res_period > 0 && a->ldr_pe >= a->N), LIME_ERR_BAD_ARG,
                  "lime_linear_f32: res_pe needs res_ids, res_period > 0 and ldr_pe >= N");
-    LIME_REQUIRE(!a->gate || (a->gate_scale && a->res && !a->res_ids && a->res_div == 1), LIME_ERR_BAD_ARG,
-                 "lime_linear_f32: gate needs gate_scale and a dense residual with res_div == 1");
     LIME_REQUIRE(!a->ln_gamma || a->ln_beta, LIME_ERR_BAD_ARG, "lime_linear_f32: ln_gamma without ln_beta");
     LIME_REQUIRE(a->act >= LIME_ACT_NONE && a->act <= LIME_ACT_SIGMOID, LIME_ERR_BAD_ARG, "lime_linear_f32: bad act %d", a->act);
     if (a->M == 0) return LIME_OK;
@@ -294,21 +519,41 @@ extern "C" int lime_linear_f32(const lime_linear_args* a, void* stream) {
     p.w = a->w; p.ldw = a->ldw; p.bias = a->bias;
     p.res = a->res; p.ldr = a->ldr; p.res_div = a->res_div > 0 ? a->res_div : 1; p.res_ids = a->res_ids;
     p.res_pe = a->res_pe; p.ldr_pe = a->ldr_pe; p.res_period = a->res_period;
-    p.gate_scale = a->gate_scale; p.gate = a->gate;
     p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps;
     p.c = a->c; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act;
     p.n_row_blocks = p.n_col_blocks = 0;
+    // acc + bias + res (the documented order with no activation) == (res + acc) + bias up to fp32 rounding
+    p.res_in_acc = (a->res != nullptr && a->act == LIME_ACT_NONE) ? 1 : 0;
 
     int vec = 4;
     while (vec > 1 && !((a->K % vec) == 0 && aligned(a->a, a->lda, vec) && aligned(a->w, a->ldw, vec) &&
                         aligned(a->a_pe, a->lda_pe, vec)))
         vec >>= 1;
     hipStream_t s = (hipStream_t)stream;
+    // Tile selection.
+    //   LayerNorm epilogue: one 128 x 256 / 128 x 320 tile spans the row (N <= 320); residual (if any) is preloaded into
+    //   the accumulators, so it must be a plain add (no activation in between).
+    //   Big M without LayerNorm, activation none / ReLU, no residual: the same eight-wave tiles, the width (256 / 320)
+    //   that pads N least.  Everything else (tanh / sigmoid, residual without LayerNorm, small M): 64 x 64 tiles.
+    const bool has_res = a->res != nullptr;
     if (a->ln_gamma) {
-        LIME_REQUIRE(a->N <= 416, LIME_ERR_UNSUPPORTED, "lime_linear_f32: LayerNorm epilogue needs N <= 416 (N=%d)", a->N);
-        if (a->N <= 320) return launch_cfg<1, 10, 4, 1, true>(p, vec, s);
-        return launch_cfg<1, 13, 4, 1, true>(p, vec, s);
+        LIME_REQUIRE(a->N <= 320, LIME_ERR_UNSUPPORTED, "lime_linear_f32: LayerNorm epilogue needs N <= 320 (N=%d)", a->N);
+        LIME_REQUIRE(a->act == LIME_ACT_NONE || (a->act == LIME_ACT_RELU && !has_res), LIME_ERR_UNSUPPORTED,
+                     "lime_linear_f32: LayerNorm epilogue supports act none (+ residual) or ReLU (no residual)");
+        const bool relu = a->act == LIME_ACT_RELU;
+        if (a->N <= 256) {
+            if (relu) return launch_big<4, true, LIME_ACT_RELU, false>(p, vec, s);
+            return has_res ? launch_big<4, true, LIME_ACT_NONE, true>(p, vec, s) : launch_big<4, true, LIME_ACT_NONE, false>(p, vec, s);
+        }
+        if (relu) return launch_big<5, true, LIME_ACT_RELU, false>(p, vec, s);
+        return has_res ? launch_big<5, true, LIME_ACT_NONE, true>(p, vec, s) : launch_big<5, true, LIME_ACT_NONE, false>(p, vec, s);
     }
-    if (a->M >= 4096) return launch_cfg<2, 2, 2, 2, false>(p, vec, s);
-    return launch_cfg<1, 1, 2, 2, false>(p, vec, s);
+    const bool simple = !has_res && (a->act == LIME_ACT_NONE || a->act == LIME_ACT_RELU);
+    if (a->M >= 4096 && simple) {
+        const int pad5 = (a->N + 319) / 320 * 320 - a->N, pad4 = (a->N + 255) / 256 * 256 - a->N;
+        const bool relu = a->act == LIME_ACT_RELU;
+        if (pad5 < pad4) return relu ? launch_big<5, false, LIME_ACT_RELU, false>(p, vec, s) : launch_big<5, false, LIME_ACT_NONE, false>(p, vec, s);
+        return relu ? launch_big<4, false, LIME_ACT_RELU, false>(p, vec, s) : launch_big<4, false, LIME_ACT_NONE, false>(p, vec, s);
+    }
+    return launch_small(p, vec, s);
 }

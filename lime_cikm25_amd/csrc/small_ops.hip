@@ -439,6 +439,34 @@ __global__ __launch_bounds__(256) void row_scale_kernel(const float* __restrict_
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) out[e] = x[e] * scale[e / D];
 }
 
+__global__ __launch_bounds__(256) void gate_ln_kernel(const float* __restrict__ y, const float* __restrict__ x,
+                                                       const float* __restrict__ scale, const float* __restrict__ bias,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                       float* __restrict__ out, int D) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [D] blended row, then 4 floats of scratch
+    float* v = sm;
+    float* red = sm + D;
+    const long r = blockIdx.x;
+    const float s = scale[r];
+    float part = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const float xv = x[r * D + d];
+        const float g = lime_sigmoid(s * y[r * D + d] + bias[d]);
+        const float wc = s * xv;
+        const float val = g * wc + (1.f - g) * xv;
+        v[d] = val;
+        part += val;
+    }
+    const float mean = block_sum(part, red) / (float)D;
+    part = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const float dv = v[d] - mean;
+        part += dv * dv;
+    }
+    const float rstd = 1.0f / sqrtf(block_sum(part, red) / (float)D + eps);
+    for (int d = threadIdx.x; d < D; d += 256) out[r * D + d] = (v[d] - mean) * rstd * gamma[d] + beta[d];
+}
+
 inline unsigned grid_for(long total, int per_block, unsigned cap = 2048) {
     long b = (total + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -598,4 +626,15 @@ extern "C" int lime_row_scale_f32(const float* x, const float* scale, float* out
     hipLaunchKernelGGL(row_scale_kernel, dim3(grid_for(rows * D, 256)), dim3(256), 0, (hipStream_t)stream, x, scale, out, (long)rows,
                        D);
     return lime_check_launch("lime_row_scale_f32");
+}
+
+extern "C" int lime_gate_ln_f32(const float* y, const float* x, const float* scale, const float* bias, const float* gamma,
+                                const float* beta, float eps, float* out, int64_t rows, int32_t D, void* stream) {
+    LIME_REQUIRE(y && x && scale && bias && gamma && beta && out, LIME_ERR_BAD_ARG, "lime_gate_ln_f32: NULL pointer");
+    LIME_REQUIRE(rows >= 0 && D > 0, LIME_ERR_BAD_ARG, "lime_gate_ln_f32: bad dims");
+    LIME_REQUIRE(D <= 8192, LIME_ERR_UNSUPPORTED, "lime_gate_ln_f32: D %d > 8192", D);
+    if (rows == 0) return LIME_OK;
+    hipLaunchKernelGGL(gate_ln_kernel, dim3((unsigned)rows), dim3(256), (size_t)(D + 4) * sizeof(float), (hipStream_t)stream, y, x,
+                       scale, bias, gamma, beta, eps, out, D);
+    return lime_check_launch("lime_gate_ln_f32");
 }

@@ -12,8 +12,8 @@ from . import ops
 
 class CandidateAware_ClickedNewsAttention(nn.Module):
     """layers.py:15-93.  Q/K topic projections on the fp32 MFMA GEMM, per-head softmax + query-weighted
-    aggregation in one workgroup per impression row, gate_proj + gated residual + LayerNorm fused into
-    the GEMM epilogue.  ``value_proj`` is kept for the state_dict only: its branch is dead in the
+    aggregation in one workgroup per impression row, gate_proj on the GEMM, gated residual + LayerNorm in one
+    row kernel.  ``value_proj`` is kept for the state_dict only: its branch is dead in the
     reference (layers.py:68,76-77)."""
 
     def __init__(self, config, news_encoder):
@@ -54,8 +54,9 @@ class CandidateAware_ClickedNewsAttention(nn.Module):
         kp = ops.linear(clicked_news_topic_embeddings.reshape(B * H, -1), self.key_proj.weight, self.key_proj.bias)
         agg = ops.cand_attn_weights(qp, kp, mask, B, N, H, D, self.num_heads)
         if self.use_residual_connection:
-            out = ops.linear(hist, self.gate_proj.weight, self.gate_proj.bias, res=hist, gate_scale=agg.view(-1),
-                             ln=(self.layernorm.weight, self.layernorm.bias), ln_eps=self.layernorm.eps)
+            y = ops.linear(hist, self.gate_proj.weight, None)                       # W_g x; the row scale commutes
+            out = ops.gate_ln(y, hist, agg.view(-1), self.gate_proj.bias, self.layernorm.weight, self.layernorm.bias,
+                              self.layernorm.eps)
         else:
             out = ops.row_scale(hist, agg.view(-1))
         return out.view(B, H, D), agg

@@ -30,11 +30,21 @@ def _linear_variant(M, N, K, ln, a, w, a_pe):
         return t is None or (t.data_ptr() % (4 * v) == 0 and _ld(t) % v == 0)
     while vec > 1 and not (K % vec == 0 and ok(a, vec) and ok(w, vec) and ok(a_pe, vec)):
         vec //= 2
+    return vec
+
+
+def linear_kernel_name(M, N, K, act, has_res, ln, vec, pe):
+    """The gemm_f32_kernel instantiation lime_linear_f32 dispatches to (mirrors the tile selection in csrc/gemm_f32.hip)."""
+    t = lambda b: 'true' if b else 'false'
     if ln:
-        tile = 'row10' if N <= 320 else 'row13'
-    else:
-        tile = 'g128' if M >= 4096 else 'g64'
-    return '%sv%d' % (tile, vec)
+        tn = 4 if N <= 256 else 5
+        return 'gemm_f32_kernel<1, %d, 4, 2, %d, true, %s, %d, %s, false>' % (tn, vec, t(pe), 1 if act == 'relu' else 0,
+                                                                             t(has_res and act != 'relu'))
+    if M >= 4096 and not has_res and act in (None, 'none', 'relu'):
+        pad5, pad4 = (N + 319) // 320 * 320 - N, (N + 255) // 256 * 256 - N
+        tn = 5 if pad5 < pad4 else 4
+        return 'gemm_f32_kernel<1, %d, 4, 2, %d, false, %s, %d, false, false>' % (tn, vec, t(pe), 1 if act == 'relu' else 0)
+    return 'gemm_f32_kernel<1, 1, 2, 2, %d, false, %s, 0, false, true>' % (vec, t(pe))
 
 
 def _p(t):
@@ -75,11 +85,11 @@ def _mask_u8(mask, name):
 
 
 def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=0, res=None, res_div=1, res_ids=None,
-           res_pe=None, res_period=0, gate_scale=None, ln=None, ln_eps=1e-5):
+           res_pe=None, res_period=0, ln=None, ln_eps=1e-5):
     """C = epilogue(A . W^T + bias) -- see ``lime_linear_f32`` in include/lime_hip.h.
 
     a: [M, K] (or the [V, K] table when a_ids is given, M = len(a_ids)); w: [N, K]; out: [M, N] (may be a view).
-    ln: (gamma, beta) for the fused LayerNorm; gate_scale: [M] for the gated-residual epilogue.
+    ln: (gamma, beta) for the fused LayerNorm (N <= 320).
     """
     lib = _lib.load()
     _mat(a, 'a')
@@ -122,8 +132,6 @@ def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=
                 args.res_pe, args.ldr_pe, args.res_period = res_pe.data_ptr(), _ld(res_pe), res_period
         elif res.shape[0] * res_div < M:
             raise ValueError('res has %d rows, needs >= %d' % (res.shape[0], (M + res_div - 1) // res_div))
-    if gate_scale is not None:
-        args.gate_scale, args.gate = _vec(gate_scale, 'gate_scale', M).data_ptr(), 1
     if ln is not None:
         args.ln_gamma = _vec(ln[0], 'ln gamma', N).data_ptr()
         args.ln_beta = _vec(ln[1], 'ln beta', N).data_ptr()
@@ -136,7 +144,8 @@ def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=
         e0.record()
         check(lib.lime_linear_f32(ctypes.byref(args), _stream()), 'lime_linear_f32')
         e1.record()
-        PROFILE.append((_linear_variant(M, N, K, ln is not None, a, w, a_pe), M, N, K, e0, e1))
+        PROFILE.append((linear_kernel_name(M, N, K, act, res is not None, ln is not None,
+                                           _linear_variant(M, N, K, ln is not None, a, w, a_pe), a_pe is not None), M, N, K, e0, e1))
         return out
     check(lib.lime_linear_f32(ctypes.byref(args), _stream()), 'lime_linear_f32')
     return out
@@ -289,6 +298,20 @@ def cand_attn_weights(qp, kp, mask, B, N, H, D, n_head):
     check(lib.lime_cand_attn_weights_f32(_p(qp), _p(kp), _p(m), _p(agg), B, N, H, D, n_head, _stream()),
           'lime_cand_attn_weights_f32')
     return agg
+
+
+def gate_ln(y, x, scale, bias, gamma, beta, eps=1e-5):
+    """LayerNorm(g * (s x) + (1 - g) x), g = sigmoid(s y + bias): the gated residual of layers.py:84-89."""
+    lib = _lib.load()
+    D = x.shape[-1]
+    x = _vec(x.contiguous(), 'x')
+    y = _vec(y.contiguous(), 'y', x.numel())
+    rows = x.numel() // D
+    out = torch.empty_like(x)
+    check(lib.lime_gate_ln_f32(_p(y), _p(x), _p(_vec(scale.contiguous(), 'scale', rows)), _p(_vec(bias, 'bias', D)),
+                               _p(_vec(gamma, 'gamma', D)), _p(_vec(beta, 'beta', D)), eps, _p(out), rows, D, _stream()),
+          'lime_gate_ln_f32')
+    return out
 
 
 def sage_mean(hist, user_nodes, B, H, n_src, D):

@@ -36,10 +36,26 @@ def test_abi_version(lib):
     assert lib.lime_abi_version() == 1
 
 
-def test_linear_args_layout_matches_header():
-    # 8-byte pointers / int64 with natural alignment: the ctypes mirror must have the C struct's size
-    assert ctypes.sizeof(_lib.LinearArgs) == 200
-    assert (_lib.LinearArgs.c.offset, _lib.LinearArgs.act.offset, _lib.LinearArgs.ln_eps.offset) == (168, 196, 160)
+def _c_layout(tmp_path):
+    """sizeof / offsetof of lime_linear_args as gcc sees the header."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    src = tmp_path / 'sz.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu", '
+                   'sizeof(lime_linear_args), offsetof(lime_linear_args, c), offsetof(lime_linear_args, act), '
+                   'offsetof(lime_linear_args, ln_eps)); return 0;}' % os.path.join(ROOT, 'include', 'lime_hip.h'))
+    exe = tmp_path / 'sz'
+    subprocess.run(['gcc', '-o', str(exe), str(src)], check=True)
+    return tuple(int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split())
+
+
+def test_linear_args_layout_matches_header(tmp_path):
+    # the ctypes mirror must have exactly the layout the C compiler gives the struct in include/lime_hip.h
+    LAYOUT = _c_layout(tmp_path)
+    assert ctypes.sizeof(_lib.LinearArgs) == LAYOUT[0]
+    assert (_lib.LinearArgs.c.offset, _lib.LinearArgs.act.offset, _lib.LinearArgs.ln_eps.offset) == LAYOUT[1:]
 
 
 def test_bad_arguments_are_rejected_without_a_launch(lib):

@@ -1,0 +1,102 @@
+// Micro-probes of the fp32 MFMA issue rate on gfx950 (diagnostic only, not part of the product).
+//   hipcc -O3 --offload-arch=gfx950 -o mfma_probe mfma_probe.hip && ./mfma_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// V0: pure 32x32x2 MFMA, NACC independent accumulators, operands in registers
+template <int NACC>
+__global__ __launch_bounds__(256) void k_pure32(float* out, int iters, float a0, float b0) {
+    f32x16 acc[NACC];
+    for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float a = a0 + threadIdx.x * 1e-3f, b = b0 + threadIdx.x * 2e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// V1: pure 16x16x4 MFMA
+template <int NACC>
+__global__ __launch_bounds__(256) void k_pure16(float* out, int iters, float a0, float b0) {
+    f32x4 acc[NACC];
+    for (int i = 0; i < NACC; ++i) for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    float a = a0 + threadIdx.x * 1e-3f, b = b0 + threadIdx.x * 2e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < NACC; ++i) for (int r = 0; r < 4; ++r) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// V2: 2x2 tiles of 32x32 per wave fed by ds_read_b128 from a static LDS image (no staging, no barrier)
+template <bool BARRIER>
+__global__ __launch_bounds__(256) void k_lds32(float* out, int iters) {
+    __shared__ __attribute__((aligned(16))) float As[128 * 36], Ws[128 * 36];
+    for (int e = threadIdx.x; e < 128 * 36; e += 256) { As[e] = e * 1e-4f; Ws[e] = e * 2e-4f; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fi = lane & 31, fh = lane >> 5;
+    const float* Ab = &As[((wave >> 1) * 64 + fi) * 36 + fh * 4];
+    const float* Wb = &Ws[((wave & 1) * 64 + fi) * 36 + fh * 4];
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f32x4 af[2], wf[2];
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * 36 + s * 8);
+            for (int j = 0; j < 2; ++j) wf[j] = *reinterpret_cast<const f32x4*>(Wb + j * 32 * 36 + s * 8);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                for (int i = 0; i < 2; ++i)
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][u], wf[j][u], acc[i][j], 0, 0, 0);
+        }
+        if (BARRIER) __syncthreads();
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <typename F>
+double time_it(F launch, int reps) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    launch(); hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < reps; ++i) launch();
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1e-3 / reps;
+}
+
+int main() {
+    float* out; hipMalloc(&out, 4096 * 256 * 4);
+    const int iters = 2000;
+    for (int blocks : {256, 512, 1024}) {
+        double t;
+        t = time_it([&] { hipLaunchKernelGGL((k_pure32<1>), dim3(blocks), dim3(256), 0, 0, out, iters, 1.f, 2.f); }, 5);
+        printf("pure32 nacc=1 blocks=%4d: %.2f TF\n", blocks, (double)blocks * 4 * iters * 4 * 1 * 4096 / t / 1e12);
+        t = time_it([&] { hipLaunchKernelGGL((k_pure32<4>), dim3(blocks), dim3(256), 0, 0, out, iters, 1.f, 2.f); }, 5);
+        printf("pure32 nacc=4 blocks=%4d: %.2f TF\n", blocks, (double)blocks * 4 * iters * 4 * 4 * 4096 / t / 1e12);
+        t = time_it([&] { hipLaunchKernelGGL((k_pure16<8>), dim3(blocks), dim3(256), 0, 0, out, iters, 1.f, 2.f); }, 5);
+        printf("pure16 nacc=8 blocks=%4d: %.2f TF\n", blocks, (double)blocks * 4 * iters * 4 * 8 * 2048 / t / 1e12);
+        t = time_it([&] { hipLaunchKernelGGL((k_lds32<false>), dim3(blocks), dim3(256), 0, 0, out, iters); }, 5);
+        printf("lds32 nobar   blocks=%4d: %.2f TF\n", blocks, (double)blocks * 4 * iters * 64 * 4096 / t / 1e12);
+        t = time_it([&] { hipLaunchKernelGGL((k_lds32<true>), dim3(blocks), dim3(256), 0, 0, out, iters); }, 5);
+        printf("lds32 barrier blocks=%4d: %.2f TF\n", blocks, (double)blocks * 4 * iters * 64 * 4096 / t / 1e12);
+    }
+    return 0;
+}
