@@ -3,22 +3,32 @@
 // The attention core of the two TransformerEncoderLayers (newsEncoders.py:316,320: 10 heads x 30,
 // no mask, padded tokens attend and are attended) and of layers.MultiHeadAttention (layers.py:227-237:
 // 10 heads x 20, key mask filled with -1e9).  Sequences are LDS-scale (S <= 512), so there is no
-// flash-style key loop: a wave owns 32 query rows, keeps the whole 32 x S score strip in MFMA
-// accumulators (16 registers per 32-key tile), does the row softmax in registers with half-wave
-// shuffle reductions (the 32x32 C layout puts a row's 32 keys on the 32 lanes of a half-wave), passes
-// each probability tile through a 4.5 KiB per-wave LDS scratch to re-enter as the A operand, and
-// multiplies by V straight from the staged [key][32] image.  K and V of a (sequence, head) pair are
-// staged once per workgroup; short sequences pack 4 (S <= 32) or 2 (S <= 64) pairs per workgroup.
+// flash-style key loop.  A wave owns 32 queries and computes the TRANSPOSED score strip
+// S^T = K Q^T (keys on the MFMA rows, queries on the lanes) into accumulators, 16 registers per 32-key
+// tile.  With the query on the lane
+//   * the softmax max / sum over the keys is a reduction over a lane's own registers plus ONE
+//     cross-half shuffle (the 32x32 C layout splits a column's 32 rows over the two half-waves),
+//     instead of a 5-step shuffle tree per row;
+//   * a probability register is already laid out as the B operand of the next product
+//     O^T = V^T P^T (register r of tile t holds key 32t + (r&3) + 8(r>>2) + 4*half for query = lane),
+//     so P never leaves the register file; the A operand is one conflict-free ds_read_b32 of the
+//     staged V image per MFMA;
+//   * 1/sum is applied to the 16 output registers, not to the S probabilities.
+// The output tile O^T (head dim on rows, query on lanes) is transposed through a 4 KiB per-wave LDS
+// scratch so the store writes whole 120-byte head rows.  K and V of a (sequence, head) pair are staged
+// once per workgroup with 8-byte loads; short sequences pack 4 (S <= 32) or 2 (S <= 64) pairs per
+// workgroup.
 #include "common.h"
 
 namespace {
 
-constexpr int LDH = 36;  // pitch of K / Q / P rows in LDS (floats): conflict-free ds_read_b128
-constexpr int LDV = 32;  // pitch of V rows: lanes read 32 consecutive floats of one key
+constexpr int LDH = 36;  // pitch of K / Q rows in LDS (floats): conflict-free ds_read_b128
+constexpr int LDV = 32;  // pitch of V rows: a half-wave reads 32 consecutive floats of one key
+constexpr int LDO = 33;  // pitch of the output transpose scratch
 
 struct AttnP {
     const float* q; const float* k; const float* v; long ld; const unsigned char* mask;
-    float* out; long ldo; int n_seq, S, n_head, hd; float scale; int n_pair;
+    float* out; long ldo; int n_seq, S, n_head, hd; float scale; int n_pair; int vec2;
 };
 
 __device__ __forceinline__ void lds_fence() {
@@ -29,6 +39,29 @@ __device__ __forceinline__ void lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// rows [0, rows) x head_dim of one (sequence, head) operand -> LDS image with `pitch`, zero-filled to 32 columns and
+// to `rows_padded` rows; `nthr` threads starting at `t0` cooperate.  src points at (first row, head column 0).
+__device__ __forceinline__ void stage_rows(float* dst, int pitch, const float* src, long ld, int rows, int rows_padded, int hd,
+                                           float scale, bool vec2, int t0, int nthr) {
+    if (vec2) {
+        const int pairs = 16;                                   // 32 columns as 16 float2
+        for (int e = t0; e < rows_padded * pairs; e += nthr) {
+            const int c = (e % pairs) * 2, r = e / pairs;
+            f32x2 v = {0.f, 0.f};
+            if (r < rows && c < hd) v = *reinterpret_cast<const f32x2*>(src + (long)r * ld + c);   // hd even: c + 1 < hd
+            dst[r * pitch + c] = v[0] * scale;
+            dst[r * pitch + c + 1] = v[1] * scale;
+        }
+    } else {
+        for (int e = t0; e < rows_padded * 32; e += nthr) {
+            const int c = e & 31, r = e >> 5;
+            float v = 0.f;
+            if (r < rows && c < hd) v = src[(long)r * ld + c];
+            dst[r * pitch + c] = v * scale;
+        }
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(256) void token_attn_kernel(const AttnP p) {
     constexpr int G = (NT >= 3) ? 1 : (4 / NT);   // (sequence, head) pairs per workgroup
@@ -37,24 +70,27 @@ __global__ __launch_bounds__(256) void token_attn_kernel(const AttnP p) {
     __shared__ __attribute__((aligned(16))) float Ks[G * SP * LDH];
     __shared__ __attribute__((aligned(16))) float Vs[G * SP * LDV];
     __shared__ __attribute__((aligned(16))) float Scr[4 * 32 * LDH];
+    __shared__ float Flag[G * SP];                // 0: key takes part, 1: masked (-1e9), 2: padding (-inf)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 31, fh = lane >> 5;
     const int S = p.S, hd = p.hd;
+    const bool need_flags = p.mask != nullptr || (S & 31) != 0;
 
-    // ---- stage K and V of this workgroup's pairs (zero-filled beyond S and beyond head_dim) ---------
-    for (int e = tid; e < G * SP * 32; e += 256) {
-        const int d = e & 31, key = (e >> 5) % SP, g = (e >> 5) / SP;
+    // ---- stage K and V of this workgroup's pairs: WPP waves per pair ---------------------------------
+    {
+        const int g = wave / WPP;
         const int pair = blockIdx.x * G + g;
-        float kv = 0.f, vv = 0.f;
-        if (pair < p.n_pair && key < S && d < hd) {
+        const int t0 = (wave % WPP) * 64 + lane, nthr = WPP * 64;
+        if (pair < p.n_pair) {
             const int seq = pair / p.n_head, head = pair - seq * p.n_head;
-            const long off = ((long)seq * S + key) * p.ld + head * hd + d;
-            kv = p.k[off];
-            vv = p.v[off];
+            const long base = (long)seq * S * p.ld + head * hd;
+            stage_rows(&Ks[g * SP * LDH], LDH, p.k + base, p.ld, S, SP, hd, 1.0f, p.vec2, t0, nthr);
+            stage_rows(&Vs[g * SP * LDV], LDV, p.v + base, p.ld, S, SP, hd, 1.0f, p.vec2, t0, nthr);
+            if (need_flags)
+                for (int key = t0; key < SP; key += nthr)
+                    Flag[g * SP + key] = key >= S ? 2.f : ((p.mask && p.mask[(long)seq * S + key] == 0) ? 1.f : 0.f);
         }
-        Ks[(g * SP + key) * LDH + d] = kv;
-        Vs[(g * SP + key) * LDV + d] = vv;
     }
     __syncthreads();
 
@@ -64,71 +100,70 @@ __global__ __launch_bounds__(256) void token_attn_kernel(const AttnP p) {
     const int seq = pair / p.n_head, head = pair - seq * p.n_head;
     const float* Kg = &Ks[g * SP * LDH];
     const float* Vg = &Vs[g * SP * LDV];
+    const float* Fg = &Flag[g * SP];
     float* scr = &Scr[wave * 32 * LDH];
+    const int krow = (0) + 4 * fh;                 // key row of accumulator register r: (r & 3) + 8 * (r >> 2) + 4 * fh
 
     for (int qt = wave % WPP; qt < NT; qt += WPP) {
         if (qt * 32 >= S) break;
-        // ---- Q tile -> scratch (scaled), then into A fragments --------------------------------------
-        for (int e = lane; e < 32 * 32; e += 64) {
-            const int d = e & 31, i = e >> 5;
-            const int qi = qt * 32 + i;
-            float x = 0.f;
-            if (qi < S && d < hd) x = p.q[((long)seq * S + qi) * p.ld + head * hd + d] * p.scale;
-            scr[i * LDH + d] = x;
-        }
+        // ---- Q tile -> scratch (scaled), then into B fragments ---------------------------------------
+        const int qrows = (S - qt * 32) < 32 ? (S - qt * 32) : 32;
+        stage_rows(scr, LDH, p.q + ((long)seq * S + qt * 32) * p.ld + head * hd, p.ld, qrows, 32, hd, p.scale, p.vec2, lane, 64);
         lds_fence();
         f32x4 qf[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const f32x4*>(&scr[fi * LDH + kk * 8 + fh * 4]);
         lds_fence();
 
-        // ---- scores: 32 queries x S keys in accumulators ---------------------------------------------
+        // ---- S^T = K Q^T: keys on rows, this lane's query on the column ---------------------------------
         f32x16 sc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            const float init = (t * 32 < S) ? 0.f : -INFINITY;      // a tile entirely beyond S is padding
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sc[t][r] = 0.f;
+            for (int r = 0; r < 16; ++r) sc[t][r] = init;
             if (t * 32 < S) {
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const f32x4 kf = *reinterpret_cast<const f32x4*>(&Kg[(t * 32 + fi) * LDH + kk * 8 + fh * 4]);
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[kk][u], kf[u], sc[t], 0, 0, 0);
+                        sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[u], qf[kk][u], sc[t], 0, 0, 0);
                 }
             }
         }
-        // ---- key padding / key mask: column = key index on this lane ---------------------------------
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int key = t * 32 + fi;
-            const bool pad = key >= S;
-            const bool masked = !pad && p.mask && p.mask[(long)seq * S + key] == 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (pad) sc[t][r] = -INFINITY;
-                else if (masked) sc[t][r] = -1e9f;        // masked_fill(mask == 0, -1e9), layers.py:233
-            }
-        }
-        // ---- row softmax: a row's keys sit on the 32 lanes of this half-wave x NT tiles ---------------
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float m = sc[0][r];
-#pragma unroll
-            for (int t = 1; t < NT; ++t) m = fmaxf(m, sc[t][r]);
-            m = wave_half_max(m);
-            float s = 0.f;
+        // ---- key padding / key mask (the key of register r is the same for a whole half-wave) ----------
+        if (need_flags) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float f = Fg[t * 32 + (r & 3) + 8 * (r >> 2) + krow];
+                    if (f == 2.f) sc[t][r] = -INFINITY;
+                    else if (f == 1.f) sc[t][r] = -1e9f;      // masked_fill(mask == 0, -1e9), layers.py:233
+                }
+            }
+        }
+        // ---- softmax over the keys of this lane's query: own registers, then the other half-wave ---------
+        float m = sc[0][0];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, sc[t][r]);
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
                 const float e = expf(sc[t][r] - m);
                 sc[t][r] = e;
-                s += e;
+                sum += e;
             }
-            const float inv = 1.0f / wave_half_sum(s);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) sc[t][r] *= inv;
         }
-        // ---- O = P V: each probability tile re-enters as the A operand through the scratch ------------
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        // ---- O^T = V^T P^T: probability registers are the B operand as they stand ----------------------
         f32x16 o;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] = 0.f;
@@ -136,28 +171,25 @@ __global__ __launch_bounds__(256) void token_attn_kernel(const AttnP p) {
         for (int t = 0; t < NT; ++t) {
             if (t * 32 < S) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * fh) * LDH + fi] = sc[t][r];
-                lds_fence();
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const f32x4 pf = *reinterpret_cast<const f32x4*>(&scr[fi * LDH + kk * 8 + fh * 4]);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float vv = Vg[(t * 32 + kk * 8 + fh * 4 + u) * LDV + fi];
-                        o = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[u], vv, o, 0, 0, 0);
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const float vv = Vg[(t * 32 + (r & 3) + 8 * (r >> 2) + krow) * LDV + fi];
+                    o = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, sc[t][r], o, 0, 0, 0);
                 }
-                lds_fence();
             }
         }
-        // ---- store: column = head dim on the lane, rows per the 32x32 C layout -----------------------
+        // ---- transpose [head dim][query] -> [query][head dim] through the scratch, store whole head rows ----
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scr[fi * LDO + (r & 3) + 8 * (r >> 2) + krow] = o[r] * inv;
+        lds_fence();
         if (fi < hd) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qi = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (qi < S) p.out[((long)seq * S + qi) * p.ldo + head * hd + fi] = o[r];
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 2 + fh;
+                const int qi = qt * 32 + row;
+                if (qi < S) p.out[((long)seq * S + qi) * p.ldo + head * hd + fi] = scr[row * LDO + fi];
             }
         }
+        lds_fence();
     }
 }
 
@@ -182,7 +214,9 @@ extern "C" int lime_token_attention_f32(const float* q, const float* k, const fl
     LIME_REQUIRE(ld_qkv >= (int64_t)n_head * head_dim && ldo >= (int64_t)n_head * head_dim, LIME_ERR_BAD_ARG,
                  "lime_token_attention_f32: leading dimension smaller than n_head * head_dim");
     if (n_seq == 0) return LIME_OK;
-    AttnP p{q, k, v, (long)ld_qkv, key_mask, out, (long)ldo, n_seq, S, n_head, head_dim, scale, n_seq * n_head};
+    // 8-byte loads need an even head_dim and leading dimension and 8-byte aligned bases
+    const int vec2 = (head_dim % 2 == 0) && (ld_qkv % 2 == 0) && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 8 == 0);
+    AttnP p{q, k, v, (long)ld_qkv, key_mask, out, (long)ldo, n_seq, S, n_head, head_dim, scale, n_seq * n_head, vec2};
     hipStream_t s = (hipStream_t)stream;
     const int nt = (S + 31) / 32;
     if (nt <= 1) return launch<1>(p, s);
