@@ -83,15 +83,24 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned vo
 __device__ __forceinline__ void buf_store1(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
 }
+__device__ __forceinline__ void buf_store4(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
 
 // TM x TN MFMA tiles (32x32) per wave, WM x WN waves per workgroup (4 or 8 waves).
-// LN:  a tile spans every output column (n_col_blocks == 1) and the epilogue applies LayerNorm; with WN > 1 the row
-//      statistics are combined across the WN waves that share a row through a small LDS exchange.
+// GENERIC (small 64x64 tiles): activation and residual placement are run-time switches; output rows sit in the
+//      accumulator registers (D = A W^T as the MFMA's C layout has it).
+// Big tiles (!GENERIC) compute the TRANSPOSED product D^T = W A^T (weights as the MFMA A operand): an output ROW is
+//      then a lane, and accumulator registers 4g .. 4g+3 are four consecutive COLUMNS of it -- residual loads and result
+//      stores are 16-byte vector accesses (20 instead of 80 per lane and tile), and the LayerNorm statistics are a sum
+//      over a lane's own registers plus one cross-half shuffle.
+//   LN:  a tile spans every output column (n_col_blocks == 1) and the epilogue applies LayerNorm; the statistics of
+//        the WN waves that share a row are combined through a small LDS exchange.  The residual (if any) is loaded
+//        straight into the accumulators at the tile boundary.
+//   ACT: compile-time activation of the non-LN big tiles (none / ReLU).
+//   VIO: 16-byte residual loads / result stores (needs N, ldc, ldr multiples of 4 and aligned bases).
 // PE:  the A operand is a gather with a positional table added (a_ids and a_pe both set).
-// ACT / RES: compile-time epilogue of the big tiles (activation none / ReLU; residual preloaded into the accumulators),
-//      so that the accumulator array only ever sees straight-line code.
-// GENERIC: small tiles -- activation, residual placement and gate are run-time switches (cheap at 16 accumulators).
-template <int TM, int TN, int WM, int WN, int VEC, bool LN, bool PE, int ACT, bool RES, bool GENERIC>
+template <int TM, int TN, int WM, int WN, int VEC, bool LN, bool PE, int ACT, bool GENERIC, bool VIO>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 1) void gemm_f32_kernel(const GemmP p) {
     constexpr int NT = WM * WN * 64;       // threads per workgroup
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -104,8 +113,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 
 
     __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
     __shared__ __attribute__((aligned(16))) float Ws[2][BN * LDK];
-    __shared__ float red_sum[(LN && WN > 1) ? WN * BM : 1];     // LayerNorm partials of the WN waves sharing a row
-    __shared__ float red_sq[(LN && WN > 1) ? WN * BM : 1];
+    __shared__ float red_sum[LN ? WN * BM : 1];                  // LayerNorm partials of the WN waves sharing a row
+    __shared__ float red_sq[LN ? WN * BM : 1];
+    __shared__ __attribute__((aligned(16))) float Bs[GENERIC ? 4 : BN];          // bias of the current tile's columns
+    __shared__ __attribute__((aligned(16))) float Gs[LN ? BN : 4], Es[LN ? BN : 4];   // LayerNorm gamma / beta
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntiles = p.n_row_blocks * p.n_col_blocks;
@@ -196,21 +207,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 
     f32x16 acc[TM][TN];
 
     // C layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-    // Residual operand of output element (i, r, j): lane part of the byte offset + wave-uniform part.
     const __amdgpu_buffer_rsrc_t rs_rpe = make_rsrc(p.res_pe ? p.res_pe : p.a);
-    auto residual = [&](long row0, int col0, int i, int r, int j, __amdgpu_buffer_rsrc_t rs_res, unsigned ro, unsigned po) {
-        const int col = wcol0 + j * 32 + fi;                        // column inside the tile
-        const bool cin = col0 + col < p.N;
-        float x = buf_load1(rs_res, (cin && ro != OOB) ? ro + col * 4 : OOB, col0 * 4);
-        if (p.res_pe) x += buf_load1(rs_rpe, (cin && ro != OOB) ? po + col * 4 : OOB, col0 * 4);
-        return x;
+    auto residual_rsrc = [&](long row0) {
+        return make_rsrc(p.res == nullptr ? p.a : (p.res_ids ? p.res : p.res + (row0 / p.res_div) * p.ldr));
     };
-    // row part of the residual offset (and of the positional table) for accumulator register r of MFMA tile i
-    auto residual_row = [&](long row0, int i, int r, unsigned& ro, unsigned& po) {
-        const int lrow = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        const long row = row0 + lrow;
+    // byte offset of output row `row` inside the residual operand (OOB when there is none), and inside the positional table
+    auto residual_row = [&](long row0, long row, unsigned& ro, unsigned& po) {
         ro = OOB; po = 0;
-        if (row < p.M) {
+        if (p.res != nullptr && row < p.M) {
             if (p.res_ids) {
                 ro = (unsigned)p.res_ids[row] * (unsigned)ldr4;
                 if (p.res_pe) po = (unsigned)(row % p.res_period) * (unsigned)((int)p.ldr_pe * 4);
@@ -219,33 +223,65 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 
             }
         }
     };
-    auto residual_rsrc = [&](long row0) {
-        return make_rsrc(p.res_ids ? p.res : p.res + (row0 / p.res_div) * p.ldr);
+    // one element of the residual: column `col` of the tile that starts at col0 (GENERIC layout)
+    auto residual1 = [&](int col0, int col, __amdgpu_buffer_rsrc_t rs_res, unsigned ro, unsigned po) {
+        const bool ok = (col0 + col < p.N) && ro != OOB;
+        float x = buf_load1(rs_res, ok ? ro + col * 4 : OOB, col0 * 4);
+        if (p.res_pe) x += buf_load1(rs_rpe, ok ? po + col * 4 : OOB, col0 * 4);
+        return x;
     };
 
-    // Accumulator init of a tile: zero, or the residual operand itself (plain residual add).
+    // Accumulator init of a tile: zero, or the residual operand itself (plain residual add; no operand -> every
+    // offset is out of range and the loads return zero, so there is no branch around the accumulators).
     auto acc_init = [&](int tile) {
-        const bool use_res = GENERIC ? (p.res_in_acc != 0) : RES;
-        if (!use_res) {
+        long row0; int col0;
+        tile_rc(tile, row0, col0);
+        if constexpr (!GENERIC) {
+            if (tid < BN) Bs[tid] = (p.bias && col0 + tid < p.N) ? p.bias[col0 + tid] : 0.f;     // read after a barrier
+        }
+        if constexpr (GENERIC) {
+            const bool use_res = p.res_in_acc != 0;
+            const __amdgpu_buffer_rsrc_t rs_res = residual_rsrc(row0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    unsigned ro = OOB, po = 0;
+                    if (use_res) residual_row(row0, row0 + wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh, ro, po);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j][r] = residual1(col0, wcol0 + j * 32 + fi, rs_res, ro, po);
+                }
+            }
+        } else if constexpr (!LN) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-            return;
-        }
-        long row0; int col0;
-        tile_rc(tile, row0, col0);
-        const __amdgpu_buffer_rsrc_t rs_res = residual_rsrc(row0);
+        } else {
+            const __amdgpu_buffer_rsrc_t rs_res = residual_rsrc(row0);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int i = 0; i < TM; ++i) {
                 unsigned ro, po;
-                residual_row(row0, i, r, ro, po);
+                residual_row(row0, row0 + wrow0 + i * 32 + fi, ro, po);          // this lane's output row
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j][r] = residual(row0, col0, i, r, j, rs_res, ro, po);
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nl = wcol0 + j * 32 + 8 * g + 4 * fh;            // first of 4 consecutive columns
+                        if constexpr (VIO) {
+                            const bool ok = (col0 + nl < p.N) && ro != OOB;
+                            f32x4 x = buf_load<4>(rs_res, ok ? ro + nl * 4 : OOB, col0 * 4);
+                            if (p.res_pe) x += buf_load<4>(rs_rpe, ok ? po + nl * 4 : OOB, col0 * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = x[e];
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = residual1(col0, nl + e, rs_res, ro, po);
+                        }
+                    }
+                }
             }
         }
     };
@@ -262,8 +298,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][u], wf[j][u], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (GENERIC) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][u], wf[j][u], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j][u], af[i][u], acc[i][j], 0, 0, 0);   // D^T = W A^T
+                }
     };
 
     // bias / act / LayerNorm / store of the finished tile.  Rows / columns outside the matrix are neutralised by a
@@ -271,26 +309,20 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 
     auto epilogue = [&](int tile) {
         long row0; int col0;
         tile_rc(tile, row0, col0);
-        float bias[TN], lng[LN ? TN : 1], lnb[LN ? TN : 1];
-        bool cin[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = col0 + wcol0 + j * 32 + fi;
-            cin[j] = col < p.N;
-            bias[j] = (p.bias && cin[j]) ? p.bias[col] : 0.f;
-            if constexpr (LN) {
-                lng[j] = cin[j] ? p.ln_g[col] : 0.f;
-                lnb[j] = cin[j] ? p.ln_b[col] : 0.f;
-            }
-        }
-        const int wn = wave % WN;
         const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(p.c + row0 * p.ldc);
-        const unsigned c_lane = (unsigned)((wrow0 + 4 * fh) * ldc4 + (wcol0 + fi) * 4);
         const long rows_left = p.M - row0;
-
-        if constexpr (!LN) {
-            // row by row: activation (+ late residual) and store; nothing is written back to the accumulators
-            const bool late_res = GENERIC && p.res != nullptr && !p.res_in_acc;
+        if constexpr (GENERIC) {
+            // row by row: activation (+ late residual) and store
+            float bias[TN];
+            bool cin[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = col0 + wcol0 + j * 32 + fi;
+                cin[j] = col < p.N;
+                bias[j] = (p.bias && cin[j]) ? p.bias[col] : 0.f;
+            }
+            const unsigned c_lane = (unsigned)((wrow0 + 4 * fh) * ldc4 + (wcol0 + fi) * 4);
+            const bool late_res = p.res != nullptr && !p.res_in_acc;
             const __amdgpu_buffer_rsrc_t rs_res = residual_rsrc(row0);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -299,104 +331,113 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 
                     const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
                     const bool rin = (wrow0 + 4 * fh + rr) < rows_left;
                     unsigned ro = OOB, po = 0;
-                    if (late_res) residual_row(row0, i, r, ro, po);
+                    if (late_res) residual_row(row0, row0 + wrow0 + 4 * fh + rr, ro, po);
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        float v = acc[i][j][r] + bias[j];
-                        if constexpr (GENERIC) {
-                            v = apply_act(v, p.act);
-                            if (late_res) v += residual(row0, col0, i, r, j, rs_res, ro, po);
-                        } else if constexpr (ACT == LIME_ACT_RELU) {
-                            v = fmaxf(v, 0.f);
-                        }
+                        float v = apply_act(acc[i][j][r] + bias[j], p.act);
+                        if (late_res) v += residual1(col0, wcol0 + j * 32 + fi, rs_res, ro, po);
                         buf_store1(v, rs_c, (rin && cin[j]) ? c_lane : OOB, rr * ldc4 + (col0 + j * 32) * 4);
                     }
                 }
             }
         } else {
-            // LayerNorm over the row: two passes, like the reference's (x - mean)^2; values stay in the accumulators
-            const float inv_n = 1.0f / (float)p.N;
-            float stat[TM][16];
+            __syncthreads();                               // Bs (written in acc_init) is visible even when a tile has one chunk
+            const int wn = wave % WN;
+            float mean[TM], rstd[TM];
+            if constexpr (LN) {
+                const float inv_n = 1.0f / (float)p.N;
+                const float lo = (p.act == LIME_ACT_RELU) ? 0.f : -INFINITY;      // ReLU as a branch-free clamp
+                // pass 1: v = acc + bias, row sum over this lane's registers, the other half-wave, the other waves
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int i = 0; i < TM; ++i) {
                     float sum = 0.f;
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        float v = acc[i][j][r] + bias[j];
-                        if constexpr (ACT == LIME_ACT_RELU) v = fmaxf(v, 0.f);
-                        v = cin[j] ? v : 0.f;
-                        acc[i][j][r] = v;
-                        sum += v;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int nl = wcol0 + j * 32 + 8 * g + 4 * fh;
+                            const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[nl]);
+                            // columns beyond N hold exact zeros already: W rows beyond N stage as zeros, the residual
+                            // load is out of range there and Bs is zero-filled -- no select needed in this pass
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float v = fmaxf(acc[i][j][4 * g + e] + b[e], lo);
+                                acc[i][j][4 * g + e] = v;
+                                sum += v;
+                            }
+                        }
                     }
-                    sum = wave_half_sum(sum);
-                    if constexpr (WN > 1) {
-                        const int lrow = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                        if (fi == 0) red_sum[wn * BM + lrow] = sum;
-                    } else {
-                        stat[i][r] = sum * inv_n;
-                    }
+                    sum += __shfl_xor(sum, 32);
+                    if (fh == 0) red_sum[wn * BM + wrow0 + i * 32 + fi] = sum;
                 }
-            }
-            if constexpr (WN > 1) {
                 __syncthreads();
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
+                    float tot = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int lrow = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                        float tot = 0.f;
-#pragma unroll
-                        for (int w = 0; w < WN; ++w) tot += red_sum[w * BM + lrow];
-                        stat[i][r] = tot * inv_n;
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                    for (int w = 0; w < WN; ++w) tot += red_sum[w * BM + wrow0 + i * 32 + fi];
+                    mean[i] = tot * inv_n;
                     float q = 0.f;
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        const float d = cin[j] ? acc[i][j][r] - stat[i][r] : 0.f;
-                        acc[i][j][r] = d;
-                        q += d * d;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int nl = wcol0 + j * 32 + 8 * g + 4 * fh;
+                            const bool gin = nl < p.N;                 // VIO: N % 4 == 0, a group is in or out as a whole
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const bool in = VIO ? gin : (nl + e < p.N);
+                                const float d = in ? acc[i][j][4 * g + e] - mean[i] : 0.f;
+                                acc[i][j][4 * g + e] = d;
+                                q += d * d;
+                            }
+                        }
                     }
-                    q = wave_half_sum(q);
-                    if constexpr (WN > 1) {
-                        const int lrow = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                        if (fi == 0) red_sq[wn * BM + lrow] = q;
-                    } else {
-                        stat[i][r] = 1.0f / sqrtf(q * inv_n + p.ln_eps);
-                    }
+                    q += __shfl_xor(q, 32);
+                    if (fh == 0) red_sq[wn * BM + wrow0 + i * 32 + fi] = q;
                 }
-            }
-            if constexpr (WN > 1) {
                 __syncthreads();
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
+                    float tot = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int lrow = wrow0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                        float tot = 0.f;
-#pragma unroll
-                        for (int w = 0; w < WN; ++w) tot += red_sq[w * BM + lrow];
-                        stat[i][r] = 1.0f / sqrtf(tot * inv_n + p.ln_eps);
-                    }
+                    for (int w = 0; w < WN; ++w) tot += red_sq[w * BM + wrow0 + i * 32 + fi];
+                    rstd[i] = 1.0f / sqrtf(tot * inv_n + p.ln_eps);
                 }
             }
+            // result: 4 consecutive columns per register group -> one 16-byte store
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
+                const bool rin = (wrow0 + i * 32 + fi) < rows_left;
+                const unsigned c_lane = (unsigned)((wrow0 + i * 32 + fi) * ldc4 + (wcol0 + 4 * fh) * 4);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
-                    const bool rin = (wrow0 + 4 * fh + rr) < rows_left;
+                for (int j = 0; j < TN; ++j) {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        buf_store1(acc[i][j][r] * stat[i][r] * lng[j] + lnb[j], rs_c, (rin && cin[j]) ? c_lane : OOB,
-                                   rr * ldc4 + (col0 + j * 32) * 4);
+                    for (int g = 0; g < 4; ++g) {
+                        const int nl = wcol0 + j * 32 + 8 * g + 4 * fh;
+                        f32x4 v;
+                        if constexpr (LN) {
+                            const f32x4 ga = *reinterpret_cast<const f32x4*>(&Gs[nl]);
+                            const f32x4 be = *reinterpret_cast<const f32x4*>(&Es[nl]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * rstd[i] * ga[e] + be[e];
+                        } else {
+                            const f32x4 b = *reinterpret_cast<const f32x4*>(&Bs[nl]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[e] = acc[i][j][4 * g + e] + b[e];
+                                if constexpr (ACT == LIME_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                            }
+                        }
+                        const int soff = (col0 + j * 32 + 8 * g) * 4;
+                        if constexpr (VIO) {
+                            buf_store4(v, rs_c, (rin && col0 + nl < p.N) ? c_lane : OOB, soff);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                buf_store1(v[e], rs_c, (rin && col0 + nl + e < p.N) ? c_lane + e * 4 : OOB, soff);
+                        }
+                    }
                 }
             }
         }
@@ -406,6 +447,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 
     // Outer loop over this workgroup's tiles, inner loop over a tile's full chunks, the (possibly partial) last chunk
     // peeled: the accumulators only ever flow through straight-line code and plain loops -- any if-merge that
     // touches them makes hipcc copy the whole 64..80-register array at the merge point.
+    if constexpr (LN) {
+        if (tid < BN) {
+            Gs[tid] = tid < p.N ? p.ln_g[tid] : 0.f;
+            Es[tid] = tid < p.N ? p.ln_b[tid] : 0.f;
+        }
+    }
     prefetch_ids(first);
     loader_set_tile(first);
     prefetch_ids(first + nwg);
@@ -459,7 +506,7 @@ int num_cus() {
     return n;
 }
 
-template <int TM, int TN, int WM, int WN, int VEC, bool LN, bool PE, int ACT, bool RES, bool GENERIC>
+template <int TM, int TN, int WM, int WN, int VEC, bool LN, bool PE, int ACT, bool GENERIC, bool VIO>
 int launch_one(const GemmP& p0, int wg_per_cu, hipStream_t stream) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     GemmP p = p0;
@@ -468,26 +515,17 @@ int launch_one(const GemmP& p0, int wg_per_cu, hipStream_t stream) {
     const long ntiles = (long)p.n_row_blocks * p.n_col_blocks;
     long nwg = (long)num_cus() * wg_per_cu;
     if (nwg > ntiles) nwg = ntiles;
-    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, WM, WN, VEC, LN, PE, ACT, RES, GENERIC>), dim3((unsigned)nwg), dim3(WM * WN * 64), 0,
+    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, WM, WN, VEC, LN, PE, ACT, GENERIC, VIO>), dim3((unsigned)nwg), dim3(WM * WN * 64), 0,
                        stream, p);
     return lime_check_launch("lime_linear_f32");
-}
-
-// big tiles (eight waves, 128 x TN*64): compile-time epilogue
-template <int TN, bool LN, int ACT, bool RES>
-int launch_big(const GemmP& p, int vec, hipStream_t s) {
-    const bool pe = p.a_pe != nullptr;
-    if (vec == 4) return pe ? launch_one<1, TN, 4, 2, 4, LN, true, ACT, RES, false>(p, 1, s) : launch_one<1, TN, 4, 2, 4, LN, false, ACT, RES, false>(p, 1, s);
-    if (vec == 2) return pe ? launch_one<1, TN, 4, 2, 2, LN, true, ACT, RES, false>(p, 1, s) : launch_one<1, TN, 4, 2, 2, LN, false, ACT, RES, false>(p, 1, s);
-    return pe ? launch_one<1, TN, 4, 2, 1, LN, true, ACT, RES, false>(p, 1, s) : launch_one<1, TN, 4, 2, 1, LN, false, ACT, RES, false>(p, 1, s);
 }
 
 // small tiles (four waves, 64 x 64): everything at run time
 int launch_small(const GemmP& p, int vec, hipStream_t s) {
     const bool pe = p.a_pe != nullptr;
-    if (vec == 4) return pe ? launch_one<1, 1, 2, 2, 4, false, true, 0, false, true>(p, 4, s) : launch_one<1, 1, 2, 2, 4, false, false, 0, false, true>(p, 4, s);
-    if (vec == 2) return pe ? launch_one<1, 1, 2, 2, 2, false, true, 0, false, true>(p, 4, s) : launch_one<1, 1, 2, 2, 2, false, false, 0, false, true>(p, 4, s);
-    return pe ? launch_one<1, 1, 2, 2, 1, false, true, 0, false, true>(p, 4, s) : launch_one<1, 1, 2, 2, 1, false, false, 0, false, true>(p, 4, s);
+    if (vec == 4) return pe ? launch_one<1, 1, 2, 2, 4, false, true, 0, true, false>(p, 4, s) : launch_one<1, 1, 2, 2, 4, false, false, 0, true, false>(p, 4, s);
+    if (vec == 2) return pe ? launch_one<1, 1, 2, 2, 2, false, true, 0, true, false>(p, 4, s) : launch_one<1, 1, 2, 2, 2, false, false, 0, true, false>(p, 4, s);
+    return pe ? launch_one<1, 1, 2, 2, 1, false, true, 0, true, false>(p, 4, s) : launch_one<1, 1, 2, 2, 1, false, false, 0, true, false>(p, 4, s);
 }
 
 inline bool aligned(const void* ptr, long ld, int vec) {
@@ -531,29 +569,34 @@ extern "C" int lime_linear_f32(const lime_linear_args* a, void* stream) {
         vec >>= 1;
     hipStream_t s = (hipStream_t)stream;
     // Tile selection.
-    //   LayerNorm epilogue: one 128 x 256 / 128 x 320 tile spans the row (N <= 320); residual (if any) is preloaded into
-    //   the accumulators, so it must be a plain add (no activation in between).
-    //   Big M without LayerNorm, activation none / ReLU, no residual: the same eight-wave tiles, the width (256 / 320)
-    //   that pads N least.  Everything else (tanh / sigmoid, residual without LayerNorm, small M): 64 x 64 tiles.
+    //   LayerNorm epilogue: one eight-wave 128 x 256 / 128 x 320 tile spans the row (N <= 320); the residual (if any) is
+    //   preloaded into the accumulators, so it must be a plain add.  Fast instantiation: 16-byte operand staging and
+    //   16-byte residual / result accesses; anything misaligned takes the scalar-IO instantiation.
+    //   Big M, no residual, activation none / ReLU, everything 16-byte friendly: the same eight-wave tiles, the width
+    //   (256 / 320) that pads N least.  Everything else: 64 x 64 tiles with run-time epilogue.
     const bool has_res = a->res != nullptr;
+    const bool vio = vec == 4 && (a->N % 4 == 0) && aligned(a->c, a->ldc, 4) && aligned(a->res, a->ldr, 4) &&
+                     aligned(a->res_pe, a->ldr_pe, 4);
     if (a->ln_gamma) {
         LIME_REQUIRE(a->N <= 320, LIME_ERR_UNSUPPORTED, "lime_linear_f32: LayerNorm epilogue needs N <= 320 (N=%d)", a->N);
         LIME_REQUIRE(a->act == LIME_ACT_NONE || (a->act == LIME_ACT_RELU && !has_res), LIME_ERR_UNSUPPORTED,
                      "lime_linear_f32: LayerNorm epilogue supports act none (+ residual) or ReLU (no residual)");
-        const bool relu = a->act == LIME_ACT_RELU;
-        if (a->N <= 256) {
-            if (relu) return launch_big<4, true, LIME_ACT_RELU, false>(p, vec, s);
-            return has_res ? launch_big<4, true, LIME_ACT_NONE, true>(p, vec, s) : launch_big<4, true, LIME_ACT_NONE, false>(p, vec, s);
-        }
-        if (relu) return launch_big<5, true, LIME_ACT_RELU, false>(p, vec, s);
-        return has_res ? launch_big<5, true, LIME_ACT_NONE, true>(p, vec, s) : launch_big<5, true, LIME_ACT_NONE, false>(p, vec, s);
+        LIME_REQUIRE(a->a_pe == nullptr, LIME_ERR_UNSUPPORTED, "lime_linear_f32: LayerNorm epilogue with a positional A operand");
+        if (a->N <= 256) return vio ? launch_one<1, 4, 4, 2, 4, true, false, 0, false, true>(p, 1, s)
+                                    : launch_one<1, 4, 4, 2, 1, true, false, 0, false, false>(p, 1, s);
+        return vio ? launch_one<1, 5, 4, 2, 4, true, false, 0, false, true>(p, 1, s)
+                   : launch_one<1, 5, 4, 2, 1, true, false, 0, false, false>(p, 1, s);
     }
     const bool simple = !has_res && (a->act == LIME_ACT_NONE || a->act == LIME_ACT_RELU);
-    if (a->M >= 4096 && simple) {
+    if (a->M >= 4096 && simple && vio) {
         const int pad5 = (a->N + 319) / 320 * 320 - a->N, pad4 = (a->N + 255) / 256 * 256 - a->N;
-        const bool relu = a->act == LIME_ACT_RELU;
-        if (pad5 < pad4) return relu ? launch_big<5, false, LIME_ACT_RELU, false>(p, vec, s) : launch_big<5, false, LIME_ACT_NONE, false>(p, vec, s);
-        return relu ? launch_big<4, false, LIME_ACT_RELU, false>(p, vec, s) : launch_big<4, false, LIME_ACT_NONE, false>(p, vec, s);
+        const bool relu = a->act == LIME_ACT_RELU, pe = a->a_pe != nullptr;
+        if (pad5 < pad4) {
+            if (pe) return relu ? launch_one<1, 5, 4, 2, 4, false, true, 1, false, true>(p, 1, s) : launch_one<1, 5, 4, 2, 4, false, true, 0, false, true>(p, 1, s);
+            return relu ? launch_one<1, 5, 4, 2, 4, false, false, 1, false, true>(p, 1, s) : launch_one<1, 5, 4, 2, 4, false, false, 0, false, true>(p, 1, s);
+        }
+        if (pe) return relu ? launch_one<1, 4, 4, 2, 4, false, true, 1, false, true>(p, 1, s) : launch_one<1, 4, 4, 2, 4, false, true, 0, false, true>(p, 1, s);
+        return relu ? launch_one<1, 4, 4, 2, 4, false, false, 1, false, true>(p, 1, s) : launch_one<1, 4, 4, 2, 4, false, false, 0, false, true>(p, 1, s);
     }
     return launch_small(p, vec, s);
 }
