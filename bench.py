@@ -78,11 +78,11 @@ def main():
         args.gpus = world
     assert torch.cuda.is_available(), 'bench.py needs the MI355X (the product path has no CPU fallback)'
     torch.cuda.set_device(local_rank)
+    from lime_cikm25_amd import distributed as D
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        D.init(backend='nccl', device_id=torch.device('cuda', local_rank))      # "nccl" is RCCL on ROCm
 
     from lime_cikm25_amd import Model, make_config, ops, synth
     overrides, B, N, desc = WORKLOADS[args.workload]
@@ -112,10 +112,7 @@ def main():
         logits = model(*batch)
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = D.max_over_ranks(dt, device='cuda')                     # the slowest rank's time
     assert torch.isfinite(logits).all()
     # Per-kernel durations: the same K steps again, launched eagerly with a HIP event pair recorded on the launch
     # stream around every lime_linear_f32 launch (events cannot be recorded inside a graph replay).

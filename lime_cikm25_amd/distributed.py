@@ -1,0 +1,53 @@
+"""One-process-per-GPU helpers for the scoring path.
+
+Impression rows are independent, so ranks score disjoint row shards with no data-path collective; the only
+collectives are the barrier / max-time reduction of the benchmark and an optional all_gather of the scores for
+metrics.  Backend: "nccl" (= RCCL over xGMI on ROCm) on GPUs, "gloo" in the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend=None, device_id=None):
+    """Initialise from the torchrun environment (RANK / WORLD_SIZE / MASTER_*); returns (rank, world)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        kw = {}
+        if device_id is not None:
+            kw['device_id'] = device_id
+        dist.init_process_group(backend=backend or ('nccl' if torch.cuda.is_available() else 'gloo'), **kw)
+    return rank, world
+
+
+def shard_rows(n_rows, rank, world):
+    """Contiguous shard [lo, hi) of rank `rank`: scoring keeps the row order, remainders go to the first ranks."""
+    base, rem = divmod(n_rows, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def max_over_ranks(seconds, device='cpu'):
+    """The slowest rank's time (what bench.py divides the total work by)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(seconds)
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_scores(local_scores, n_rows):
+    """all_gather of per-shard score vectors back into row order (shards may differ by one row)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local_scores
+    world = dist.get_world_size()
+    sizes = [shard_rows(n_rows, r, world) for r in range(world)]
+    width = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((width,) + tuple(local_scores.shape[1:]), dtype=local_scores.dtype, device=local_scores.device)
+    pad[:local_scores.shape[0]] = local_scores
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([b[:hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)

@@ -33,18 +33,18 @@ def _linear_variant(M, N, K, ln, a, w, a_pe):
     return vec
 
 
-def linear_kernel_name(M, N, K, act, has_res, ln, vec, pe):
-    """The gemm_f32_kernel instantiation lime_linear_f32 dispatches to (mirrors the tile selection in csrc/gemm_f32.hip)."""
+def linear_kernel_name(M, N, K, act, ln, vec, pe, vio, has_res):
+    """The gemm_f32_kernel<TM, TN, WM, WN, VEC, LN, PE, ACT, GENERIC, VIO> instantiation lime_linear_f32 dispatches to
+    (mirrors the tile selection at the end of csrc/gemm_f32.hip; used by bench.py to label its per-kernel timings)."""
     t = lambda b: 'true' if b else 'false'
     if ln:
         tn = 4 if N <= 256 else 5
-        return 'gemm_f32_kernel<1, %d, 4, 2, %d, true, %s, %d, %s, false>' % (tn, vec, t(pe), 1 if act == 'relu' else 0,
-                                                                             t(has_res and act != 'relu'))
-    if M >= 4096 and not has_res and act in (None, 'none', 'relu'):
+        return 'gemm_f32_kernel<1, %d, 4, 2, %d, true, false, 0, false, %s>' % (tn, 4 if vio else 1, t(vio))
+    if M >= 4096 and not has_res and act in (None, 'none', 'relu') and vio:
         pad5, pad4 = (N + 319) // 320 * 320 - N, (N + 255) // 256 * 256 - N
         tn = 5 if pad5 < pad4 else 4
-        return 'gemm_f32_kernel<1, %d, 4, 2, %d, false, %s, %d, false, false>' % (tn, vec, t(pe), 1 if act == 'relu' else 0)
-    return 'gemm_f32_kernel<1, 1, 2, 2, %d, false, %s, 0, false, true>' % (vec, t(pe))
+        return 'gemm_f32_kernel<1, %d, 4, 2, 4, false, %s, %d, false, true>' % (tn, t(pe), 1 if act == 'relu' else 0)
+    return 'gemm_f32_kernel<1, 1, 2, 2, %d, false, %s, 0, true, false>' % (vec, t(pe))
 
 
 def _p(t):
@@ -144,8 +144,11 @@ def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=
         e0.record()
         check(lib.lime_linear_f32(ctypes.byref(args), _stream()), 'lime_linear_f32')
         e1.record()
-        PROFILE.append((linear_kernel_name(M, N, K, act, res is not None, ln is not None,
-                                           _linear_variant(M, N, K, ln is not None, a, w, a_pe), a_pe is not None), M, N, K, e0, e1))
+        vec = _linear_variant(M, N, K, ln is not None, a, w, a_pe)
+        al4 = lambda t: t is None or (t.data_ptr() % 16 == 0 and _ld(t) % 4 == 0)
+        vio = vec == 4 and N % 4 == 0 and al4(out) and al4(res) and al4(res_pe)
+        PROFILE.append((linear_kernel_name(M, N, K, act, ln is not None, vec, a_pe is not None, vio, res is not None),
+                        M, N, K, e0, e1))
         return out
     check(lib.lime_linear_f32(ctypes.byref(args), _stream()), 'lime_linear_f32')
     return out
