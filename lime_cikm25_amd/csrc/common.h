@@ -59,6 +59,15 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + s_barrier, and the fence
+// also waits vmcnt(0): every global load still in flight (a prefetch) and every store (an epilogue) would be drained
+// at each barrier.  The kernels here exchange data between waves through LDS only.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ float lime_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // XCD-aware bijective remap of a 1-D grid: the 8 XCDs take workgroups round-robin by blockIdx, so

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 
                 }
             }
         } else {
-            __syncthreads();                               // Bs (written in acc_init) is visible even when a tile has one chunk
+            lds_barrier();                               // Bs (written in acc_init) is visible even when a tile has one chunk
             const int wn = wave % WN;
             float mean[TM], rstd[TM];
             if constexpr (LN) {
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 
                     sum += __shfl_xor(sum, 32);
                     if (fh == 0) red_sum[wn * BM + wrow0 + i * 32 + fi] = sum;
                 }
-                __syncthreads();
+                lds_barrier();
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     float tot = 0.f;
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 
                     q += __shfl_xor(q, 32);
                     if (fh == 0) red_sq[wn * BM + wrow0 + i * 32 + fi] = q;
                 }
-                __syncthreads();
+                lds_barrier();
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     float tot = 0.f;
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 
     prefetch_ids(first + nwg);
     issue(0);
     commit(0);
-    __syncthreads();
+    lds_barrier();
     int buf = 0;
     for (int tile = first; tile < ntiles; tile += nwg) {
         const bool more = tile + nwg < ntiles;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 
             for (int s = 0; s < BK / 8; ++s) k8_step(Ab, Wb, s);
             __builtin_amdgcn_sched_barrier(0);        // ... and its waits + LDS writes BELOW them
             commit(buf ^ 1);
-            __syncthreads();
+            lds_barrier();
             buf ^= 1;
         }
         // last chunk of the tile: the loader moves on to the next tile first
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 
         __builtin_amdgcn_sched_barrier(0);
         epilogue(tile);
         if (more) commit(buf ^ 1);
-        __syncthreads();
+        lds_barrier();
         buf ^= 1;
     }
 }

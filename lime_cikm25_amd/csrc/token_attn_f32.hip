@@ -15,189 +15,269 @@
 //     staged V image per MFMA;
 //   * 1/sum is applied to the 16 output registers, not to the S probabilities.
 // The output tile O^T (head dim on rows, query on lanes) is transposed through a 4 KiB per-wave LDS
-// scratch so the store writes whole 120-byte head rows.  K and V of a (sequence, head) pair are staged
-// once per workgroup with 8-byte loads; short sequences pack 4 (S <= 32) or 2 (S <= 64) pairs per
-// workgroup.
+// scratch so the store writes whole 120-byte head rows.  Workgroups are persistent: K and V of the next
+// (sequence, head) group are prefetched into registers (8-byte loads) while the current one is computed from
+// LDS; Q fragments come straight from global memory in MFMA operand form; short sequences pack 4 (S <= 32)
+// or 2 (S <= 64) pairs per group.  Scores live in the log2 domain so the exponential is one v_exp_f32.
 #include "common.h"
 
 namespace {
 
-constexpr int LDH = 36;  // pitch of K / Q rows in LDS (floats): conflict-free ds_read_b128
+constexpr int LDH = 36;  // pitch of K rows in LDS (floats): conflict-free ds_read_b128
 constexpr int LDV = 32;  // pitch of V rows: a half-wave reads 32 consecutive floats of one key
 constexpr int LDO = 33;  // pitch of the output transpose scratch
+constexpr float LOG2E = 1.4426950408889634f;
 
 struct AttnP {
     const float* q; const float* k; const float* v; long ld; const unsigned char* mask;
-    float* out; long ldo; int n_seq, S, n_head, hd; float scale; int n_pair; int vec2;
+    float* out; long ldo; int n_seq, S, n_head, hd; float scale; int n_pair; int vec2; int n_group;
 };
 
 __device__ __forceinline__ void lds_fence() {
-    // LDS ops of one wave execute in order; this keeps the compiler from reordering across the point
-    // and drains lgkmcnt so that a tile written by some lanes is read back by others
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // LDS ops of one wave execute in order; drain lgkmcnt so that a tile written by some lanes is read back by
+    // others, and keep the compiler from moving memory ops across the point.  Deliberately NOT a workgroup-scope
+    // fence: that also waits vmcnt(0), i.e. for the K / V prefetch and the output stores still in flight.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// rows [0, rows) x head_dim of one (sequence, head) operand -> LDS image with `pitch`, zero-filled to 32 columns and
-// to `rows_padded` rows; `nthr` threads starting at `t0` cooperate.  src points at (first row, head column 0).
-__device__ __forceinline__ void stage_rows(float* dst, int pitch, const float* src, long ld, int rows, int rows_padded, int hd,
-                                           float scale, bool vec2, int t0, int nthr) {
-    if (vec2) {
-        const int pairs = 16;                                   // 32 columns as 16 float2
-        for (int e = t0; e < rows_padded * pairs; e += nthr) {
-            const int c = (e % pairs) * 2, r = e / pairs;
-            f32x2 v = {0.f, 0.f};
-            if (r < rows && c < hd) v = *reinterpret_cast<const f32x2*>(src + (long)r * ld + c);   // hd even: c + 1 < hd
-            dst[r * pitch + c] = v[0] * scale;
-            dst[r * pitch + c + 1] = v[1] * scale;
-        }
+// Two floats of row `r`, columns c, c+1 of a (sequence, head) operand; zero outside [0, rows) x [0, hd).
+// FAST: rows are all valid and hd is even / 8-byte aligned -> one unconditional 8-byte load (column clamped) + select.
+template <bool FAST>
+__device__ __forceinline__ f32x2 load2(const float* src, long ld, int r, int c, int rows, int hd, bool vec2) {
+    if constexpr (FAST) {
+        const int cc = c < hd ? c : hd - 2;
+        f32x2 v = *reinterpret_cast<const f32x2*>(src + (long)r * ld + cc);
+        if (c >= hd) v = f32x2{0.f, 0.f};
+        return v;
     } else {
-        for (int e = t0; e < rows_padded * 32; e += nthr) {
-            const int c = e & 31, r = e >> 5;
-            float v = 0.f;
-            if (r < rows && c < hd) v = src[(long)r * ld + c];
-            dst[r * pitch + c] = v * scale;
+        f32x2 v = {0.f, 0.f};
+        if (r < rows) {
+            const float* p = src + (long)r * ld + c;
+            if (vec2) {
+                if (c < hd) v = *reinterpret_cast<const f32x2*>(p);          // hd even: c + 1 < hd as well
+            } else {
+                if (c < hd) v[0] = p[0];
+                if (c + 1 < hd) v[1] = p[1];
+            }
         }
+        return v;
     }
 }
 
-template <int NT>
-__global__ __launch_bounds__(256) void token_attn_kernel(const AttnP p) {
-    constexpr int G = (NT >= 3) ? 1 : (4 / NT);   // (sequence, head) pairs per workgroup
+// A workgroup walks groups of G (sequence, head) pairs: K / V of the next group are prefetched into registers while
+// the current group is computed from LDS (the staging latency of a one-shot workgroup was half its life).
+// FAST: S == NT * 32, no key mask, 8-byte loads -- no flag pass, no bounds branches (the title / body shapes of the
+// encoder layers); otherwise the general path with per-key flags.  The score strip never crosses an if-merge: hipcc
+// copies the whole accumulator array at a merge.
+template <int NT, bool FAST>
+__global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_attn_kernel(const AttnP p) {
+    constexpr int G = (NT >= 3) ? 1 : (4 / NT);   // (sequence, head) pairs per group
     constexpr int WPP = 4 / G;                     // waves per pair
     constexpr int SP = NT * 32;                    // padded sequence length
+    constexpr int NLD = G * SP * 16 / 256;         // float2 per thread and operand for one group
+    constexpr bool PREFETCH = NT == 3 || NT == 4;  // short sequences are latency-bound either way; long ones need the registers
     __shared__ __attribute__((aligned(16))) float Ks[G * SP * LDH];
     __shared__ __attribute__((aligned(16))) float Vs[G * SP * LDV];
-    __shared__ __attribute__((aligned(16))) float Scr[4 * 32 * LDH];
+    __shared__ __attribute__((aligned(16))) float Scr[4 * 32 * LDO];
     __shared__ float Flag[G * SP];                // 0: key takes part, 1: masked (-1e9), 2: padding (-inf)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 31, fh = lane >> 5;
     const int S = p.S, hd = p.hd;
-    const bool need_flags = p.mask != nullptr || (S & 31) != 0;
+    const bool vec2 = p.vec2 != 0;
+    const int krow = 4 * fh;                       // key row of accumulator register r: (r & 3) + 8 * (r >> 2) + 4 * fh
 
-    // ---- stage K and V of this workgroup's pairs: WPP waves per pair ---------------------------------
-    {
-        const int g = wave / WPP;
-        const int pair = blockIdx.x * G + g;
-        const int t0 = (wave % WPP) * 64 + lane, nthr = WPP * 64;
-        if (pair < p.n_pair) {
-            const int seq = pair / p.n_head, head = pair - seq * p.n_head;
-            const long base = (long)seq * S * p.ld + head * hd;
-            stage_rows(&Ks[g * SP * LDH], LDH, p.k + base, p.ld, S, SP, hd, 1.0f, p.vec2, t0, nthr);
-            stage_rows(&Vs[g * SP * LDV], LDV, p.v + base, p.ld, S, SP, hd, 1.0f, p.vec2, t0, nthr);
-            if (need_flags)
-                for (int key = t0; key < SP; key += nthr)
-                    Flag[g * SP + key] = key >= S ? 2.f : ((p.mask && p.mask[(long)seq * S + key] == 0) ? 1.f : 0.f);
+    f32x2 kreg[NLD], vreg[NLD];
+    auto fetch = [&](int group) {                  // this thread's share of the group's K / V -> registers
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + i * 256;
+            const int c = (e & 15) * 2, r = (e >> 4) % SP, g = (e >> 4) / SP;
+            const int pair = group * G + g;
+            f32x2 kv = {0.f, 0.f}, vv = {0.f, 0.f};
+            if (pair < p.n_pair) {
+                const int seq = pair / p.n_head, head = pair - seq * p.n_head;
+                const long base = (long)seq * S * p.ld + head * hd;
+                kv = load2<FAST>(p.k + base, p.ld, r, c, S, hd, vec2);
+                vv = load2<FAST>(p.v + base, p.ld, r, c, S, hd, vec2);
+            }
+            kreg[i] = kv;
+            vreg[i] = vv;
         }
-    }
-    __syncthreads();
+    };
+    auto stash = [&](int group) {                  // registers -> LDS images (+ key flags)
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + i * 256;
+            const int c = (e & 15) * 2, r = (e >> 4) % SP, g = (e >> 4) / SP;
+            *reinterpret_cast<f32x2*>(&Ks[(g * SP + r) * LDH + c]) = kreg[i];
+            *reinterpret_cast<f32x2*>(&Vs[(g * SP + r) * LDV + c]) = vreg[i];
+        }
+        if constexpr (!FAST) {
+            for (int e = tid; e < G * SP; e += 256) {
+                const int key = e % SP, pair = group * G + e / SP;
+                float f = key >= S ? 2.f : 0.f;
+                if (f == 0.f && p.mask && pair < p.n_pair && p.mask[(long)(pair / p.n_head) * S + key] == 0) f = 1.f;
+                Flag[e] = f;
+            }
+        }
+    };
 
     const int g = wave / WPP;
-    const int pair = blockIdx.x * G + g;
-    if (pair >= p.n_pair) return;                  // no barrier below this point
-    const int seq = pair / p.n_head, head = pair - seq * p.n_head;
     const float* Kg = &Ks[g * SP * LDH];
     const float* Vg = &Vs[g * SP * LDV];
     const float* Fg = &Flag[g * SP];
-    float* scr = &Scr[wave * 32 * LDH];
-    const int krow = (0) + 4 * fh;                 // key row of accumulator register r: (r & 3) + 8 * (r >> 2) + 4 * fh
+    float* scr = &Scr[wave * 32 * LDO];
+    const float qscale = p.scale * LOG2E;          // scores in the log2 domain: p = exp2(s' - max')
+    const float masked = -1e9f * LOG2E;
 
-    for (int qt = wave % WPP; qt < NT; qt += WPP) {
-        if (qt * 32 >= S) break;
-        // ---- Q tile -> scratch (scaled), then into B fragments ---------------------------------------
-        const int qrows = (S - qt * 32) < 32 ? (S - qt * 32) : 32;
-        stage_rows(scr, LDH, p.q + ((long)seq * S + qt * 32) * p.ld + head * hd, p.ld, qrows, 32, hd, p.scale, p.vec2, lane, 64);
-        lds_fence();
-        f32x4 qf[4];
+    // Q fragments straight from global memory: lane (query fi, half fh) needs Q[q][8kk + 4fh .. +3]
+    f32x2 qraw[8], qnext[8];
+    auto q_rows = [&](int grp, int qt, f32x2* dst) {
+        const int pr = grp * G + g;
+        if (pr >= p.n_pair || qt * 32 >= S) return;
+        const int sq = pr / p.n_head, hh = pr - sq * p.n_head;
+        const float* qsrc = p.q + ((long)sq * S + qt * 32) * p.ld + hh * hd;
+        const int qrows = S - qt * 32;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const f32x4*>(&scr[fi * LDH + kk * 8 + fh * 4]);
-        lds_fence();
+        for (int kk = 0; kk < 4; ++kk) {
+            dst[2 * kk] = load2<FAST>(qsrc, p.ld, fi, kk * 8 + fh * 4, qrows, hd, vec2);
+            dst[2 * kk + 1] = load2<FAST>(qsrc, p.ld, fi, kk * 8 + fh * 4 + 2, qrows, hd, vec2);
+        }
+    };
+    auto load_q = [&](int grp, int qt) { q_rows(grp, qt, qraw); };
+    auto prefetch_q = [&](int grp) { q_rows(grp, wave % WPP, qnext); };
 
-        // ---- S^T = K Q^T: keys on rows, this lane's query on the column ---------------------------------
-        f32x16 sc[NT];
+    int group = blockIdx.x;
+    if (PREFETCH) { fetch(group); prefetch_q(group); }
+    for (; group < p.n_group; group += gridDim.x) {
+        if (!PREFETCH) fetch(group);
+        stash(group);
+        lds_barrier();
+        const int pair = group * G + g;
+        const bool live = pair < p.n_pair;
+        const int seq = live ? pair / p.n_head : 0, head = live ? pair - seq * p.n_head : 0;
+        const int qt0 = wave % WPP;
+        if (!PREFETCH) { if (live && qt0 * 32 < S) load_q(group, qt0); }
+        else {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float init = (t * 32 < S) ? 0.f : -INFINITY;      // a tile entirely beyond S is padding
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[t][r] = init;
-            if (t * 32 < S) {
+            for (int i = 0; i < 8; ++i) qraw[i] = qnext[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (PREFETCH && group + (int)gridDim.x < p.n_group) {          // next group's K / V / Q: in flight under the MFMAs
+            fetch(group + gridDim.x);
+            prefetch_q(group + gridDim.x);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (live) {
+            for (int qt = qt0; qt < NT; qt += WPP) {
+                if (qt * 32 >= S) break;
+                if (qt != qt0) load_q(group, qt);
+                f32x4 qf[4];
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const f32x4 kf = *reinterpret_cast<const f32x4*>(&Kg[(t * 32 + fi) * LDH + kk * 8 + fh * 4]);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[u], qf[kk][u], sc[t], 0, 0, 0);
+                    qf[kk][0] = qraw[2 * kk][0] * qscale; qf[kk][1] = qraw[2 * kk][1] * qscale;
+                    qf[kk][2] = qraw[2 * kk + 1][0] * qscale; qf[kk][3] = qraw[2 * kk + 1][1] * qscale;
                 }
-            }
-        }
-        // ---- key padding / key mask (the key of register r is the same for a whole half-wave) ----------
-        if (need_flags) {
+                // ---- S^T = K Q^T: keys on rows, this lane's query on the column (rows beyond S are zeros in LDS) ------
+                f32x16 sc[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+                for (int t = 0; t < NT; ++t) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float f = Fg[t * 32 + (r & 3) + 8 * (r >> 2) + krow];
-                    if (f == 2.f) sc[t][r] = -INFINITY;
-                    else if (f == 1.f) sc[t][r] = -1e9f;      // masked_fill(mask == 0, -1e9), layers.py:233
+                    for (int r = 0; r < 16; ++r) sc[t][r] = 0.f;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const f32x4 kf = *reinterpret_cast<const f32x4*>(&Kg[(t * 32 + fi) * LDH + kk * 8 + fh * 4]);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[u], qf[kk][u], sc[t], 0, 0, 0);
+                    }
                 }
-            }
-        }
-        // ---- softmax over the keys of this lane's query: own registers, then the other half-wave ---------
-        float m = sc[0][0];
+                // ---- key padding / key mask: a select per register (its key is the same for a whole half-wave) -----
+                if constexpr (!FAST) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+                    for (int t = 0; t < NT; ++t) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) m = fmaxf(m, sc[t][r]);
-        m = fmaxf(m, __shfl_xor(m, 32));
-        float sum = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = expf(sc[t][r] - m);
-                sc[t][r] = e;
-                sum += e;
-            }
-        }
-        sum += __shfl_xor(sum, 32);
-        const float inv = 1.0f / sum;
-        // ---- O^T = V^T P^T: probability registers are the B operand as they stand ----------------------
-        f32x16 o;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t * 32 < S) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float vv = Vg[(t * 32 + (r & 3) + 8 * (r >> 2) + krow) * LDV + fi];
-                    o = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, sc[t][r], o, 0, 0, 0);
+                        for (int r = 0; r < 16; ++r) {
+                            const float f = Fg[t * 32 + (r & 3) + 8 * (r >> 2) + krow];
+                            const float v = sc[t][r];
+                            sc[t][r] = (f == 2.f) ? -INFINITY : ((f == 1.f) ? masked : v);   // masked_fill(mask == 0, -1e9), layers.py:233
+                        }
+                    }
                 }
+                // ---- softmax over the keys of this lane's query: own registers, then the other half-wave -----------
+                float m = sc[0][0];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m = fmaxf(m, sc[t][r]);
+                m = fmaxf(m, __shfl_xor(m, 32));
+                float sum = 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(sc[t][r] - m);      // v_exp_f32: 1 ulp
+                        sc[t][r] = e;
+                        sum += e;
+                    }
+                }
+                sum += __shfl_xor(sum, 32);
+                const float inv = 1.0f / sum;
+                // ---- O^T = V^T P^T: probability registers are the B operand as they stand --------------------------
+                f32x16 o;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float vv = Vg[(t * 32 + (r & 3) + 8 * (r >> 2) + krow) * LDV + fi];      // rows beyond S are zeros
+                        o = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, sc[t][r], o, 0, 0, 0);
+                    }
+                }
+                // ---- transpose [head dim][query] -> [query][head dim] through the scratch, store whole head rows ----
+#pragma unroll
+                for (int r = 0; r < 16; ++r) scr[fi * LDO + (r & 3) + 8 * (r >> 2) + krow] = o[r] * inv;
+                lds_fence();
+                if (fi < hd) {
+#pragma unroll
+                    for (int it = 0; it < 16; ++it) {
+                        const int row = it * 2 + fh;
+                        const int qi = qt * 32 + row;
+                        if (qi < S) p.out[((long)seq * S + qi) * p.ldo + head * hd + fi] = scr[row * LDO + fi];
+                    }
+                }
+                lds_fence();
             }
         }
-        // ---- transpose [head dim][query] -> [query][head dim] through the scratch, store whole head rows ----
-#pragma unroll
-        for (int r = 0; r < 16; ++r) scr[fi * LDO + (r & 3) + 8 * (r >> 2) + krow] = o[r] * inv;
-        lds_fence();
-        if (fi < hd) {
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int row = it * 2 + fh;
-                const int qi = qt * 32 + row;
-                if (qi < S) p.out[((long)seq * S + qi) * p.ldo + head * hd + fi] = scr[row * LDO + fi];
-            }
-        }
-        lds_fence();
+        lds_barrier();                           // everyone is done with this group's LDS images
     }
 }
 
+int attn_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
 template <int NT>
-int launch(const AttnP& p, hipStream_t s) {
+int launch(AttnP p, hipStream_t s) {
     constexpr int G = (NT >= 3) ? 1 : (4 / NT);
-    const unsigned blocks = (unsigned)((p.n_pair + G - 1) / G);
-    hipLaunchKernelGGL((token_attn_kernel<NT>), dim3(blocks), dim3(256), 0, s, p);
+    p.n_group = (p.n_pair + G - 1) / G;
+    // LDS per workgroup decides how many are resident per CU; a few persistent workgroups per CU
+    const int per_cu = NT <= 2 ? 3 : (NT <= 4 ? 2 : 1);
+    long blocks = (long)attn_num_cus() * per_cu;
+    if (blocks > p.n_group) blocks = p.n_group;
+    const bool fast = p.mask == nullptr && p.S == NT * 32 && p.vec2;
+    if (fast) hipLaunchKernelGGL((token_attn_kernel<NT, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((token_attn_kernel<NT, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     return lime_check_launch("lime_token_attention_f32");
 }
 
@@ -216,7 +296,7 @@ extern "C" int lime_token_attention_f32(const float* q, const float* k, const fl
     if (n_seq == 0) return LIME_OK;
     // 8-byte loads need an even head_dim and leading dimension and 8-byte aligned bases
     const int vec2 = (head_dim % 2 == 0) && (ld_qkv % 2 == 0) && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 8 == 0);
-    AttnP p{q, k, v, (long)ld_qkv, key_mask, out, (long)ldo, n_seq, S, n_head, head_dim, scale, n_seq * n_head, vec2};
+    AttnP p{q, k, v, (long)ld_qkv, key_mask, out, (long)ldo, n_seq, S, n_head, head_dim, scale, n_seq * n_head, vec2, 0};
     hipStream_t s = (hipStream_t)stream;
     const int nt = (S + 31) / 32;
     if (nt <= 1) return launch<1>(p, s);
