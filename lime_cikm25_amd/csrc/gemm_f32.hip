@@ -26,6 +26,25 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifdef LIME_STAMPS
+// Diagnostic build only (tools/gemm_stamps.py): per-wave s_memtime sums of the main-loop segments.  The stamp values go to
+// a buffer nothing else reads; no output depends on them.  Never compiled into liblime_hip.so.
+static unsigned long long* g_stamp_buf = nullptr;
+extern "C" void lime_debug_set_stamp_buffer(unsigned long long* p) { g_stamp_buf = p; }
+#define LIME_NSEG 8
+#define STAMP(i)                                                            \
+    {                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();         \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                 \
+        tsum[i] += t_ - tlast;                                              \
+        tlast = t_;                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+    }
+#else
+#define STAMP(i)
+#endif
+
 namespace {
 
 constexpr int BK = 32;    // K depth of one staged chunk
@@ -38,6 +57,9 @@ struct GemmP {
     const float* ln_g; const float* ln_b; float ln_eps;
     float* c; long ldc; int M, N, K; int act;
     int n_row_blocks, n_col_blocks;
+#ifdef LIME_STAMPS
+    unsigned long long* stamps;
+#endif
     int res_in_acc;      // residual is loaded into the accumulators at the tile boundary (plain add, no act, no gate)
 };
 
@@ -177,16 +199,24 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 
     };
 
     vec_t areg[APASS], wreg[WPASS], pereg[PE ? APASS : 1];
-    auto issue = [&](int k0) {
+    // Loads of one chunk; `part` < 0 issues all of them.  The main loop issues them in three parts in front of the first
+    // three k8 steps of the current chunk -- part 0: the activation rows (and positional rows), which come from HBM / the
+    // Infinity Cache and need the longest cover; parts 1, 2: the weight rows (L2 hits).  A wave that issues all 6..9 loads
+    // back to back sits 1.7..3 k cycles in VMEM issue (measured with s_memtime stamps: 17..24 % of its life) while the
+    // MFMA pipe drains; spread out, each stall hides under the 16..20 MFMAs just issued.
+    auto issue = [&](int k0, int part) {
         const bool kin = (k0 + sk) < p.K;           // only the tail chunk of a tile has lanes beyond K
         const int soff = k0 * 4;
+        if (part < 0 || part == 0) {
 #pragma unroll
-        for (int i = 0; i < APASS; ++i) {
-            areg[i] = buf_load<VEC>(rs_a, kin ? a_voff[i] : OOB, soff);
-            if constexpr (PE) pereg[i] = buf_load<VEC>(rs_pe, kin ? pe_voff[i] : OOB, soff);
+            for (int i = 0; i < APASS; ++i) {
+                areg[i] = buf_load<VEC>(rs_a, kin ? a_voff[i] : OOB, soff);
+                if constexpr (PE) pereg[i] = buf_load<VEC>(rs_pe, kin ? pe_voff[i] : OOB, soff);
+            }
         }
 #pragma unroll
-        for (int i = 0; i < WPASS; ++i) wreg[i] = buf_load<VEC>(rs_w, kin ? w_voff[i] : OOB, soff);
+        for (int i = 0; i < WPASS; ++i)
+            if (part < 0 || part == 1 + (i & 1)) wreg[i] = buf_load<VEC>(rs_w, kin ? w_voff[i] : OOB, soff);
     };
     auto commit = [&](int buf) {
 #pragma unroll
@@ -456,30 +486,42 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 
     prefetch_ids(first);
     loader_set_tile(first);
     prefetch_ids(first + nwg);
-    issue(0);
+    issue(0, -1);
     commit(0);
     lds_barrier();
     int buf = 0;
+#ifdef LIME_STAMPS
+    unsigned long long tsum[LIME_NSEG] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     for (int tile = first; tile < ntiles; tile += nwg) {
         const bool more = tile + nwg < ntiles;
         acc_init(tile);
+        STAMP(0)                                      // 0: accumulator init (residual loads issued)
         for (int t = 0; t + 1 < nchunk; ++t) {
-            issue((t + 1) * BK);
-            __builtin_amdgcn_sched_barrier(0);        // keep the prefetch ABOVE the MFMAs (hipcc otherwise sinks it to its use)
+            STAMP(1)
             const float* Ab = &As[buf][a_off];
             const float* Wb = &Ws[buf][w_off];
 #pragma unroll
-            for (int s = 0; s < BK / 8; ++s) k8_step(Ab, Wb, s);
-            __builtin_amdgcn_sched_barrier(0);        // ... and its waits + LDS writes BELOW them
+            for (int s = 0; s < BK / 8; ++s) {
+                if (s < 3) issue((t + 1) * BK, s);    // a third of the next chunk's loads in front of each of the first k8 steps
+                __builtin_amdgcn_sched_barrier(0);    // pinned: hipcc otherwise sinks every load down to its use
+                k8_step(Ab, Wb, s);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            STAMP(2)                                  // 2: prefetch issue + fragment reads + MFMA issue of a full chunk
             commit(buf ^ 1);
+            STAMP(3)                                  // 3: vmcnt wait + LDS writes
             lds_barrier();
+            STAMP(4)                                  // 4: barrier
             buf ^= 1;
         }
         // last chunk of the tile: the loader moves on to the next tile first
         if (more) {
             loader_set_tile(tile + nwg);
             prefetch_ids(tile + 2 * nwg);
-            issue(0);
+            issue(0, -1);
         }
         __builtin_amdgcn_sched_barrier(0);
         {
@@ -488,11 +530,20 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 
             for (int s = 0; s < tail_steps; ++s) k8_step(Ab, Wb, s);
         }
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(5)                                      // 5: loader switch + tail chunk
         epilogue(tile);
+        STAMP(6)                                      // 6: epilogue
         if (more) commit(buf ^ 1);
         lds_barrier();
+        STAMP(7)                                      // 7: first commit of the next tile + barrier
         buf ^= 1;
     }
+#ifdef LIME_STAMPS
+    if (p.stamps && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < LIME_NSEG; ++i) p.stamps[((long)blockIdx.x * (NT / 64) + wave) * LIME_NSEG + i] = tsum[i];
+    }
+#endif
 }
 
 int num_cus() {
@@ -515,6 +566,9 @@ int launch_one(const GemmP& p0, int wg_per_cu, hipStream_t stream) {
     const long ntiles = (long)p.n_row_blocks * p.n_col_blocks;
     long nwg = (long)num_cus() * wg_per_cu;
     if (nwg > ntiles) nwg = ntiles;
+#ifdef LIME_STAMPS
+    p.stamps = g_stamp_buf;
+#endif
     hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, WM, WN, VEC, LN, PE, ACT, GENERIC, VIO>), dim3((unsigned)nwg), dim3(WM * WN * 64), 0,
                        stream, p);
     return lime_check_launch("lime_linear_f32");

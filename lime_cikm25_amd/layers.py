@@ -42,24 +42,34 @@ class CandidateAware_ClickedNewsAttention(nn.Module):
         nn.init.xavier_uniform_(self.gate_proj.weight)
         nn.init.zeros_(self.gate_proj.bias)
 
-    def forward(self, clicked_news_embeddings, clicked_news_topic_embeddings, candidate_topic_embeddings, mask=None):
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError('training-mode dropout (p=0.2, layers.py:36,74) is not part of the scoring path yet')
-        B, H, D = clicked_news_embeddings.shape
+    def attention_weights(self, clicked_news_topic_embeddings, candidate_topic_embeddings, mask=None):
+        """agg [B, H] of layers.py:66-81: topic projections, per-head masked softmax, query-norm weighting, outer softmax."""
+        B, H, _ = clicked_news_topic_embeddings.shape
         N = candidate_topic_embeddings.shape[1]
-        hist = clicked_news_embeddings.reshape(B * H, D)
+        D = self.news_embedding_dim
         if mask is None:
-            mask = torch.ones(B, H, dtype=torch.bool, device=hist.device)
+            mask = torch.ones(B, H, dtype=torch.bool, device=clicked_news_topic_embeddings.device)
         qp = ops.linear(candidate_topic_embeddings.reshape(B * N, -1), self.query_proj.weight, self.query_proj.bias)
         kp = ops.linear(clicked_news_topic_embeddings.reshape(B * H, -1), self.key_proj.weight, self.key_proj.bias)
-        agg = ops.cand_attn_weights(qp, kp, mask, B, N, H, D, self.num_heads)
+        return ops.cand_attn_weights(qp, kp, mask, B, N, H, D, self.num_heads)
+
+    def refine(self, clicked_news_embeddings, agg):
+        """layers.py:83-91: weighted history, gated residual, LayerNorm."""
+        B, H, D = clicked_news_embeddings.shape
+        hist = clicked_news_embeddings.reshape(B * H, D)
         if self.use_residual_connection:
             y = ops.linear(hist, self.gate_proj.weight, None)                       # W_g x; the row scale commutes
             out = ops.gate_ln(y, hist, agg.view(-1), self.gate_proj.bias, self.layernorm.weight, self.layernorm.bias,
                               self.layernorm.eps)
         else:
             out = ops.row_scale(hist, agg.view(-1))
-        return out.view(B, H, D), agg
+        return out.view(B, H, D)
+
+    def forward(self, clicked_news_embeddings, clicked_news_topic_embeddings, candidate_topic_embeddings, mask=None):
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError('training-mode dropout (p=0.2, layers.py:36,74) is not part of the scoring path yet')
+        agg = self.attention_weights(clicked_news_topic_embeddings, candidate_topic_embeddings, mask)
+        return self.refine(clicked_news_embeddings, agg), agg
 
 
 class MultiHeadAttention(nn.Module):

@@ -8,6 +8,16 @@ from .util import RemainingLifetimeWeighting
 # positions (in the 26-tensor signature, model.py:151-154) of the inputs the scoring path reads; the others
 # (user_ID, *_entity, content masks, user_history_graph / category_mask / category_indices) are ignored by the
 # reference too (last bullet)
+_SIDE2 = {}
+
+
+def _second_side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE2:
+        _SIDE2[key] = torch.cuda.Stream(device=device)
+    return _SIDE2[key]
+
+
 _USED = (1, 2, 3, 4, 6, 9, 10, 11, 15, 16, 17, 18, 20, 23, 24, 25)
 
 
@@ -115,13 +125,21 @@ class Model(nn.Module):
             news_user_topic_lifetime = news_user_topic_lifetime.unsqueeze(1)
             remaining_lifetime = remaining_lifetime.unsqueeze(1)
         with torch.no_grad():
+            # candidate-aware attention weights depend on topic ids and the history mask only: side stream, joined below
+            main = torch.cuda.current_stream()
+            side2 = _second_side_stream(user_category.device)
+            side2.wait_stream(main)
+            with torch.cuda.stream(side2):
+                agg = self.user_encoder.attention_weights(news_category, news_subCategory, user_category, user_subCategory,
+                                                          user_history_mask)
             news_representation, history_embedding = self.news_encoder.encode_many([
                 (news_title_text, news_title_mask, news_content_text, news_category, news_subCategory, news_freshness,
                  news_user_topic_lifetime),                                      # model.py:171-173
                 (user_title_text, user_title_mask, user_content_text, user_category, user_subCategory, user_freshness,
                  user_user_topic_lifetime)])                                     # userEncoders.py:110-112
+            main.wait_stream(side2)
             _, logits = self.user_encoder.match(history_embedding, news_category, news_subCategory, user_category,
                                                 user_subCategory, user_history_mask, news_representation,
                                                 remaining_lifetime=remaining_lifetime.float(),
-                                                weighting=self.remaining_lifetime_weighting)   # model.py:174-181
+                                                weighting=self.remaining_lifetime_weighting, agg=agg)   # model.py:174-181
         return logits

@@ -31,6 +31,18 @@ def _no_train_dropout(module, p):
                                   '(eval-mode children, or dropout_rate = 0); see SURVEY.md section 8f row 2')
 
 
+_SIDE = {}
+
+
+def _side_stream(device):
+    """One side stream per device for branches that are independent of the token encoders (fork / join with
+    wait_stream, which is also how the fork is recorded into the HIP graph)."""
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 def _i32(t):
     return t if t.dtype == torch.int32 else t.to(torch.int32)
 
@@ -121,8 +133,15 @@ class LIME(nn.Module):
         M = title_text.shape[0]
         cdim = self.base_news_encoder.news_embedding_dim
         fused = torch.empty((M, 2 * cdim), dtype=torch.float32, device=title_text.device)
+        # the freshness branch (buckets, two 10-row tables, one small GEMM) does not depend on the content encoder and
+        # writes the other half of the fused rows: it runs on a side stream under the token encoders
+        main = torch.cuda.current_stream()
+        side = _side_stream(title_text.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.freshness_encoder.encode_flat(freshness, lifetime, fused[:, cdim:])
         self.base_news_encoder.encode_flat(title_text, title_mask, content_text, category, subCategory, fused[:, :cdim])
-        self.freshness_encoder.encode_flat(freshness, lifetime, fused[:, cdim:])
+        main.wait_stream(side)
         if isinstance(self.project, nn.Identity):
             return fused
         return ops.linear(fused, self.project.weight, self.project.bias)             # newsEncoders.py:152-153

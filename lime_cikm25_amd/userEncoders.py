@@ -106,12 +106,25 @@ class CROWN(UserEncoder):
                             ne.category_affine.weight, ne.category_affine.bias)
         return rep.view(*shape, -1)
 
+    def attention_weights(self, category, subCategory, user_category, user_subCategory, user_history_mask):
+        """The candidate-aware attention weights agg [B, H] (layers.py:66-81).  They depend on the topic ids and the
+        history mask only -- not on any news embedding -- so the model computes them on a side stream while the token
+        encoders run."""
+        if not self.use_candidate_aware_attn:
+            return None
+        if self.training and self.candidate_aware_attn.dropout.p > 0:
+            raise NotImplementedError('training-mode dropout (p=0.2, layers.py:36,74) is not part of the scoring path yet')
+        cand_topic = self._topic(category, subCategory)
+        hist_topic = self._topic(user_category, user_subCategory)
+        return self.candidate_aware_attn.attention_weights(hist_topic, cand_topic, user_history_mask)
+
     def match(self, history_embedding, category, subCategory, user_category, user_subCategory, user_history_mask,
-              candidate_news_representation, remaining_lifetime=None, weighting=None):
+              candidate_news_representation, remaining_lifetime=None, weighting=None, agg=None):
         """Everything after the history has been encoded (userEncoders.py:103-105, :114-169).
 
         Returns (user_representation [B, N, D], logits [B, N] or None).  With ``weighting`` (the model's
         RemainingLifetimeWeighting) the dot-product match and the lifetime weight are fused into the last kernel.
+        ``agg``: precomputed ``attention_weights(...)``.
         """
         if self.training and self.dropout_rate > 0:
             raise NotImplementedError('training-mode dropout on user_node_embedding (userEncoders.py:121) is not implemented')
@@ -119,9 +132,9 @@ class CROWN(UserEncoder):
         N = candidate_news_representation.shape[1]
         cand = candidate_news_representation.contiguous()
         if self.use_candidate_aware_attn:
-            cand_topic = self._topic(category, subCategory)
-            hist_topic = self._topic(user_category, user_subCategory)
-            history_embedding, _ = self.candidate_aware_attn(history_embedding, hist_topic, cand_topic, mask=user_history_mask)
+            if agg is None:
+                agg = self.attention_weights(category, subCategory, user_category, user_subCategory, user_history_mask)
+            history_embedding = self.candidate_aware_attn.refine(history_embedding, agg)
         g = self.graph_sage.forward_closed_form(history_embedding, self.user_node_embedding, n_src=B)       # :121,:151-157
         kp = ops.linear(g.view(B * H, D), self.K.weight, None)                                               # :161
         qp = ops.linear(cand.view(B * N, D), self.Q.weight, self.Q.bias)                                     # :162
