@@ -172,7 +172,7 @@ int lime_sage_mean_f32(const float* hist, const float* user_nodes, float* out, i
                        int32_t n_src, int32_t D, void* stream);
 
 /*
- * lime_interest_match_f32: userEncoders.py:163-169 + util.py:23-49 fused, one workgroup per row b:
+ * lime_interest_match_f32: userEncoders.py:163-169 + util.py:23-49 fused, one workgroup per (row b, candidate n):
  *   a[n, h] = kp[b, h, :] . qp[b, n, :] * scale;  alpha = softmax_h (unmasked);  u[b, n, :] = sum_h alpha g[b, h, :]
  *   base = u . cand[b, n, :];  w = sigmoid(alpha_s * r) (x beta_s where r < 0 when use_penalty; |r| when not)
  *   logits[b, n] = use_weight ? base * w : base;   user_rep receives u.  Either of user_rep / logits may be NULL.

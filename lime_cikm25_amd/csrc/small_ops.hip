@@ -217,9 +217,9 @@ __global__ __launch_bounds__(256) void additive_pool_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------
-// candidate-aware attention weights: one workgroup per impression row
+// candidate-aware attention weights: one workgroup per impression row (heads one after the other: large N / H)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cand_attn_weights_kernel(const float* __restrict__ qp, const float* __restrict__ kp,
+__global__ __launch_bounds__(256) void cand_attn_weights_serial_kernel(const float* __restrict__ qp, const float* __restrict__ kp,
                                                                  const unsigned char* __restrict__ mask, float* __restrict__ agg,
                                                                  int N, int H, int D, int n_head) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -319,6 +319,127 @@ __global__ __launch_bounds__(256) void cand_attn_weights_kernel(const float* __r
     for (int h = threadIdx.x; h < H; h += 256) agg[(long)b * H + h] = v[h] * inv;
 }
 
+// Same result, heads spread over the four waves: wave w owns heads w, w + 4, ... with its own K / Q tiles and its own
+// partial sums, so the head loop needs no workgroup barrier (the serial kernel spends most of its 80 us in them).
+// Per (head, candidate) the softmax terms are identical; the sum over heads is taken wave 0..3 in a fixed order.
+__device__ __forceinline__ void wave_lds_fence() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(256) void cand_attn_weights_kernel(const float* __restrict__ qp, const float* __restrict__ kp,
+                                                                 const unsigned char* __restrict__ mask, float* __restrict__ agg,
+                                                                 int N, int H, int D, int n_head) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int hd = D / n_head;
+    const int hdp = hd + 1;                        // odd pitch: conflict-free column walks
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int per_wave = (N + H) * hdp + N * H + N;
+    float* Qh = sm + wave * per_wave;              // [N][hdp]   this wave's query tile
+    float* Kh = Qh + N * hdp;                      // [H][hdp]   this wave's key tile
+    float* asum = Kh + H * hdp;                    // [N][H]     this wave's sum over its heads of the softmaxed weights
+    float* qn2 = asum + N * H;                     // [N]        this wave's share of the squared query norm
+    float* red = sm + 4 * per_wave;                // [4]
+    const int b = blockIdx.x;
+    const float inv_scale = 1.0f / sqrtf((float)D);
+    for (int e = lane; e < N * H; e += 64) asum[e] = 0.f;
+    for (int e = lane; e < N; e += 64) qn2[e] = 0.f;
+    for (int head = wave; head < n_head; head += 4) {
+        wave_lds_fence();
+        for (int e = lane; e < N * hd; e += 64) {
+            const int n = e / hd, j = e - n * hd;
+            Qh[n * hdp + j] = qp[((long)b * N + n) * D + head * hd + j];
+        }
+        for (int e = lane; e < H * hd; e += 64) {
+            const int h = e / hd, j = e - h * hd;
+            Kh[h * hdp + j] = kp[((long)b * H + h) * D + head * hd + j];
+        }
+        wave_lds_fence();
+        for (int n = lane; n < N; n += 64) {
+            float q2 = 0.f;
+            for (int j = 0; j < hd; ++j) q2 += Qh[n * hdp + j] * Qh[n * hdp + j];
+            qn2[n] += q2;
+        }
+        for (int n = 0; n < N; ++n) {              // keys across the 64 lanes; row max / sum by wave shuffles
+            float sc[8];                           // H <= 512 -> at most 8 keys per lane
+            float mx = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int h = c * 64 + lane;
+                float v = -INFINITY;
+                if (h < H) {
+                    float dot = 0.f;
+                    for (int j = 0; j < hd; ++j) dot += Qh[n * hdp + j] * Kh[h * hdp + j];
+                    v = dot * inv_scale;
+                    if (mask[(long)b * H + h] == 0) v = -1e9f;       // layers.py:72
+                }
+                sc[c] = v;
+                mx = fmaxf(mx, v);
+            }
+            mx = wave_max(mx);
+            float den = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                sc[c] = (c * 64 + lane < H) ? expf(sc[c] - mx) : 0.f;
+                den += sc[c];
+            }
+            const float inv = 1.0f / wave_sum(den);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int h = c * 64 + lane;
+                if (h < H) asum[n * H + h] += sc[c] * inv;
+            }
+        }
+    }
+    __syncthreads();
+    // fold the four waves' partials into wave 0's arrays (fixed order)
+    float* asum0 = sm + (N + H) * hdp;
+    float* qn20 = asum0 + N * H;
+    for (int e = threadIdx.x; e < N * H; e += 256) {
+        float t = asum0[e];
+        for (int w = 1; w < 4; ++w) t += sm[w * per_wave + (N + H) * hdp + e];
+        asum0[e] = t;
+    }
+    for (int e = threadIdx.x; e < N; e += 256) {
+        float t = qn20[e];
+        for (int w = 1; w < 4; ++w) t += sm[w * per_wave + (N + H) * hdp + N * H + e];
+        qn20[e] = t;
+    }
+    __syncthreads();
+    // query weights: softmax over the candidates of ||Q_n||_2 (layers.py:79)
+    float* qw = sm;                                // reuse wave 0's Q tile
+    {
+        float mx = -INFINITY;
+        for (int n = 0; n < N; ++n) mx = fmaxf(mx, sqrtf(qn20[n]));
+        float den = 0.f;
+        for (int n = 0; n < N; ++n) den += expf(sqrtf(qn20[n]) - mx);
+        __syncthreads();
+        for (int n = threadIdx.x; n < N; n += 256) qw[n] = expf(sqrtf(qn20[n]) - mx) / den;
+    }
+    __syncthreads();
+    // agg = softmax_H(sum_n qw_n * asum[n][h])  (layers.py:80-81)
+    float* v = sm + N * hdp;                       // reuse wave 0's K tile, H floats
+    float mx = -INFINITY;
+    for (int h = threadIdx.x; h < H; h += 256) {
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) acc += asum0[n * H + h] * qw[n];
+        v[h] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float part = 0.f;
+    for (int h = threadIdx.x; h < H; h += 256) {
+        const float e = expf(v[h] - mx);
+        v[h] = e;
+        part += e;
+    }
+    const float inv = 1.0f / block_sum(part, red);
+    for (int h = threadIdx.x; h < H; h += 256) agg[(long)b * H + h] = v[h] * inv;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // GraphSAGE mean over the first n_src node slots of cat[hist[b], user_nodes]
 // ---------------------------------------------------------------------------------------------------
@@ -335,73 +456,70 @@ __global__ __launch_bounds__(256) void sage_mean_kernel(const float* __restrict_
 
 // ---------------------------------------------------------------------------------------------------
 // history-vs-candidate attention + dot-product interest match + remaining-lifetime weight:
-// one workgroup per impression row
+// one workgroup per (impression row, candidate)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void interest_match_kernel(const float* __restrict__ kp, const float* __restrict__ qp,
                                                               const float* __restrict__ g, const float* __restrict__ cand,
                                                               const float* __restrict__ remaining, float* __restrict__ user_rep,
                                                               float* __restrict__ logits, int N, int H, int A, int D, float scale,
                                                               float alpha_s, float beta_s, int use_weight, int use_penalty) {
+    // one workgroup per (impression row, candidate): B * N workgroups instead of B keep the chip busy
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Qs = sm;                     // [N][A]  candidate queries of this row
-    float* al = Qs + N * A;             // [N][H]  attention logits, then weights
-    float* red = al + N * H;            // [4]
-    const long b = blockIdx.x;
+    float* Qs = sm;                     // [A]  this candidate's query
+    float* al = Qs + A;                 // [H]  attention logits, then weights
+    float* red = al + H;                // [4]
+    const long bn = blockIdx.x;
+    const long b = bn / N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int e = threadIdx.x; e < N * A; e += 256) Qs[e] = qp[b * N * A + e];
+    for (int e = threadIdx.x; e < A; e += 256) Qs[e] = qp[bn * A + e];
     __syncthreads();
-    // a[n][h] = kp[b,h,:] . qp[b,n,:] * scale: a wave streams one key row (coalesced), lanes over A
+    // a[h] = kp[b,h,:] . q * scale: a wave streams one key row (coalesced), lanes over A, shuffle reduction
     for (int h = wave; h < H; h += 4) {
         const float* krow = kp + (b * H + h) * A;
-        for (int n = 0; n < N; ++n) {
-            float part = 0.f;
-            for (int j = lane; j < A; j += 64) part += krow[j] * Qs[n * A + j];
-            part = wave_sum(part);
-            if (lane == 0) al[n * H + h] = part * scale;
-        }
-    }
-    __syncthreads();
-    // softmax over the history (unmasked, userEncoders.py:164): one wave per candidate
-    for (int n = wave; n < N; n += 4) {
-        float mx = -INFINITY;
-        for (int h = lane; h < H; h += 64) mx = fmaxf(mx, al[n * H + h]);
-        mx = wave_max(mx);
-        float den = 0.f;
-        for (int h = lane; h < H; h += 64) {
-            const float e = expf(al[n * H + h] - mx);
-            al[n * H + h] = e;
-            den += e;
-        }
-        const float inv = 1.0f / wave_sum(den);
-        for (int h = lane; h < H; h += 64) al[n * H + h] *= inv;
-    }
-    __syncthreads();
-    // u[n] = sum_h alpha[n][h] g[b,h,:];  base[n] = u[n] . cand[b,n,:]
-    for (int n = 0; n < N; ++n) {
         float part = 0.f;
-        for (int d = threadIdx.x; d < D; d += 256) {
-            float u = 0.f;
-            for (int h = 0; h < H; ++h) u += al[n * H + h] * g[(b * H + h) * D + d];
-            if (user_rep) user_rep[(b * N + n) * D + d] = u;
-            part += u * cand[(b * N + n) * D + d];
-        }
-        const float base = block_sum(part, red);
-        if (threadIdx.x == 0 && logits) {
-            float out = base;
-            if (use_weight) {
-                const float r = remaining[b * N + n];
-                float w;
-                if (use_penalty) {
-                    // util.py:40-43: positive_mask * w + negative_mask * beta * w
-                    w = lime_sigmoid(alpha_s * r);
-                    w = (r >= 0.f ? 1.f : 0.f) * w + (r < 0.f ? 1.f : 0.f) * beta_s * w;
-                } else {
-                    w = lime_sigmoid(alpha_s * fabsf(r));
-                }
-                out = base * w;
+        for (int j = lane; j < A; j += 64) part += krow[j] * Qs[j];
+        part = wave_sum(part);
+        if (lane == 0) al[h] = part * scale;
+    }
+    __syncthreads();
+    // softmax over the history (unmasked, userEncoders.py:164)
+    float mx = -INFINITY;
+    for (int h = threadIdx.x; h < H; h += 256) mx = fmaxf(mx, al[h]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float den = 0.f;
+    for (int h = threadIdx.x; h < H; h += 256) {
+        const float e = expf(al[h] - mx);
+        al[h] = e;
+        den += e;
+    }
+    const float inv = 1.0f / block_sum(den, red);
+    // u = sum_h alpha[h] g[b,h,:];  base = u . cand[b,n,:]
+    float part = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float u = 0.f;
+        for (int h = 0; h < H; ++h) u += (al[h] * inv) * g[(b * H + h) * D + d];
+        if (user_rep) user_rep[bn * D + d] = u;
+        part += u * cand[bn * D + d];
+    }
+    const float base = block_sum(part, red);
+    if (threadIdx.x == 0 && logits) {
+        float out = base;
+        if (use_weight) {
+            const float r = remaining[bn];
+            float w;
+            if (use_penalty) {
+                // util.py:40-43: positive_mask * w + negative_mask * beta * w
+                w = lime_sigmoid(alpha_s * r);
+                w = (r >= 0.f ? 1.f : 0.f) * w + (r < 0.f ? 1.f : 0.f) * beta_s * w;
+            } else {
+                w = lime_sigmoid(alpha_s * fabsf(r));
             }
-            logits[b * N + n] = out;
+            out = base * w;
         }
+        logits[bn] = out;
     }
 }
 
@@ -569,12 +687,19 @@ extern "C" int lime_cand_attn_weights_f32(const float* qp, const float* kp, cons
     LIME_REQUIRE(N <= 128 && H <= 512, LIME_ERR_UNSUPPORTED, "lime_cand_attn_weights_f32: N <= 128 and H <= 512 only");
     if (B == 0) return LIME_OK;
     const int hdp = D / n_head + 1;
-    const size_t lds = (size_t)((N + H) * hdp + N * H + N + 4) * sizeof(float);
+    const size_t per_wave = (size_t)((N + H) * hdp + N * H + N);
+    const size_t lds_par = (4 * per_wave + 4) * sizeof(float);
+    if (lds_par <= 64 * 1024) {                 // heads spread over the waves
+        hipLaunchKernelGGL(cand_attn_weights_kernel, dim3((unsigned)B), dim3(256), lds_par, (hipStream_t)stream, qp, kp, mask, agg, N,
+                           H, D, n_head);
+        return lime_check_launch("lime_cand_attn_weights_f32");
+    }
+    const size_t lds = (per_wave + 4) * sizeof(float);
     LIME_REQUIRE(lds <= 160 * 1024, LIME_ERR_UNSUPPORTED, "lime_cand_attn_weights_f32: %zu B of LDS needed", lds);
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)cand_attn_weights_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(cand_attn_weights_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, qp, kp, mask, agg, N, H, D,
-                       n_head);
+        (void)hipFuncSetAttribute((const void*)cand_attn_weights_serial_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(cand_attn_weights_serial_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, qp, kp, mask, agg, N, H,
+                       D, n_head);
     return lime_check_launch("lime_cand_attn_weights_f32");
 }
 
@@ -598,11 +723,9 @@ extern "C" int lime_interest_match_f32(const float* kp, const float* qp, const f
     LIME_REQUIRE(!(use_weight && logits) || remaining, LIME_ERR_BAD_ARG, "lime_interest_match_f32: remaining is NULL");
     LIME_REQUIRE(B >= 0 && N > 0 && H > 0 && A > 0 && D > 0, LIME_ERR_BAD_ARG, "lime_interest_match_f32: bad dims");
     if (B == 0) return LIME_OK;
-    const size_t lds = (size_t)(N * A + N * H + 4) * sizeof(float);
-    LIME_REQUIRE(lds <= 160 * 1024, LIME_ERR_UNSUPPORTED, "lime_interest_match_f32: %zu B of LDS needed (N=%d)", lds, N);
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)interest_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(interest_match_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, kp, qp, g, cand, remaining,
+    const size_t lds = (size_t)(A + H + 4) * sizeof(float);
+    LIME_REQUIRE(lds <= 64 * 1024, LIME_ERR_UNSUPPORTED, "lime_interest_match_f32: %zu B of LDS needed", lds);
+    hipLaunchKernelGGL(interest_match_kernel, dim3((unsigned)(B * N)), dim3(256), lds, (hipStream_t)stream, kp, qp, g, cand, remaining,
                        user_rep, logits, N, H, A, D, scale, alpha_s, beta_s, use_weight, use_penalty);
     return lime_check_launch("lime_interest_match_f32");
 }
