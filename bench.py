@@ -77,12 +77,14 @@ def main():
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
         args.gpus = world
     assert torch.cuda.is_available(), 'bench.py needs the MI355X (the product path has no CPU fallback)'
+    local_rank %= max(1, torch.cuda.device_count())      # (a 2-rank rehearsal on a 1-GPU box shares the device)
     torch.cuda.set_device(local_rank)
     from lime_cikm25_amd import distributed as D
     dist = None
     if world > 1:
         import torch.distributed as dist
-        D.init(backend='nccl', device_id=torch.device('cuda', local_rank))      # "nccl" is RCCL on ROCm
+        backend = os.environ.get('LIME_BENCH_BACKEND', 'nccl')                  # "nccl" is RCCL on ROCm; gloo only to rehearse
+        D.init(backend=backend, device_id=torch.device('cuda', local_rank) if backend == 'nccl' else None)
 
     from lime_cikm25_amd import Model, make_config, ops, synth
     overrides, B, N, desc = WORKLOADS[args.workload]

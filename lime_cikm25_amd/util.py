@@ -1,7 +1,11 @@
-"""Drop-in for the scoring-path part of the reference's util.py (RemainingLifetimeWeighting, util.py:15-52)."""
+"""Drop-in for the scoring-path part of the reference's util.py: RemainingLifetimeWeighting (util.py:15-52) and the
+eval harness around the model, compute_scores (util.py:77-129)."""
+import numpy as np
+import torch
 import torch.nn as nn
 
 from . import ops
+from .evaluate import scoring
 
 
 class RemainingLifetimeWeighting(nn.Module):
@@ -20,3 +24,59 @@ class RemainingLifetimeWeighting(nn.Module):
 
     def initialize(self):
         pass
+
+
+def rank_impressions(scores, indices):
+    """util.py:113-123: per impression, the 1-based rank of every candidate under a stable descending sort (ties keep
+    the candidate order; +0.0 and -0.0 tie).  ``scores``: one per row; ``indices``: the impression of each row
+    (non-decreasing, 0-based; impressions without rows get an empty list).  Returns a list of rank lists."""
+    scores = np.asarray(scores, dtype=np.float64)
+    indices = np.asarray(indices, dtype=np.int64)
+    n_imp = int(indices[-1]) + 1 if indices.size else 0
+    pos = np.arange(scores.size)
+    order = np.lexsort((pos, -scores, indices))             # by impression, then score descending, then candidate order
+    starts = np.searchsorted(indices, np.arange(n_imp), side='left')
+    counts = np.bincount(indices, minlength=n_imp)
+    rank = np.empty(scores.size, dtype=np.int64)
+    rank[order] = pos - np.repeat(starts, counts) + 1       # position inside the impression's sorted block
+    return [rank[starts[i]:starts[i] + counts[i]].tolist() for i in range(n_imp)]
+
+
+def write_rank_file(result_file, ranks):
+    """util.py:117-123: ``<impression> [r1,r2,...]`` lines, 1-based impression ids, no spaces, no trailing newline."""
+    with open(result_file, 'w', encoding='utf-8') as f:
+        for i, r in enumerate(ranks):
+            f.write(('' if i == 0 else '\n') + str(i + 1) + ' ' + str(r).replace(' ', ''))
+
+
+def compute_scores(model, batches, indices, result_file, truth_file=None):
+    """The reference's dev / test pass (util.py:77-129) over an iterable of 25-tensor batches (what DevTest_Dataset
+    yields, dataset.py:216-227): score every (impression, candidate) row with the model in eval mode, write the rank
+    file, and -- given the truth file -- return (AUC, MRR, nDCG@5, nDCG@10), else four Nones.  The remaining lifetime is
+    derived per ``config.lifetime_type`` exactly as util.py:98-106."""
+    config = model.config
+    dev = getattr(model, 'device', None) or next(model.parameters()).device
+    scores = []
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        for batch in batches:
+            batch = [x.to(dev, non_blocking=True) for x in batch]
+            news_category, news_freshness, news_user_topic_lifetime = batch[15], batch[23], batch[24]
+            if config.lifetime_type == 'fixed':
+                remaining_lifetime = config.fixed_lifetime - news_freshness
+            elif config.lifetime_type == 'topic_wise':
+                remaining_lifetime = config.category_lifetime_map.to(news_category.device)[news_category.long()] - news_freshness
+            elif config.lifetime_type == 'user_topic':
+                remaining_lifetime = news_user_topic_lifetime - news_freshness
+            else:
+                raise ValueError('Invalid lifetime_type')
+            scores.append(model(*batch, remaining_lifetime).squeeze(dim=1).float().cpu())
+    model.train(was_training)
+    scores = torch.cat(scores).tolist() if scores else []
+    assert len(scores) == len(indices), 'one score per (impression, candidate) row'
+    write_rank_file(result_file, rank_impressions(scores, indices))
+    if truth_file is None:
+        return None, None, None, None
+    with open(truth_file, 'r', encoding='utf-8') as truth_f, open(result_file, 'r', encoding='utf-8') as result_f:
+        return scoring(truth_f, result_f)
