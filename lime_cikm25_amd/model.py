@@ -8,16 +8,6 @@ from .util import RemainingLifetimeWeighting
 # positions (in the 26-tensor signature, model.py:151-154) of the inputs the scoring path reads; the others
 # (user_ID, *_entity, content masks, user_history_graph / category_mask / category_indices) are ignored by the
 # reference too (last bullet)
-_SIDE2 = {}
-
-
-def _second_side_stream(device):
-    key = (device.type, device.index)
-    if key not in _SIDE2:
-        _SIDE2[key] = torch.cuda.Stream(device=device)
-    return _SIDE2[key]
-
-
 _USED = (1, 2, 3, 4, 6, 9, 10, 11, 15, 16, 17, 18, 20, 23, 24, 25)
 
 
@@ -127,7 +117,7 @@ class Model(nn.Module):
         with torch.no_grad():
             # candidate-aware attention weights depend on topic ids and the history mask only: side stream, joined below
             main = torch.cuda.current_stream()
-            side2 = _second_side_stream(user_category.device)
+            side2 = newsEncoders._side_stream(user_category.device, 2)
             side2.wait_stream(main)
             with torch.cuda.stream(side2):
                 agg = self.user_encoder.attention_weights(news_category, news_subCategory, user_category, user_subCategory,

@@ -34,10 +34,10 @@ def _no_train_dropout(module, p):
 _SIDE = {}
 
 
-def _side_stream(device):
-    """One side stream per device for branches that are independent of the token encoders (fork / join with
-    wait_stream, which is also how the fork is recorded into the HIP graph)."""
-    key = (device.type, device.index)
+def _side_stream(device, which=0):
+    """Side streams (per device) for branches that are independent of each other (fork / join with wait_stream,
+    which is also how the fork is recorded into the HIP graph)."""
+    key = (device.type, device.index, which)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]
@@ -360,13 +360,22 @@ class CROWN(NewsEncoder):
         ldx = (kin + 3) // 4 * 4                                   # 352: keeps the rows 16-byte aligned
         # rows [0, M): [title_pooled | category_rep], rows [M, 2M): [body_pooled | category_rep]   (:343-344)
         xin = torch.empty((2 * M, ldx), dtype=torch.float32, device=dev)
+        # The title and body encoders are independent chains of five GEMM / attention launches each.  They run on two
+        # streams: every launch is a persistent grid of one workgroup per CU, so the second chain's workgroups move in as
+        # the first chain's last, partially filled round of tiles drains (the title GEMMs have only 1.7 .. 5.2 tiles per
+        # CU: up to 14 % of a launch is such a tail).
+        main = torch.cuda.current_stream()
+        side = _side_stream(dev, 1)
+        side.wait_stream(main)
         for half, (ids, pos, tr, S) in enumerate(((title_text, self.title_pos_encoder, self.title_transformer, T),
                                                   (content_text, self.body_pos_encoder, self.body_transformer, L))):
             step = max(1, MAX_TOKENS_PER_PASS // S)
-            for m0 in range(0, M, step):
-                m1 = min(M, m0 + step)
-                y = encode_tokens(ids[m0:m1], table, pos.table(), tr, self.head_num)                 # :311-320
-                ops.mean_pool(y, m1 - m0, S, out=xin[half * M + m0:half * M + m1, :E])                # :317,:321
+            with torch.cuda.stream(side if half == 0 else main):
+                for m0 in range(0, M, step):
+                    m1 = min(M, m0 + step)
+                    y = encode_tokens(ids[m0:m1], table, pos.table(), tr, self.head_num)                 # :311-320
+                    ops.mean_pool(y, m1 - m0, S, out=xin[half * M + m0:half * M + m1, :E])                # :317,:321
+        main.wait_stream(side)
         # category representation (:340-342) and the raw category / subCategory rows of feature_fusion (:221-225)
         sub_table = self.subCategory_embedding.weight
         ops.topic_rep(category, subCategory, self.category_embedding.weight, sub_table, self.category_affine.weight,

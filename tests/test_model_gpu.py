@@ -208,11 +208,11 @@ def test_eval_harness_on_gpu(tmp_path):
     want = torch.cat(want).numpy()
     labels = [[1] + [0] * (n - 1) for n in sizes]
     truth = tmp_path / 'truth.txt'
-    truth.write_text('\\n'.join('%d %s' % (i + 1, str(l).replace(' ', '')) for i, l in enumerate(labels)))
+    truth.write_text('\n'.join('%d %s' % (i + 1, str(l).replace(' ', '')) for i, l in enumerate(labels)))
     got = U.compute_scores(model, batches, indices, str(tmp_path / 'hip.txt'), str(truth))
     U.write_rank_file(str(tmp_path / 'cpu.txt'), U.rank_impressions(want, indices))
     from lime_cikm25_amd.evaluate import scoring
     with open(truth) as tf, open(tmp_path / 'cpu.txt') as rf:
         ref = scoring(tf, rf)
     assert np.allclose(got, ref, atol=1e-3)
-    assert (tmp_path / 'hip.txt').read_text().count('\\n') == 11
+    assert (tmp_path / 'hip.txt').read_text().count('\n') == 11
