@@ -94,13 +94,24 @@ int lime_embed_pe_f32(const int32_t* ids, const float* table, int64_t ld_table, 
  * lime_token_attention_f32: softmax(Q K^T * scale [+ key mask]) V per (sequence, head), exact-fp32 MFMA.
  * Replaces the attention core of nn.MultiheadAttention inside the TransformerEncoderLayers
  * (newsEncoders.py:316,320; unmasked) and layers.MultiHeadAttention.forward (layers.py:227-237; key mask
- * filled with -1e9).  q/k/v: row (seq * S + t), column (head * head_dim + d), leading dimension ld_qkv
- * (the three may alias one packed [tokens, 3*E] buffer).  key_mask: uint8 [n_seq, S], 0 = masked, or NULL.
- * out[(seq * S + t) * ldo + head * head_dim + d].   Requires S <= 512, head_dim <= 32.
+ * filled with -1e9).  q/k/v: row (seq * S + t), column (head * head_stride + d), d < head_dim, leading dimension
+ * ld_qkv (the three may alias one packed buffer).  head_stride == head_dim is the packed layout of the reference;
+ * head_stride = 32 (heads padded with zero columns, see lime_pad_heads_f32) lets the kernel use aligned 16-byte loads.
+ * key_mask: uint8 [n_seq, S], 0 = masked, or NULL.  out[(seq * S + t) * ldo + head * head_dim + d] (always packed).
+ * Requires S <= 512, head_dim <= 32, head_stride >= head_dim.
  */
 int lime_token_attention_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const uint8_t* key_mask,
                              float* out, int64_t ldo, int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim,
-                             float scale, void* stream);
+                             int32_t head_stride, float scale, void* stream);
+
+/*
+ * lime_pad_heads_f32: dst[(blk * head_stride + d), :] = d < head_dim ? src[(blk * head_dim + d), :] : 0 for blk < n_blk.
+ * Pads the rows of in_proj_weight / in_proj_bias (n_blk = 3 * n_head blocks of head_dim rows, `cols` columns) so that the
+ * in_proj GEMM writes every head at a 128-byte aligned column offset.  src [n_blk * head_dim, cols] (ld lds),
+ * dst [n_blk * head_stride, cols] (ld ldd).
+ */
+int lime_pad_heads_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t n_blk, int32_t head_dim,
+                       int32_t head_stride, int32_t cols, void* stream);
 
 /* lime_mean_pool_f32: out[s, :] = mean_t x[(s * S + t), :]   (newsEncoders.py:317,321; padding included) */
 int lime_mean_pool_f32(const float* x, int64_t ldx, float* out, int64_t ldo, int32_t n_seq, int32_t S, int32_t dim,

@@ -37,7 +37,8 @@ SIGNATURES = {
     'lime_embed_pe_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int64,
                                     c_int32, c_void_p]),
     'lime_token_attention_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
-                                           c_int32, c_int32, c_int32, c_float, c_void_p]),
+                                           c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    'lime_pad_heads_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'lime_mean_pool_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     'lime_bucketize_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     'lime_topic_rep_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32,

@@ -609,6 +609,17 @@ __global__ __launch_bounds__(256) void gate_ln_kernel(const float* __restrict__ 
     for (int d = threadIdx.x; d < D; d += 256) out[r * D + d] = (v[d] - mean) * rstd * gamma[d] + beta[d];
 }
 
+__global__ __launch_bounds__(256) void pad_heads_kernel(const float* __restrict__ src, long lds_, float* __restrict__ dst, long ldd,
+                                                         int n_blk, int hd, int hs, int cols) {
+    const long total = (long)n_blk * hs * cols;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long row = e / cols;
+        const int c = (int)(e - row * cols);
+        const int blk = (int)(row / hs), d = (int)(row - (long)blk * hs);
+        dst[row * ldd + c] = d < hd ? src[((long)blk * hd + d) * lds_ + c] : 0.f;
+    }
+}
+
 inline unsigned grid_for(long total, int per_block, unsigned cap = 2048) {
     long b = (total + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -789,4 +800,14 @@ extern "C" int lime_gate_ln_f32(const float* y, const float* x, const float* sca
     hipLaunchKernelGGL(gate_ln_kernel, dim3((unsigned)rows), dim3(256), (size_t)(D + 4) * sizeof(float), (hipStream_t)stream, y, x,
                        scale, bias, gamma, beta, eps, out, D);
     return lime_check_launch("lime_gate_ln_f32");
+}
+
+extern "C" int lime_pad_heads_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t n_blk, int32_t head_dim,
+                                  int32_t head_stride, int32_t cols, void* stream) {
+    LIME_REQUIRE(src && dst, LIME_ERR_BAD_ARG, "lime_pad_heads_f32: NULL pointer");
+    LIME_REQUIRE(n_blk > 0 && head_dim > 0 && head_stride >= head_dim && cols > 0 && lds >= cols && ldd >= cols, LIME_ERR_BAD_ARG,
+                 "lime_pad_heads_f32: bad dims");
+    hipLaunchKernelGGL(pad_heads_kernel, dim3(grid_for((long)n_blk * head_stride * cols, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       (long)lds, dst, (long)ldd, n_blk, head_dim, head_stride, cols);
+    return lime_check_launch("lime_pad_heads_f32");
 }

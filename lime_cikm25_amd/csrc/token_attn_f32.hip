@@ -11,8 +11,8 @@
 //     instead of a 5-step shuffle tree per row;
 //   * a probability register is already laid out as the B operand of the next product
 //     O^T = V^T P^T (register r of tile t holds key 32t + (r&3) + 8(r>>2) + 4*half for query = lane),
-//     so P never leaves the register file; the A operand is one conflict-free ds_read_b32 of the
-//     staged V image per MFMA;
+//     so P never leaves the register file; V is staged transposed so that one conflict-free ds_read_b128
+//     supplies the A operands of four consecutive MFMAs;
 //   * 1/sum is applied to the 16 output registers, not to the S probabilities.
 // The output tile O^T (head dim on rows, query on lanes) is transposed through a 4 KiB per-wave LDS
 // scratch so the store writes whole 120-byte head rows.  Workgroups are persistent: K and V of the next
@@ -20,17 +20,39 @@
 // LDS; Q fragments come straight from global memory in MFMA operand form; short sequences pack 4 (S <= 32)
 // or 2 (S <= 64) pairs per group.  Scores live in the log2 domain so the exponential is one v_exp_f32.
 #include "common.h"
+#include <type_traits>
+
+#ifdef LIME_STAMPS
+// Diagnostic build only (tools/attn_stamps.py): per-wave s_memtime sums of the loop segments; never in liblime_hip.so.
+static unsigned long long* g_attn_stamp_buf = nullptr;
+extern "C" void lime_debug_set_attn_stamp_buffer(unsigned long long* p) { g_attn_stamp_buf = p; }
+#define ASTAMP(i)                                                           \
+    {                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();         \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                 \
+        tsum[i] += t_ - tlast;                                              \
+        tlast = t_;                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+    }
+#else
+#define ASTAMP(i)
+#endif
 
 namespace {
 
 constexpr int LDH = 36;  // pitch of K rows in LDS (floats): conflict-free ds_read_b128
-constexpr int LDV = 32;  // pitch of V rows: a half-wave reads 32 consecutive floats of one key
+// V is staged TRANSPOSED, Vt[head dim][key] with pitch SP + 4: accumulator registers 4g .. 4g+3 of a probability tile
+// are keys 32t + 8g + 4*half + 0..3, so the matching A operands of four consecutive PV MFMAs are one ds_read_b128
 constexpr int LDO = 33;  // pitch of the output transpose scratch
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct AttnP {
     const float* q; const float* k; const float* v; long ld; const unsigned char* mask;
-    float* out; long ldo; int n_seq, S, n_head, hd; float scale; int n_pair; int vec2; int n_group;
+    float* out; long ldo; int n_seq, S, n_head, hd, hs; float scale; int n_pair; int vec2; int n_group;
+#ifdef LIME_STAMPS
+    unsigned long long* stamps;
+#endif
 };
 
 __device__ __forceinline__ void lds_fence() {
@@ -41,28 +63,19 @@ __device__ __forceinline__ void lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// Two floats of row `r`, columns c, c+1 of a (sequence, head) operand; zero outside [0, rows) x [0, hd).
-// FAST: rows are all valid and hd is even / 8-byte aligned -> one unconditional 8-byte load (column clamped) + select.
-template <bool FAST>
+// Two floats of row `r`, columns c, c+1 of a (sequence, head) operand; zero outside [0, rows) x [0, hd) (general path).
 __device__ __forceinline__ f32x2 load2(const float* src, long ld, int r, int c, int rows, int hd, bool vec2) {
-    if constexpr (FAST) {
-        const int cc = c < hd ? c : hd - 2;
-        f32x2 v = *reinterpret_cast<const f32x2*>(src + (long)r * ld + cc);
-        if (c >= hd) v = f32x2{0.f, 0.f};
-        return v;
-    } else {
-        f32x2 v = {0.f, 0.f};
-        if (r < rows) {
-            const float* p = src + (long)r * ld + c;
-            if (vec2) {
-                if (c < hd) v = *reinterpret_cast<const f32x2*>(p);          // hd even: c + 1 < hd as well
-            } else {
-                if (c < hd) v[0] = p[0];
-                if (c + 1 < hd) v[1] = p[1];
-            }
+    f32x2 v = {0.f, 0.f};
+    if (r < rows) {
+        const float* p = src + (long)r * ld + c;
+        if (vec2) {
+            if (c < hd) v = *reinterpret_cast<const f32x2*>(p);          // hd even: c + 1 < hd as well
+        } else {
+            if (c < hd) v[0] = p[0];
+            if (c + 1 < hd) v[1] = p[1];
         }
-        return v;
     }
+    return v;
 }
 
 // A workgroup walks groups of G (sequence, head) pairs: K / V of the next group are prefetched into registers while
@@ -75,44 +88,70 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
     constexpr int G = (NT >= 3) ? 1 : (4 / NT);   // (sequence, head) pairs per group
     constexpr int WPP = 4 / G;                     // waves per pair
     constexpr int SP = NT * 32;                    // padded sequence length
-    constexpr int NLD = G * SP * 16 / 256;         // float2 per thread and operand for one group
+    constexpr int NLD = FAST ? G * SP * 8 / 256 : G * SP * 16 / 256;   // 16-byte (FAST) / 8-byte loads per thread and operand
     constexpr bool PREFETCH = NT == 3 || NT == 4;  // short sequences are latency-bound either way; long ones need the registers
     __shared__ __attribute__((aligned(16))) float Ks[G * SP * LDH];
-    __shared__ __attribute__((aligned(16))) float Vs[G * SP * LDV];
+    constexpr int LDVT = SP + 4;                   // pitch of Vt rows (keys of one head dim)
+    __shared__ __attribute__((aligned(16))) float Vs[G * 32 * LDVT];
     __shared__ __attribute__((aligned(16))) float Scr[4 * 32 * LDO];
     __shared__ float Flag[G * SP];                // 0: key takes part, 1: masked (-1e9), 2: padding (-inf)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 31, fh = lane >> 5;
-    const int S = p.S, hd = p.hd;
+    const int S = p.S, hd = p.hd, hs = p.hs;
     const bool vec2 = p.vec2 != 0;
     const int krow = 4 * fh;                       // key row of accumulator register r: (r & 3) + 8 * (r >> 2) + 4 * fh
 
-    f32x2 kreg[NLD], vreg[NLD];
+    typedef typename std::conditional<FAST, f32x4, f32x2>::type ld_t;
+    ld_t kreg[NLD], vreg[NLD];
+    // FAST (heads padded to 32 columns, 16-byte aligned; S == NT * 32): unconditional 16-byte loads that carry no
+    // arithmetic -- an invalid pair is clamped to the last pair and zero-filled in stash().  A select right behind each
+    // load made hipcc wait for every load before issuing the next one (s_memtime stamps: 58 % of a wave's life was this
+    // "prefetch", 16 serialized round trips).
     auto fetch = [&](int group) {                  // this thread's share of the group's K / V -> registers
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = tid + i * 256;
-            const int c = (e & 15) * 2, r = (e >> 4) % SP, g = (e >> 4) / SP;
-            const int pair = group * G + g;
-            f32x2 kv = {0.f, 0.f}, vv = {0.f, 0.f};
-            if (pair < p.n_pair) {
+            if constexpr (FAST) {
+                const int c = (e & 7) * 4, r = (e >> 3) % SP, g = (e >> 3) / SP;
+                int pair = group * G + g;
+                pair = pair < p.n_pair ? pair : p.n_pair - 1;
                 const int seq = pair / p.n_head, head = pair - seq * p.n_head;
-                const long base = (long)seq * S * p.ld + head * hd;
-                kv = load2<FAST>(p.k + base, p.ld, r, c, S, hd, vec2);
-                vv = load2<FAST>(p.v + base, p.ld, r, c, S, hd, vec2);
+                const long off = ((long)seq * S + r) * p.ld + head * hs + c;
+                kreg[i] = *reinterpret_cast<const f32x4*>(p.k + off);
+                vreg[i] = *reinterpret_cast<const f32x4*>(p.v + off);
+            } else {
+                const int c = (e & 15) * 2, r = (e >> 4) % SP, g = (e >> 4) / SP;
+                const int pair = group * G + g;
+                f32x2 kv = {0.f, 0.f}, vv = {0.f, 0.f};
+                if (pair < p.n_pair) {
+                    const int seq = pair / p.n_head, head = pair - seq * p.n_head;
+                    const long base = (long)seq * S * p.ld + head * hs;
+                    kv = load2(p.k + base, p.ld, r, c, S, hd, vec2);
+                    vv = load2(p.v + base, p.ld, r, c, S, hd, vec2);
+                }
+                kreg[i] = kv;
+                vreg[i] = vv;
             }
-            kreg[i] = kv;
-            vreg[i] = vv;
         }
     };
     auto stash = [&](int group) {                  // registers -> LDS images (+ key flags)
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = tid + i * 256;
-            const int c = (e & 15) * 2, r = (e >> 4) % SP, g = (e >> 4) / SP;
-            *reinterpret_cast<f32x2*>(&Ks[(g * SP + r) * LDH + c]) = kreg[i];
-            *reinterpret_cast<f32x2*>(&Vs[(g * SP + r) * LDV + c]) = vreg[i];
+            if constexpr (FAST) {
+                const int c = (e & 7) * 4, r = (e >> 3) % SP, g = (e >> 3) / SP;
+                f32x4 kv = kreg[i], vv = vreg[i];
+                if (group * G + g >= p.n_pair) { kv = f32x4{0.f, 0.f, 0.f, 0.f}; vv = kv; }
+                *reinterpret_cast<f32x4*>(&Ks[(g * SP + r) * LDH + c]) = kv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Vs[(g * 32 + c + j) * LDVT + r] = vv[j];
+            } else {
+                const int c = (e & 15) * 2, r = (e >> 4) % SP, g = (e >> 4) / SP;
+                *reinterpret_cast<f32x2*>(&Ks[(g * SP + r) * LDH + c]) = kreg[i];
+                Vs[(g * 32 + c) * LDVT + r] = vreg[i][0];
+                Vs[(g * 32 + c + 1) * LDVT + r] = vreg[i][1];
+            }
         }
         if constexpr (!FAST) {
             for (int e = tid; e < G * SP; e += 256) {
@@ -126,35 +165,53 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
 
     const int g = wave / WPP;
     const float* Kg = &Ks[g * SP * LDH];
-    const float* Vg = &Vs[g * SP * LDV];
+    const float* Vg = &Vs[g * 32 * LDVT];
     const float* Fg = &Flag[g * SP];
     float* scr = &Scr[wave * 32 * LDO];
     const float qscale = p.scale * LOG2E;          // scores in the log2 domain: p = exp2(s' - max')
     const float masked = -1e9f * LOG2E;
 
     // Q fragments straight from global memory: lane (query fi, half fh) needs Q[q][8kk + 4fh .. +3]
-    f32x2 qraw[8], qnext[8];
-    auto q_rows = [&](int grp, int qt, f32x2* dst) {
-        const int pr = grp * G + g;
-        if (pr >= p.n_pair || qt * 32 >= S) return;
-        const int sq = pr / p.n_head, hh = pr - sq * p.n_head;
-        const float* qsrc = p.q + ((long)sq * S + qt * 32) * p.ld + hh * hd;
-        const int qrows = S - qt * 32;
+    // FAST: four 16-byte loads (the pad columns are real zeros); general: eight 8-byte / scalar loads
+    typedef typename std::conditional<FAST, f32x4, f32x2>::type q_t;
+    constexpr int NQ = FAST ? 4 : 8;
+    q_t qraw[NQ], qnext[NQ];
+    auto q_rows = [&](int grp, int qt, q_t* dst) {
+        int pr = grp * G + g;
+        if constexpr (FAST) {                         // S == NT * 32: every query row exists
+            pr = pr < p.n_pair ? pr : p.n_pair - 1;
+            const int sq = pr / p.n_head, hh = pr - sq * p.n_head;
+            const float* qsrc = p.q + ((long)sq * S + qt * 32 + fi) * p.ld + hh * hs + fh * 4;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            dst[2 * kk] = load2<FAST>(qsrc, p.ld, fi, kk * 8 + fh * 4, qrows, hd, vec2);
-            dst[2 * kk + 1] = load2<FAST>(qsrc, p.ld, fi, kk * 8 + fh * 4 + 2, qrows, hd, vec2);
+            for (int kk = 0; kk < 4; ++kk) dst[kk] = *reinterpret_cast<const f32x4*>(qsrc + kk * 8);
+        } else {
+            if (pr >= p.n_pair || qt * 32 >= S) return;
+            const int sq = pr / p.n_head, hh = pr - sq * p.n_head;
+            const float* qsrc = p.q + ((long)sq * S + qt * 32) * p.ld + hh * hs;
+            const int qrows = S - qt * 32;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                dst[2 * kk] = load2(qsrc, p.ld, fi, kk * 8 + fh * 4, qrows, hd, vec2);
+                dst[2 * kk + 1] = load2(qsrc, p.ld, fi, kk * 8 + fh * 4 + 2, qrows, hd, vec2);
+            }
         }
     };
     auto load_q = [&](int grp, int qt) { q_rows(grp, qt, qraw); };
     auto prefetch_q = [&](int grp) { q_rows(grp, wave % WPP, qnext); };
 
+#ifdef LIME_STAMPS
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     int group = blockIdx.x;
     if (PREFETCH) { fetch(group); prefetch_q(group); }
     for (; group < p.n_group; group += gridDim.x) {
         if (!PREFETCH) fetch(group);
         stash(group);
+        ASTAMP(0)
         lds_barrier();
+        ASTAMP(1)
         const int pair = group * G + g;
         const bool live = pair < p.n_pair;
         const int seq = live ? pair / p.n_head : 0, head = live ? pair - seq * p.n_head : 0;
@@ -162,7 +219,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
         if (!PREFETCH) { if (live && qt0 * 32 < S) load_q(group, qt0); }
         else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) qraw[i] = qnext[i];
+            for (int i = 0; i < NQ; ++i) qraw[i] = qnext[i];
         }
         __builtin_amdgcn_sched_barrier(0);
         if (PREFETCH && group + (int)gridDim.x < p.n_group) {          // next group's K / V / Q: in flight under the MFMAs
@@ -170,6 +227,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
             prefetch_q(group + gridDim.x);
         }
         __builtin_amdgcn_sched_barrier(0);
+        ASTAMP(2)
         if (live) {
             for (int qt = qt0; qt < NT; qt += WPP) {
                 if (qt * 32 >= S) break;
@@ -177,8 +235,12 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
                 f32x4 qf[4];
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    qf[kk][0] = qraw[2 * kk][0] * qscale; qf[kk][1] = qraw[2 * kk][1] * qscale;
-                    qf[kk][2] = qraw[2 * kk + 1][0] * qscale; qf[kk][3] = qraw[2 * kk + 1][1] * qscale;
+                    if constexpr (FAST) {
+                        qf[kk] = qraw[kk] * qscale;
+                    } else {
+                        qf[kk][0] = qraw[2 * kk][0] * qscale; qf[kk][1] = qraw[2 * kk][1] * qscale;
+                        qf[kk][2] = qraw[2 * kk + 1][0] * qscale; qf[kk][3] = qraw[2 * kk + 1][1] * qscale;
+                    }
                 }
                 // ---- S^T = K Q^T: keys on rows, this lane's query on the column (rows beyond S are zeros in LDS) ------
                 f32x16 sc[NT];
@@ -194,6 +256,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
                             sc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[u], qf[kk][u], sc[t], 0, 0, 0);
                     }
                 }
+                ASTAMP(3)
                 // ---- key padding / key mask: a select per register (its key is the same for a whole half-wave) -----
                 if constexpr (!FAST) {
 #pragma unroll
@@ -225,6 +288,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
                 }
                 sum += __shfl_xor(sum, 32);
                 const float inv = 1.0f / sum;
+                ASTAMP(4)
                 // ---- O^T = V^T P^T: probability registers are the B operand as they stand --------------------------
                 f32x16 o;
 #pragma unroll
@@ -232,11 +296,15 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float vv = Vg[(t * 32 + (r & 3) + 8 * (r >> 2) + krow) * LDV + fi];      // rows beyond S are zeros
-                        o = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, sc[t][r], o, 0, 0, 0);
+                    for (int gq = 0; gq < 4; ++gq) {
+                        // keys 32t + 8gq + 4*half + 0..3 of head dim `fi` (rows beyond S are zeros)
+                        const f32x4 vv = *reinterpret_cast<const f32x4*>(&Vg[fi * LDVT + t * 32 + gq * 8 + krow]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            o = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[e], sc[t][4 * gq + e], o, 0, 0, 0);
                     }
                 }
+                ASTAMP(5)
                 // ---- transpose [head dim][query] -> [query][head dim] through the scratch, store whole head rows ----
 #pragma unroll
                 for (int r = 0; r < 16; ++r) scr[fi * LDO + (r & 3) + 8 * (r >> 2) + krow] = o[r] * inv;
@@ -250,10 +318,17 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
                     }
                 }
                 lds_fence();
+                ASTAMP(6)
             }
         }
         lds_barrier();                           // everyone is done with this group's LDS images
+        ASTAMP(7)
     }
+#ifdef LIME_STAMPS
+    if (p.stamps && lane == 0) {
+        for (int i = 0; i < 8; ++i) p.stamps[((long)blockIdx.x * 4 + wave) * 8 + i] = tsum[i];
+    }
+#endif
 }
 
 int attn_num_cus() {
@@ -275,7 +350,12 @@ int launch(AttnP p, hipStream_t s) {
     const int per_cu = NT <= 2 ? 3 : (NT <= 4 ? 2 : 1);
     long blocks = (long)attn_num_cus() * per_cu;
     if (blocks > p.n_group) blocks = p.n_group;
-    const bool fast = p.mask == nullptr && p.S == NT * 32 && p.vec2;
+#ifdef LIME_STAMPS
+    p.stamps = g_attn_stamp_buf;
+#endif
+    // FAST: no mask, S a multiple of 32, heads padded to 32 columns, 16-byte aligned operands
+    const bool fast = p.mask == nullptr && p.S == NT * 32 && p.hs == 32 && p.ld % 4 == 0 &&
+                      (((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v) % 16 == 0);
     if (fast) hipLaunchKernelGGL((token_attn_kernel<NT, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((token_attn_kernel<NT, false>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     return lime_check_launch("lime_token_attention_f32");
@@ -285,18 +365,20 @@ int launch(AttnP p, hipStream_t s) {
 
 extern "C" int lime_token_attention_f32(const float* q, const float* k, const float* v, int64_t ld_qkv,
                                         const uint8_t* key_mask, float* out, int64_t ldo, int32_t n_seq, int32_t S,
-                                        int32_t n_head, int32_t head_dim, float scale, void* stream) {
+                                        int32_t n_head, int32_t head_dim, int32_t head_stride, float scale, void* stream) {
     LIME_REQUIRE(q && k && v && out, LIME_ERR_BAD_ARG, "lime_token_attention_f32: NULL pointer");
     LIME_REQUIRE(n_seq >= 0 && S > 0 && n_head > 0 && head_dim > 0, LIME_ERR_BAD_ARG,
                  "lime_token_attention_f32: bad dims n_seq=%d S=%d n_head=%d head_dim=%d", n_seq, S, n_head, head_dim);
     LIME_REQUIRE(head_dim <= 32, LIME_ERR_UNSUPPORTED, "lime_token_attention_f32: head_dim %d > 32", head_dim);
+    LIME_REQUIRE(head_stride >= head_dim, LIME_ERR_BAD_ARG, "lime_token_attention_f32: head_stride %d < head_dim %d", head_stride, head_dim);
     LIME_REQUIRE(S <= 512, LIME_ERR_UNSUPPORTED, "lime_token_attention_f32: S %d > 512", S);
-    LIME_REQUIRE(ld_qkv >= (int64_t)n_head * head_dim && ldo >= (int64_t)n_head * head_dim, LIME_ERR_BAD_ARG,
+    LIME_REQUIRE(ld_qkv >= (int64_t)n_head * head_stride && ldo >= (int64_t)n_head * head_dim, LIME_ERR_BAD_ARG,
                  "lime_token_attention_f32: leading dimension smaller than n_head * head_dim");
     if (n_seq == 0) return LIME_OK;
     // 8-byte loads need an even head_dim and leading dimension and 8-byte aligned bases
-    const int vec2 = (head_dim % 2 == 0) && (ld_qkv % 2 == 0) && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 8 == 0);
-    AttnP p{q, k, v, (long)ld_qkv, key_mask, out, (long)ldo, n_seq, S, n_head, head_dim, scale, n_seq * n_head, vec2, 0};
+    const int vec2 = (head_dim % 2 == 0) && (head_stride % 2 == 0) && (ld_qkv % 2 == 0) &&
+                     (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 8 == 0);
+    AttnP p{q, k, v, (long)ld_qkv, key_mask, out, (long)ldo, n_seq, S, n_head, head_dim, head_stride, scale, n_seq * n_head, vec2, 0};
     hipStream_t s = (hipStream_t)stream;
     const int nt = (S + 31) / 32;
     if (nt <= 1) return launch<1>(p, s);

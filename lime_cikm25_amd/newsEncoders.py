@@ -276,15 +276,20 @@ def encode_tokens(ids, table, pe, transformer, nhead):
     M, S = ids.shape
     E = table.shape[1]
     hd = E // nhead
+    hs = 32 if hd <= 32 else hd                    # heads padded to 32 columns in the in_proj output: the 128 x 320 GEMM
+    W = nhead * hs                                 # tiles compute those columns anyway, and attention gets 16-byte loads
     flat = ids.reshape(-1)
     x = None
     for li, layer in enumerate(transformer.layers):
         sa = layer.self_attn
+        w_in = ops.pad_heads(sa.in_proj_weight, 3 * nhead, hd, hs) if hs != hd else sa.in_proj_weight
+        b_in = ops.pad_heads(sa.in_proj_bias, 3 * nhead, hd, hs) if hs != hd else sa.in_proj_bias
         if li == 0:
-            qkv = ops.linear(table, sa.in_proj_weight, sa.in_proj_bias, a_ids=flat, a_pe=pe, a_period=S)
+            qkv = ops.linear(table, w_in, b_in, a_ids=flat, a_pe=pe, a_period=S)
         else:
-            qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias)
-        attn = ops.token_attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], M, S, nhead, hd, 1.0 / math.sqrt(hd))
+            qkv = ops.linear(x, w_in, b_in)
+        attn = ops.token_attention(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, 1.0 / math.sqrt(hd),
+                                   head_stride=hs)
         ln1 = (layer.norm1.weight, layer.norm1.bias)
         if li == 0:
             x1 = ops.linear(attn, sa.out_proj.weight, sa.out_proj.bias, res=table, res_ids=flat, res_pe=pe, res_period=S,

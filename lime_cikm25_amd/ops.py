@@ -170,13 +170,15 @@ def embed_pe(ids, table, pe=None, period=0, out=None):
     return out
 
 
-def token_attention(q, k, v, n_seq, S, n_head, head_dim, scale, key_mask=None, out=None):
-    """softmax(Q K^T * scale [+mask]) V per (sequence, head); q/k/v: [n_seq*S, n_head*head_dim] views of one pitch."""
+def token_attention(q, k, v, n_seq, S, n_head, head_dim, scale, key_mask=None, out=None, head_stride=None):
+    """softmax(Q K^T * scale [+mask]) V per (sequence, head); q/k/v: [n_seq*S, n_head*head_stride] views of one pitch
+    (head_stride defaults to head_dim, the packed layout); out: [n_seq*S, n_head*head_dim]."""
     lib = _lib.load()
+    hs = head_dim if head_stride is None else head_stride
     for t, n in ((q, 'q'), (k, 'k'), (v, 'v')):
         _mat(t, n)
-        if tuple(t.shape) != (n_seq * S, n_head * head_dim):
-            raise ValueError('%s must be [%d, %d]' % (n, n_seq * S, n_head * head_dim))
+        if tuple(t.shape) != (n_seq * S, n_head * hs):
+            raise ValueError('%s must be [%d, %d]' % (n, n_seq * S, n_head * hs))
     if not (_ld(q) == _ld(k) == _ld(v)):
         raise ValueError('q, k and v must share one leading dimension')
     if out is None:
@@ -185,9 +187,23 @@ def token_attention(q, k, v, n_seq, S, n_head, head_dim, scale, key_mask=None, o
     m = _mask_u8(key_mask, 'key_mask')
     if m is not None and m.numel() != n_seq * S:
         raise ValueError('key_mask must have n_seq * S elements')
-    check(lib.lime_token_attention_f32(_p(q), _p(k), _p(v), _ld(q), _p(m), _p(out), _ld(out), n_seq, S, n_head, head_dim,
+    check(lib.lime_token_attention_f32(_p(q), _p(k), _p(v), _ld(q), _p(m), _p(out), _ld(out), n_seq, S, n_head, head_dim, hs,
                                        scale, _stream()), 'lime_token_attention_f32')
     return out
+
+
+def pad_heads(src, n_blk, head_dim, head_stride):
+    """[n_blk * head_dim, cols] (or a vector of n_blk * head_dim) -> rows padded with zeros to head_stride per block."""
+    lib = _lib.load()
+    vec = src.dim() == 1
+    s2 = src.view(-1, 1) if vec else src
+    _mat(s2, 'src')
+    if s2.shape[0] != n_blk * head_dim:
+        raise ValueError('src must have n_blk * head_dim rows')
+    dst = torch.empty((n_blk * head_stride, s2.shape[1]), dtype=torch.float32, device=src.device)
+    check(lib.lime_pad_heads_f32(_p(s2), _ld(s2), _p(dst), _ld(dst), n_blk, head_dim, head_stride, s2.shape[1], _stream()),
+          'lime_pad_heads_f32')
+    return dst.view(-1) if vec else dst
 
 
 def mean_pool(x, n_seq, S, out=None):

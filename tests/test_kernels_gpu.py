@@ -157,6 +157,44 @@ def test_token_attention(ops, S, h, hd):
     check(got, attn_ref(qkv, n_seq, S, h, hd, scale), what='attn S=%d' % S)
 
 
+@pytest.mark.parametrize('S', [1, 31, 32, 64, 96, 100, 128, 160, 256])
+@pytest.mark.parametrize('h,hd', [(10, 30), (7, 20), (3, 32)])
+def test_token_attention_padded_heads(ops, S, h, hd):
+    """The model's layout: every head of Q/K/V padded to 32 columns by padding in_proj's rows (pad_heads)."""
+    n_seq, hs = (37 if S <= 128 else 3), 32
+    E, W = h * hd, h * hs
+    qkv = rnd(n_seq * S, 3 * E, seed=S + 7, scale=2.0)
+    padded = ops.pad_heads(dev(qkv.t().contiguous()), 3 * h, hd, hs).t().contiguous()      # rows of a [3E, tok] matrix
+    assert padded.shape == (n_seq * S, 3 * W)
+    ref_pad = torch.zeros(n_seq * S, 3 * h, hs)
+    ref_pad[:, :, :hd] = qkv.view(n_seq * S, 3 * h, hd)
+    assert torch.equal(padded.cpu(), ref_pad.view(n_seq * S, 3 * W))
+    scale = 1.0 / math.sqrt(hd)
+    got = ops.token_attention(padded[:, :W], padded[:, W:2 * W], padded[:, 2 * W:], n_seq, S, h, hd, scale, head_stride=hs)
+    check(got, attn_ref(qkv, n_seq, S, h, hd, scale), what='padded attn S=%d' % S)
+
+
+def test_token_attention_padded_heads_garbage_pad(ops):
+    """Pad columns hold zeros in the model, but the general (non-FAST) path must not read them at all."""
+    n_seq, S, h, hd, hs = 4, 40, 10, 30, 32
+    E, W = h * hd, h * hs
+    qkv = rnd(n_seq * S, 3 * E, seed=3, scale=2.0)
+    pad = torch.full((n_seq * S, 3 * h, hs), float('nan'))
+    pad[:, :, :hd] = qkv.view(n_seq * S, 3 * h, hd)
+    d = dev(pad.view(n_seq * S, 3 * W))
+    scale = 1.0 / math.sqrt(hd)
+    got = ops.token_attention(d[:, :W], d[:, W:2 * W], d[:, 2 * W:], n_seq, S, h, hd, scale, head_stride=hs)
+    check(got, attn_ref(qkv, n_seq, S, h, hd, scale), what='padded attn, NaN pads')
+
+
+def test_pad_heads_bias(ops):
+    b = rnd(90, seed=1)
+    got = ops.pad_heads(dev(b), 9, 10, 16).cpu()
+    ref = torch.zeros(9, 16)
+    ref[:, :10] = b.view(9, 10)
+    assert torch.equal(got, ref.view(-1))
+
+
 @pytest.mark.parametrize('S', [16, 32, 48])
 def test_token_attention_key_mask(ops, S):
     n_seq, h, hd = 6, 10, 20

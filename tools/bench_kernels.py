@@ -40,16 +40,20 @@ def main():
         tok = M * S
         ids = torch.randint(0, V, (tok,), generator=g, dtype=torch.int32).to(dev)
         pe = rnd(S, E)
-        qkv = torch.empty(tok, 3 * E, device=dev)
+        W = 320                              # heads padded to 32 columns, as newsEncoders.encode_tokens lays them out
+        w_in_p = ops.pad_heads(w_in, 30, 30, 32)
+        b_in_p = ops.pad_heads(b_in, 30, 30, 32)
+        qkv = torch.empty(tok, 3 * W, device=dev)
         attn = torch.empty(tok, E, device=dev)
         x1 = torch.empty(tok, E, device=dev)
         h = torch.empty(tok, F, device=dev)
         x2 = torch.empty(tok, E, device=dev)
         cases = [
             ('qkv_' + name, 2.0 * tok * 3 * E * E,
-             lambda: ops.linear(table, w_in, b_in, a_ids=ids, a_pe=pe, a_period=S, out=qkv)),
+             lambda: ops.linear(table, w_in_p, b_in_p, a_ids=ids, a_pe=pe, a_period=S, out=qkv)),
             ('attn_' + name, 4.0 * tok * S * E,
-             lambda: ops.token_attention(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], M, S, 10, 30, 1 / math.sqrt(30), out=attn)),
+             lambda: ops.token_attention(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, 10, 30, 1 / math.sqrt(30), out=attn,
+                                         head_stride=32)),
             ('out_' + name, 2.0 * tok * E * E,
              lambda: ops.linear(attn, w_o, b_o, res=table, res_ids=ids, res_pe=pe, res_period=S, ln=ln, out=x1)),
             ('ffn1_' + name, 2.0 * tok * F * E, lambda: ops.linear(x1, w1, b1, act='relu', out=h)),
