@@ -60,7 +60,10 @@ enum { LIME_ACT_NONE = 0, LIME_ACT_RELU = 1, LIME_ACT_TANH = 2, LIME_ACT_SIGMOID
  *   v  = acc + bias[n]                                   (bias may be NULL)
  *   v  = act(v)                                          (LIME_ACT_*)
  *   v += residual(r, n)                                  (res may be NULL)
- *        res_ids == NULL : res[(r / res_div) * ldr + n]   (res_div >= 1; > 1 broadcasts one row to res_div rows)
+ *        res_ids == NULL : res[(r / res_div) * ldr + n]   (res_div >= 1; > 1 broadcasts one row to res_div rows);
+ *                          with res_mod > 0 the row is ((r / res_div) % res_mod): a [res_mod, N] table repeated down
+ *                          the rows -- in_proj of the encoder layers uses it for the positional term, which is linear:
+ *                          (E[ids] + PE) W^T + b = E[ids] W^T + (PE W^T + b)[r % S]
  *        res_ids != NULL : res[res_ids[r] * ldr + n] (+ res_pe[(r % res_period) * ldr_pe + n])
  *   ln_gamma != NULL : v = LayerNorm over the N columns of row r (eps = ln_eps); requires N <= 320 and either no
  *        activation (residual allowed) or ReLU without residual
@@ -78,9 +81,15 @@ typedef struct {
     float* c;             int64_t ldc;
     int32_t M, N, K;
     int32_t act;
+    int32_t res_mod;      /* > 0 (res_ids == NULL): residual row = (r / res_div) % res_mod -- a periodic table */
+    int32_t reserved;     /* must be 0 */
 } lime_linear_args;
 
 int lime_linear_f32(const lime_linear_args* args, void* stream);
+
+/* The kernel instantiation the calling thread's last lime_linear_f32 launched (e.g. "gemm_pp_kernel<10, true, false, 1>"),
+ * as rocprofv3 names it: lets a profiler harness match its own event timings to the kernel trace. */
+const char* lime_last_linear_kernel(void);
 
 /*
  * lime_embed_pe_f32: out[r, :] = table[ids[r], :] + pe[(r % period), :]   (pe may be NULL)

@@ -26,6 +26,7 @@ class LinearArgs(Structure):
         ('c', c_void_p), ('ldc', c_int64),
         ('M', c_int32), ('N', c_int32), ('K', c_int32),
         ('act', c_int32),
+        ('res_mod', c_int32), ('reserved', c_int32),
     ]
 
 
@@ -33,6 +34,7 @@ class LinearArgs(Structure):
 SIGNATURES = {
     'lime_abi_version': (c_int32, []),
     'lime_last_error_string': (c_char_p, []),
+    'lime_last_linear_kernel': (c_char_p, []),
     'lime_linear_f32': (c_int32, [POINTER(LinearArgs), c_void_p]),
     'lime_embed_pe_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int64,
                                     c_int32, c_void_p]),

@@ -12,6 +12,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void lime_set_error(const char* fmt, ...);
+void lime_set_last_linear_kernel(const char* fmt, ...);      // lime_last_linear_kernel(): which instantiation ran
 
 #define LIME_REQUIRE(cond, code, ...)            \
     do {                                         \

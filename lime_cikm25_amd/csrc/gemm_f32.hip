@@ -24,6 +24,7 @@
 //   * XCD-aware bijective remap of the workgroup id: an XCD walks whole row panels, so the N-tiles that
 //     re-read one A panel hit the same 4 MiB L2.
 #include "common.h"
+#include "gemm_pp.h"
 #include <stdlib.h>
 
 #ifdef LIME_STAMPS
@@ -53,7 +54,7 @@ constexpr int LDK = 36;   // LDS row pitch in floats: 144 B, conflict-free for d
 struct GemmP {
     const float* a; long lda; const int* a_ids; const float* a_pe; long lda_pe; int a_period;
     const float* w; long ldw; const float* bias;
-    const float* res; long ldr; int res_div; const int* res_ids; const float* res_pe; long ldr_pe; int res_period;
+    const float* res; long ldr; int res_div; int res_mod; const int* res_ids; const float* res_pe; long ldr_pe; int res_period;
     const float* ln_g; const float* ln_b; float ln_eps;
     float* c; long ldc; int M, N, K; int act;
     int n_row_blocks, n_col_blocks;
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 
     // C layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
     const __amdgpu_buffer_rsrc_t rs_rpe = make_rsrc(p.res_pe ? p.res_pe : p.a);
     auto residual_rsrc = [&](long row0) {
-        return make_rsrc(p.res == nullptr ? p.a : (p.res_ids ? p.res : p.res + (row0 / p.res_div) * p.ldr));
+        return make_rsrc(p.res == nullptr ? p.a : ((p.res_ids || p.res_mod > 0) ? p.res : p.res + (row0 / p.res_div) * p.ldr));
     };
     // byte offset of output row `row` inside the residual operand (OOB when there is none), and inside the positional table
     auto residual_row = [&](long row0, long row, unsigned& ro, unsigned& po) {
@@ -248,6 +249,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 
             if (p.res_ids) {
                 ro = (unsigned)p.res_ids[row] * (unsigned)ldr4;
                 if (p.res_pe) po = (unsigned)(row % p.res_period) * (unsigned)((int)p.ldr_pe * 4);
+            } else if (p.res_mod > 0) {
+                ro = (unsigned)(((row / p.res_div) % p.res_mod) * ldr4);              // a periodic [res_mod, N] table
             } else {
                 ro = (unsigned)((row / p.res_div - row0 / p.res_div) * ldr4);
             }
@@ -571,6 +574,8 @@ int launch_one(const GemmP& p0, int wg_per_cu, hipStream_t stream) {
 #endif
     hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, WM, WN, VEC, LN, PE, ACT, GENERIC, VIO>), dim3((unsigned)nwg), dim3(WM * WN * 64), 0,
                        stream, p);
+    lime_set_last_linear_kernel("gemm_f32_kernel<%d, %d, %d, %d, %d, %s, %s, %d, %s, %s>", TM, TN, WM, WN, VEC, LN ? "true" : "false",
+                                PE ? "true" : "false", ACT, GENERIC ? "true" : "false", VIO ? "true" : "false");
     return lime_check_launch("lime_linear_f32");
 }
 
@@ -604,12 +609,21 @@ extern "C" int lime_linear_f32(const lime_linear_args* a, void* stream) {
                  "lime_linear_f32: res_pe needs res_ids, res_period > 0 and ldr_pe >= N");
     LIME_REQUIRE(!a->ln_gamma || a->ln_beta, LIME_ERR_BAD_ARG, "lime_linear_f32: ln_gamma without ln_beta");
     LIME_REQUIRE(a->act >= LIME_ACT_NONE && a->act <= LIME_ACT_SIGMOID, LIME_ERR_BAD_ARG, "lime_linear_f32: bad act %d", a->act);
+    LIME_REQUIRE(a->res_mod >= 0 && a->reserved == 0, LIME_ERR_BAD_ARG, "lime_linear_f32: res_mod < 0 or reserved != 0");
     if (a->M == 0) return LIME_OK;
+
+    // big M, 16-byte friendly operands: two four-wave workgroups per CU with LDS-DMA staging (gemm_pp_f32.hip)
+    static const bool pp_off = getenv("LIME_GEMM_NO_PP") != nullptr;          // A/B switch for tools/, not a product option
+    if (!pp_off) {
+        const int st = lime_linear_pp(a, (hipStream_t)stream);
+        if (st != LIME_PP_NOT_APPLICABLE) return st;
+    }
 
     GemmP p;
     p.a = a->a; p.lda = a->lda; p.a_ids = a->a_ids; p.a_pe = a->a_pe; p.lda_pe = a->lda_pe; p.a_period = a->a_period;
     p.w = a->w; p.ldw = a->ldw; p.bias = a->bias;
     p.res = a->res; p.ldr = a->ldr; p.res_div = a->res_div > 0 ? a->res_div : 1; p.res_ids = a->res_ids;
+    p.res_mod = (a->res && !a->res_ids && a->res_mod > 0) ? a->res_mod : 0;
     p.res_pe = a->res_pe; p.ldr_pe = a->ldr_pe; p.res_period = a->res_period;
     p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps;
     p.c = a->c; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act;

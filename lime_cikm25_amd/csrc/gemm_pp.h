@@ -1,0 +1,20 @@
+// Internal interface between lime_linear_f32's dispatcher (gemm_f32.hip) and the two-workgroups-per-CU LDS-DMA
+// kernel (gemm_pp_f32.hip).
+#pragma once
+#include "common.h"
+
+#define LIME_PP_NOT_APPLICABLE 1
+
+struct PPParams {
+    const float* a; long lda; const int* a_ids;
+    const float* w; long ldw; const float* bias;
+    const float* res; long ldr; int res_mod; const int* res_ids; const float* res_pe; long ldr_pe; int res_period;
+    const float* ln_g; const float* ln_b; float ln_eps;
+    float* c; long ldc; int M, N, K;
+    int n_row_blocks, n_col_blocks;
+#ifdef LIME_STAMPS
+    unsigned long long* stamps;
+#endif
+};
+
+int lime_linear_pp(const lime_linear_args* a, hipStream_t stream);

@@ -1,0 +1,443 @@
+// lime_linear_f32, big-M instantiations: two independent four-wave workgroups per CU ("ping-pong"), operands staged
+// global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), exact-fp32 MFMA.
+//
+// Why a second GEMM kernel (the eight-wave persistent kernel of gemm_f32.hip stays for every other shape):
+// s_memtime stamps of that kernel on the encoder shapes (K = 300 ... 512, i.e. 10 ... 16 chunks per tile) showed the MFMA
+// pipe issued only ~60 % of a wave's life: 8-18 % went to vmcnt + ds_write of the register-staged prefetch, 5-15 % to the
+// workgroup barrier, 13-30 % to the tile boundary (residual loads into the accumulators, LayerNorm epilogue, stores) --
+// and with ONE workgroup per CU every wave of the CU sits in those phases at the same time, so nothing fills the pipe.
+// Here:
+//   * a workgroup is 4 waves (one per SIMD) and owns a 128 x 320 (or 128 x 256) output tile; TWO workgroups are resident
+//     per CU (2 x 61 KB LDS, <= 256 VGPRs), each SIMD holds one wave of either.  They run unsynchronised, so one
+//     workgroup's barrier / load wait / epilogue is the other's MFMA time.  A lone wave can keep its SIMD's MFMA pipe full
+//     (10 independent accumulator tiles), so a CU with one workgroup left is not slower per tile.
+//   * operands go global -> LDS without passing registers: no staging VGPRs (the budget goes to a 32 x 320 accumulator
+//     slab per wave), no ds_write, no vmcnt wait in front of a ds_write.  K chunks are 16 deep, two LDS stages; the DMA of
+//     chunk c + 1 is in flight under the MFMAs of chunk c; one barrier per chunk.
+//   * an LDS-DMA instruction writes 1 KB linearly (lane l -> base + 16 l), so rows cannot be padded; the image is
+//     [row][16 floats] with the 16-byte segment index XOR-swizzled by (row >> 2) & 3 -- applied to the per-lane SOURCE
+//     address when staging and to the ds_read_b128 address when reading fragments (conflict free: the 16 lanes of a
+//     read phase cover all 16 bank groups).
+//   * a wave owns 32 output rows x all tile columns of the transposed product D^T = W A^T: an output row is a lane (two
+//     lanes, one per half-wave), its columns are that lane's registers -- residual loads / result stores are 16-byte
+//     accesses, and LayerNorm needs no cross-wave exchange at all (in-lane sums + one cross-half shuffle).
+//   * k beyond K, rows beyond M and weight rows beyond N are out-of-range buffer offsets: the DMA writes zeros.
+#include "common.h"
+#include "gemm_pp.h"
+
+#ifdef LIME_STAMPS
+// Diagnostic build only (tools/gemm_stamps.py): per-wave s_memtime sums of the main-loop segments; never in liblime_hip.so.
+static unsigned long long* g_pp_stamp_buf = nullptr;
+extern "C" void lime_debug_set_pp_stamp_buffer(unsigned long long* p) { g_pp_stamp_buf = p; }
+#define PSTAMP(i)                                                           \
+    {                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();         \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                 \
+        tsum[i] += t_ - tlast;                                              \
+        tlast = t_;                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+    }
+#else
+#define PSTAMP(i)
+#endif
+
+namespace {
+
+constexpr int BM = 128;   // output rows per tile (4 waves x 32)
+constexpr int BK = 16;    // k depth of one LDS stage
+constexpr unsigned OOB = 0x80000000u;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFF0, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ int buf_load_i32(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return (int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0);
+}
+// 16 bytes per lane global -> LDS (lane l lands at lds_base + 16 l), out-of-range offsets write zeros.
+// (The builtin only exists in the device pass; inside a kernel TEMPLATE it makes the host pass drop the launch stub.)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, float* lds_base, unsigned voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds_base, 16, voff, soff, 0, 0);
+#endif
+}
+__device__ __forceinline__ void buf_store4(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+
+// NTL: 32-column MFMA tiles per wave (tile width 32 * NTL).  LN: LayerNorm epilogue (one column block spans N).
+// RES: 0 none, 1 dense residual rows ((r / 1) % res_mod), 2 gathered rows + positional table.
+template <int NTL, bool LN, bool RELU, int RES>
+__global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
+    constexpr int BN = NTL * 32;
+    constexpr int A_ST = BM * BK, W_ST = BN * BK, STAGE = A_ST + W_ST;     // floats
+    constexpr int NWI = BN / 64;                                            // weight DMA instructions per wave and chunk
+    // ONE __shared__ object (a second one beside an LDS-DMA target makes hipcc drain vmcnt before every ds_read)
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE + 4 * BN];
+    float* const Bs = lds + 2 * STAGE;             // bias of the tile's columns, double-buffered by tile parity
+    float* const Gs = Bs + 2 * BN;                 // LayerNorm gamma / beta (column block 0 only)
+    float* const Es = Gs + BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 31, fh = lane >> 5;
+    const int nwg = gridDim.x;
+    const int wg = xcd_remap(blockIdx.x, nwg);
+    const int ntiles = p.n_row_blocks * p.n_col_blocks;
+
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w);
+    const bool gather_a = p.a_ids != nullptr;
+    const int lda4 = (int)p.lda * 4, ldw4 = (int)p.ldw * 4, ldc4 = (int)p.ldc * 4, ldr4 = (int)p.ldr * 4;
+
+    // ---- loader state: per-lane byte offsets of the rows this lane stages ---------------------------------------------
+    // DMA instruction `idx` of an operand covers image rows 16 idx .. 16 idx + 15; lane l fills row 16 idx + (l >> 2),
+    // physical segment l & 3, which holds logical segment (l & 3) ^ ((row >> 2) & 3) = (l & 3) ^ ((l >> 4) & 3).
+    const int srow = lane >> 2;
+    const int lseg = (lane & 3) ^ ((lane >> 4) & 3);
+    unsigned a_voff[2], w_voff[NWI];
+    int aid_next[2];                                   // gathered row ids of the NEXT tile (loaded a tile ahead)
+    int rid_next = 0;                                  // RES == 2: residual row id of this lane's output row, next tile
+    __amdgpu_buffer_rsrc_t rs_a = make_rsrc(p.a);
+
+    auto tile_rc = [&](int tile, int& row0, int& col0) {
+        const int rb = tile / p.n_col_blocks;
+        row0 = rb * BM;
+        col0 = (tile - rb * p.n_col_blocks) * BN;
+    };
+    auto prefetch_ids = [&](int tile) {                // ids of `tile` -> registers (any tile index: out of range reads 0)
+        int row0, col0;
+        tile_rc(tile, row0, col0);
+        const bool live = tile < ntiles;
+        const __amdgpu_buffer_rsrc_t rs_aids = make_rsrc(p.a_ids ? (const void*)p.a_ids : (const void*)p.w);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = row0 + 16 * (wave * 2 + j) + srow;
+            aid_next[j] = buf_load_i32(rs_aids, (gather_a && live && row < p.M) ? (unsigned)row * 4u : OOB);
+        }
+        if constexpr (RES == 2) {
+            const int row = row0 + 32 * wave + fi;
+            const __amdgpu_buffer_rsrc_t rs_rids = make_rsrc(p.res_ids ? (const void*)p.res_ids : (const void*)p.w);
+            rid_next = buf_load_i32(rs_rids, (live && row < p.M) ? (unsigned)row * 4u : OOB);
+        }
+    };
+    auto loader_set_tile = [&](int tile) {             // consumes aid_next
+        int row0, col0;
+        tile_rc(tile, row0, col0);
+        // dense A: the descriptor base moves to the tile's first row, offsets stay small; gather: base = the table
+        rs_a = make_rsrc(gather_a ? p.a : p.a + (long)row0 * p.lda);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rl = 16 * (wave * 2 + j) + srow;
+            const unsigned rowsel = gather_a ? (unsigned)aid_next[j] : (unsigned)rl;
+            a_voff[j] = (row0 + rl < p.M) ? rowsel * (unsigned)lda4 + (unsigned)lseg * 16u : OOB;
+        }
+#pragma unroll
+        for (int j = 0; j < NWI; ++j) {
+            const int n = col0 + 16 * (wave * NWI + j) + srow;
+            w_voff[j] = (n < p.N) ? (unsigned)n * (unsigned)ldw4 + (unsigned)lseg * 16u : OOB;
+        }
+    };
+    auto issue = [&](int stage, int k0) {              // DMA of chunk k0 .. k0 + 15 into `stage`
+        const bool kin = k0 + lseg * 4 < p.K;          // K % 4 == 0: a segment is valid or not as a whole
+        float* const sb = lds + stage * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            dma16(rs_a, sb + (wave * 2 + j) * 256, kin ? a_voff[j] : OOB, k0 * 4);
+#pragma unroll
+        for (int j = 0; j < NWI; ++j)
+            dma16(rs_w, sb + A_ST + (wave * NWI + j) * 256, kin ? w_voff[j] : OOB, k0 * 4);
+    };
+
+    // ---- compute state ---------------------------------------------------------------------------------------------
+    // fragment of k-step s (k = 8 s + 4 h .. + 3 of the chunk): logical segment 2 s + h of row i
+    const int sw = (fi >> 2) & 3;
+    const int a_off = (32 * wave + fi) * BK, w_off = A_ST + fi * BK;
+    const int seg0 = ((0 + fh) ^ sw) * 4, seg1 = ((2 + fh) ^ sw) * 4;
+    f32x16 acc[NTL];
+
+    auto compute = [&](int stage) {
+        const float* sb = lds + stage * STAGE;
+        constexpr int HT = NTL / 2;                    // weight fragments are read half a slab at a time (register budget)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int sg = s == 0 ? seg0 : seg1;
+            const f32x4 af = *reinterpret_cast<const f32x4*>(sb + a_off + sg);
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                f32x4 wf[HT];
+#pragma unroll
+                for (int t = 0; t < HT; ++t) wf[t] = *reinterpret_cast<const f32x4*>(sb + w_off + (hb * HT + t) * 32 * BK + sg);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int t = 0; t < HT; ++t)
+                        acc[hb * HT + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[t][q], af[q], acc[hb * HT + t], 0, 0, 0);
+            }
+        }
+    };
+
+    // C layout of D^T: lane (i, h) holds output row (token) i of the wave's 32, columns 32 t + 8 g + 4 h + j in acc[t][4 g + j].
+    auto acc_init = [&](int tile, int par, int rid) {
+        int row0, col0;
+        tile_rc(tile, row0, col0);
+        float* const bs = Bs + (par ? BN : 0);
+        for (int c = tid; c < BN; c += 256) bs[c] = (p.bias && col0 + c < p.N) ? p.bias[col0 + c] : 0.f;
+        if constexpr (RES == 0) {
+#pragma unroll
+            for (int t = 0; t < NTL; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        } else {
+            const int row = row0 + 32 * wave + fi;
+            unsigned ro = OOB, po = OOB;
+            const __amdgpu_buffer_rsrc_t rs_rpe = make_rsrc(p.res_pe ? p.res_pe : p.w);
+            __amdgpu_buffer_rsrc_t rs_res;
+            if constexpr (RES == 1) {
+                if (p.res_mod > 0) {
+                    rs_res = make_rsrc(p.res);
+                    if (row < p.M) ro = (unsigned)(row % p.res_mod) * (unsigned)ldr4;
+                } else {
+                    rs_res = make_rsrc(p.res + (long)row0 * p.ldr);
+                    if (row < p.M) ro = (unsigned)(32 * wave + fi) * (unsigned)ldr4;
+                }
+            } else {
+                rs_res = make_rsrc(p.res);
+                if (row < p.M) {
+                    ro = (unsigned)rid * (unsigned)ldr4;
+                    if (p.res_pe) po = (unsigned)(row % p.res_period) * (unsigned)((int)p.ldr_pe * 4);
+                }
+            }
+            // Column validity is only tested in the last two 32-column tiles (the dispatcher guarantees N - col0 >= BN - 64):
+            // elsewhere the offset is `row offset + literal`, which hipcc cannot hoist out of the tile loop (40 hoisted
+            // offsets and 40 hoisted lane masks cost 100+ spilled registers).
+            const unsigned rof = ro == OOB ? OOB : ro + (unsigned)fh * 16u;
+            const unsigned pof = po == OOB ? OOB : po + (unsigned)fh * 16u;
+#pragma unroll
+            for (int t = 0; t < NTL; ++t) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cc = 32 * t + 8 * g;                 // + 4 fh
+                    unsigned o1 = rof + (unsigned)cc * 4u, o2 = pof + (unsigned)cc * 4u;
+                    if (t >= NTL - 2) {
+                        const bool ok = col0 + cc + 4 * fh < p.N;
+                        o1 = ok ? o1 : OOB;
+                        o2 = ok ? o2 : OOB;
+                    }
+                    f32x4 x = buf_load4(rs_res, o1, col0 * 4);
+                    if constexpr (RES == 2) x += buf_load4(rs_rpe, o2, col0 * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[t][4 * g + j] = x[j];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    auto epilogue = [&](int tile, int par) {
+        int row0, col0;
+        tile_rc(tile, row0, col0);
+        const float* const bs = Bs + (par ? BN : 0);
+        const int row = row0 + 32 * wave + fi;
+        const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(p.c + (long)row0 * p.ldc + col0);
+        const unsigned co = (row < p.M) ? (unsigned)(32 * wave + fi) * (unsigned)ldc4 : OOB;
+        float mean = 0.f, rstd = 0.f;
+        float sum = 0.f, sq = 0.f;
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(bs + 4 * fh + 32 * t + 8 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[t][4 * g + j] + b[j];
+                    if constexpr (RELU) v = fmaxf(v, 0.f);
+                    acc[t][4 * g + j] = v;
+                    if constexpr (LN) { sum += v; sq += v * v; }      // columns beyond N are exact zeros (zero weights, zero bias)
+                }
+            }
+        }
+        if constexpr (LN) {
+            sum += __shfl_xor(sum, 32);
+            sq += __shfl_xor(sq, 32);
+            const float inv_n = 1.0f / (float)p.N;
+            mean = sum * inv_n;
+            const float var = fmaxf(sq * inv_n - mean * mean, 0.f);
+            rstd = rsqrtf(var + p.ln_eps);
+        }
+        const unsigned cof = co == OOB ? OOB : co + (unsigned)fh * 16u;
+        const float* const gs = Gs + 4 * fh;
+        const float* const es = Es + 4 * fh;
+#pragma unroll
+        for (int t = 0; t < NTL; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cc = 32 * t + 8 * g;                     // + 4 fh
+                f32x4 y;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = acc[t][4 * g + j];
+                if constexpr (LN) {
+                    const f32x4 ga = *reinterpret_cast<const f32x4*>(gs + cc);
+                    const f32x4 be = *reinterpret_cast<const f32x4*>(es + cc);
+                    y = (y - mean) * rstd * ga + be;
+                }
+                unsigned o = cof + (unsigned)cc * 4u;
+                if (t >= NTL - 2) o = (col0 + cc + 4 * fh < p.N) ? o : OOB;
+                buf_store4(y, rs_c, o, 0);
+            }
+        }
+    };
+
+    // ---- main: tiles wg, wg + nwg, ... as one stream of chunks ---------------------------------------------------------
+    if constexpr (LN) {
+        for (int c = tid; c < BN; c += 256) {
+            Gs[c] = c < p.N ? p.ln_g[c] : 0.f;
+            Es[c] = c < p.N ? p.ln_b[c] : 0.f;
+        }
+    }
+    const int nchunk = (p.K + BK - 1) / BK;
+    int tile = wg;
+    if (tile >= ntiles) return;
+    prefetch_ids(tile);
+    int rid_cur = rid_next;
+    loader_set_tile(tile);
+    prefetch_ids(tile + nwg);
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    int stage = 0, par = 0;
+#ifdef LIME_STAMPS
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+    for (; tile < ntiles; tile += nwg, par ^= 1) {
+        const bool more = tile + nwg < ntiles;
+        acc_init(tile, par, rid_cur);
+        PSTAMP(0)                                     // 0: accumulator init (residual loads issued)
+        for (int c = 0; c + 1 < nchunk; ++c) {
+            issue(stage ^ 1, (c + 1) * BK);
+            PSTAMP(1)                                 // 1: DMA issue
+            compute(stage);
+            PSTAMP(2)                                 // 2: fragment reads + MFMA issue
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PSTAMP(3)                                 // 3: DMA landed
+            lds_barrier();
+            PSTAMP(4)                                 // 4: barrier
+            stage ^= 1;
+        }
+        // last chunk of the tile: the loader moves on to the next tile first
+        if (more) {
+            rid_cur = rid_next;
+            loader_set_tile(tile + nwg);
+            prefetch_ids(tile + 2 * nwg);
+            issue(stage ^ 1, 0);
+        }
+        PSTAMP(5)                                     // 5: loader switch
+        compute(stage);
+        PSTAMP(2)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PSTAMP(3)
+        lds_barrier();
+        PSTAMP(4)
+        stage ^= 1;
+        // the stores retire under the next tile's first chunk; the bias image this reads is double-buffered by tile parity
+        // (the next tile's acc_init rewrites the other half)
+        epilogue(tile, par);
+        PSTAMP(6)                                     // 6: epilogue
+    }
+#ifdef LIME_STAMPS
+    if (p.stamps && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p.stamps[((long)blockIdx.x * 4 + wave) * 8 + i] = tsum[i];
+    }
+#endif
+}
+
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+template <int NTL, bool LN, bool RELU, int RES>
+int launch(const PPParams& p0, hipStream_t stream) {
+    PPParams p = p0;
+    p.n_row_blocks = (p.M + BM - 1) / BM;
+    p.n_col_blocks = (p.N + NTL * 32 - 1) / (NTL * 32);
+    const long ntiles = (long)p.n_row_blocks * p.n_col_blocks;
+    long nwg = 2L * num_cus();
+    if (nwg > ntiles) nwg = ntiles;
+#ifdef LIME_STAMPS
+    p.stamps = g_pp_stamp_buf;
+#endif
+    hipLaunchKernelGGL((gemm_pp_kernel<NTL, LN, RELU, RES>), dim3((unsigned)nwg), dim3(256), 0, stream, p);
+    lime_set_last_linear_kernel("gemm_pp_kernel<%d, %s, %s, %d>", NTL, LN ? "true" : "false", RELU ? "true" : "false", RES);
+    return lime_check_launch("lime_linear_f32");
+}
+
+inline bool al16(const void* ptr, long ld) { return ptr == nullptr || (((uintptr_t)ptr % 16) == 0 && (ld % 4) == 0); }
+
+}  // namespace
+
+// LIME_OK / error: launched (or failed); LIME_PP_NOT_APPLICABLE: the caller takes the general kernel.
+int lime_linear_pp(const lime_linear_args* a, hipStream_t s) {
+    const bool has_res = a->res != nullptr, ln = a->ln_gamma != nullptr;
+    const bool relu = a->act == LIME_ACT_RELU;
+    if (a->M < 4096 || a->a_pe != nullptr) return LIME_PP_NOT_APPLICABLE;
+    if (!(a->act == LIME_ACT_NONE || (relu && !has_res))) return LIME_PP_NOT_APPLICABLE;
+    if (a->K % 4 || a->N % 4 || a->K < 2 * 16) return LIME_PP_NOT_APPLICABLE;      // >= 2 chunks: a barrier between the
+                                                                                     // bias image's write and its read
+    if (!al16(a->a, a->lda) || !al16(a->w, a->ldw) || !al16(a->c, a->ldc) || !al16(a->res, a->ldr) || !al16(a->res_pe, a->ldr_pe))
+        return LIME_PP_NOT_APPLICABLE;
+    if (a->bias && (uintptr_t)a->bias % 4) return LIME_PP_NOT_APPLICABLE;
+    // 32-bit byte offsets: within one 128-row block of a dense operand, within the whole of a gathered / periodic one
+    const long lim = 0x7FFFFFF0L;
+    if (128L * a->lda * 4 >= lim || (long)a->N * a->ldw * 4 >= lim || 128L * a->ldc * 4 >= lim || 128L * a->ldr * 4 >= lim)
+        return LIME_PP_NOT_APPLICABLE;
+    if ((long)a->M * 4 >= lim) return LIME_PP_NOT_APPLICABLE;
+    int res = 0;
+    if (has_res) {
+        if (a->res_ids) res = 2;
+        else if (a->res_div <= 1) res = 1;
+        else return LIME_PP_NOT_APPLICABLE;
+        if (res == 1 && a->res_mod > 0 && (long)a->res_mod * a->ldr * 4 >= lim) return LIME_PP_NOT_APPLICABLE;
+    }
+    if (ln && (a->N > 320 || relu)) return LIME_PP_NOT_APPLICABLE;
+    // column validity is tested in the last two 32-column tiles of a block only: the last block must not be narrower
+    auto tail_ok = [&](int bn) { const int last = a->N - (a->N - 1) / bn * bn; return last >= bn - 64; };
+
+    PPParams p;
+    p.a = a->a; p.lda = a->lda; p.a_ids = a->a_ids;
+    p.w = a->w; p.ldw = a->ldw; p.bias = a->bias;
+    p.res = a->res; p.ldr = a->ldr; p.res_mod = a->res_mod; p.res_ids = a->res_ids;
+    p.res_pe = a->res_pe; p.ldr_pe = a->ldr_pe; p.res_period = a->res_period > 0 ? a->res_period : 1;
+    p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps;
+    p.c = a->c; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K;
+    p.n_row_blocks = p.n_col_blocks = 0;
+    if (ln) {
+        if (!tail_ok(320)) return LIME_PP_NOT_APPLICABLE;
+        if (res == 0) return launch<10, true, false, 0>(p, s);
+        if (res == 1) return launch<10, true, false, 1>(p, s);
+        return launch<10, true, false, 2>(p, s);
+    }
+    if (res == 2) return LIME_PP_NOT_APPLICABLE;
+    // the tile width (256 / 320) that pads N least
+    const int pad5 = (a->N + 319) / 320 * 320 - a->N, pad4 = (a->N + 255) / 256 * 256 - a->N;
+    if (!tail_ok(pad5 < pad4 ? 320 : 256)) return LIME_PP_NOT_APPLICABLE;
+    if (pad5 < pad4) {
+        if (res == 1) return launch<10, false, false, 1>(p, s);
+        return relu ? launch<10, false, true, 0>(p, s) : launch<10, false, false, 0>(p, s);
+    }
+    if (res == 1) return launch<8, false, false, 1>(p, s);
+    return relu ? launch<8, false, true, 0>(p, s) : launch<8, false, false, 0>(p, s);
+}

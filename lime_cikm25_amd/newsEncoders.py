@@ -13,6 +13,7 @@ called.  All arithmetic runs in hand-written HIP kernels (lime_cikm25_amd.ops ->
   mean pool / intent tail / buckets   small fixed-order kernels
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -34,9 +35,14 @@ def _no_train_dropout(module, p):
 _SIDE = {}
 
 
+SERIAL_STREAMS = bool(int(os.environ.get('LIME_SERIAL_STREAMS', '0')))     # measurement aid: every branch on the caller's stream
+
+
 def _side_stream(device, which=0):
     """Side streams (per device) for branches that are independent of each other (fork / join with wait_stream,
     which is also how the fork is recorded into the HIP graph)."""
+    if SERIAL_STREAMS:
+        return torch.cuda.current_stream(device)
     key = (device.type, device.index, which)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
@@ -285,7 +291,10 @@ def encode_tokens(ids, table, pe, transformer, nhead):
         w_in = ops.pad_heads(sa.in_proj_weight, 3 * nhead, hd, hs) if hs != hd else sa.in_proj_weight
         b_in = ops.pad_heads(sa.in_proj_bias, 3 * nhead, hd, hs) if hs != hd else sa.in_proj_bias
         if li == 0:
-            qkv = ops.linear(table, w_in, b_in, a_ids=flat, a_pe=pe, a_period=S)
+            # (E[ids] + PE) W^T + b = E[ids] W^T + (PE W^T + b)[t]: the positional term is an [S, 3W] table added as a
+            # periodic residual, so the A operand is a pure row gather (which the LDS-DMA GEMM can stage directly)
+            pew = ops.linear(pe[:S], w_in, b_in)
+            qkv = ops.linear(table, w_in, None, a_ids=flat, res=pew, res_mod=S)
         else:
             qkv = ops.linear(x, w_in, b_in)
         attn = ops.token_attention(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, 1.0 / math.sqrt(hd),

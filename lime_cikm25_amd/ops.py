@@ -23,30 +23,6 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _linear_variant(M, N, K, ln, a, w, a_pe):
-    """Which gemm_f32_kernel instantiation lime_linear_f32 dispatches to (mirrors csrc/gemm_f32.hip)."""
-    vec = 4
-    def ok(t, v):
-        return t is None or (t.data_ptr() % (4 * v) == 0 and _ld(t) % v == 0)
-    while vec > 1 and not (K % vec == 0 and ok(a, vec) and ok(w, vec) and ok(a_pe, vec)):
-        vec //= 2
-    return vec
-
-
-def linear_kernel_name(M, N, K, act, ln, vec, pe, vio, has_res):
-    """The gemm_f32_kernel<TM, TN, WM, WN, VEC, LN, PE, ACT, GENERIC, VIO> instantiation lime_linear_f32 dispatches to
-    (mirrors the tile selection at the end of csrc/gemm_f32.hip; used by bench.py to label its per-kernel timings)."""
-    t = lambda b: 'true' if b else 'false'
-    if ln:
-        tn = 4 if N <= 256 else 5
-        return 'gemm_f32_kernel<1, %d, 4, 2, %d, true, false, 0, false, %s>' % (tn, 4 if vio else 1, t(vio))
-    if M >= 4096 and not has_res and act in (None, 'none', 'relu') and vio:
-        pad5, pad4 = (N + 319) // 320 * 320 - N, (N + 255) // 256 * 256 - N
-        tn = 5 if pad5 < pad4 else 4
-        return 'gemm_f32_kernel<1, %d, 4, 2, 4, false, %s, %d, false, true>' % (tn, t(pe), 1 if act == 'relu' else 0)
-    return 'gemm_f32_kernel<1, 1, 2, 2, %d, false, %s, 0, true, false>' % (vec, t(pe))
-
-
 def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -85,7 +61,7 @@ def _mask_u8(mask, name):
 
 
 def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=0, res=None, res_div=1, res_ids=None,
-           res_pe=None, res_period=0, ln=None, ln_eps=1e-5):
+           res_pe=None, res_period=0, ln=None, ln_eps=1e-5, res_mod=0):
     """C = epilogue(A . W^T + bias) -- see ``lime_linear_f32`` in include/lime_hip.h.
 
     a: [M, K] (or the [V, K] table when a_ids is given, M = len(a_ids)); w: [N, K]; out: [M, N] (may be a view).
@@ -130,6 +106,10 @@ def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=
                 if res_pe.shape[1] != N or res_pe.shape[0] < res_period or res_period <= 0:
                     raise ValueError('res_pe must be [>=res_period, N]')
                 args.res_pe, args.ldr_pe, args.res_period = res_pe.data_ptr(), _ld(res_pe), res_period
+        elif res_mod > 0:
+            if res.shape[0] < res_mod:
+                raise ValueError('res has %d rows, res_mod is %d' % (res.shape[0], res_mod))
+            args.res_mod = res_mod
         elif res.shape[0] * res_div < M:
             raise ValueError('res has %d rows, needs >= %d' % (res.shape[0], (M + res_div - 1) // res_div))
     if ln is not None:
@@ -144,11 +124,7 @@ def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=
         e0.record()
         check(lib.lime_linear_f32(ctypes.byref(args), _stream()), 'lime_linear_f32')
         e1.record()
-        vec = _linear_variant(M, N, K, ln is not None, a, w, a_pe)
-        al4 = lambda t: t is None or (t.data_ptr() % 16 == 0 and _ld(t) % 4 == 0)
-        vio = vec == 4 and N % 4 == 0 and al4(out) and al4(res) and al4(res_pe)
-        PROFILE.append((linear_kernel_name(M, N, K, act, ln is not None, vec, a_pe is not None, vio, res is not None),
-                        M, N, K, e0, e1))
+        PROFILE.append((lib.lime_last_linear_kernel().decode(), M, N, K, e0, e1))
         return out
     check(lib.lime_linear_f32(ctypes.byref(args), _stream()), 'lime_linear_f32')
     return out

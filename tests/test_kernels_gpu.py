@@ -124,6 +124,105 @@ def test_linear_gated_residual_layernorm(ops):
     check(got, want, what='gate')
 
 
+# ---- the two-workgroups-per-CU LDS-DMA kernel (gemm_pp_f32.hip): M >= 4096, 16-byte friendly operands -----------------
+def last_kernel():
+    from lime_cikm25_amd import _lib
+    return _lib.load().lime_last_linear_kernel().decode()
+
+
+@pytest.mark.parametrize('M,N,K', [(4096, 512, 300), (4100, 300, 300), (5003, 960, 300), (4097, 256, 512), (6000, 320, 32),
+                                   (4300, 900, 304), (4200, 576, 44), (70000, 512, 300), (4128, 640, 1000)])
+@pytest.mark.parametrize('act', [None, 'relu'])
+def test_linear_pp_plain(ops, M, N, K, act):
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3)
+    want = a @ w.t() + b
+    if act == 'relu':
+        want = torch.relu(want)
+    got = ops.linear(dev(a), dev(w), dev(b), act=act)
+    assert last_kernel().startswith('gemm_pp_kernel'), last_kernel()
+    check(got, want, what='pp linear %s' % ((M, N, K, act),))
+    got2 = ops.linear(dev(a), dev(w), None, act=act)             # no bias
+    check(got2, torch.relu(a @ w.t()) if act == 'relu' else a @ w.t(), what='pp linear, no bias')
+
+
+@pytest.mark.parametrize('M,N,K', [(4096, 300, 300), (5001, 300, 512), (4500, 320, 64), (4100, 288, 300), (9000, 260, 100)])
+def test_linear_pp_residual_layernorm(ops, M, N, K):
+    a, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3), rnd(M, N, seed=4)
+    g, be = rnd(N, seed=5) + 1.5, rnd(N, seed=6)
+    got = ops.linear(dev(a), dev(w), dev(b), res=dev(r), ln=(dev(g), dev(be)))
+    assert last_kernel() == 'gemm_pp_kernel<10, true, false, 1>', last_kernel()
+    check(got, O.layer_norm(r + a @ w.t() + b, g, be), what='pp res + LN')
+    got = ops.linear(dev(a), dev(w), dev(b), ln=(dev(g), dev(be)))
+    assert last_kernel() == 'gemm_pp_kernel<10, true, false, 0>', last_kernel()
+    check(got, O.layer_norm(a @ w.t() + b, g, be), what='pp LN')
+    got = ops.linear(dev(a), dev(w), dev(b), res=dev(r))
+    assert last_kernel().startswith('gemm_pp_kernel'), last_kernel()
+    check(got, r + a @ w.t() + b, what='pp res')
+
+
+@pytest.mark.parametrize('M,S,N', [(4224, 32, 960), (4200, 128, 960), (4099, 100, 300), (8192, 128, 512)])
+def test_linear_pp_gather_and_periodic_residual(ops, M, S, N):
+    """in_proj as the encoder issues it: A = table rows by id, the positional term as a periodic [S, N] residual."""
+    V, E = 700, 300
+    ids = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(6), dtype=torch.int32)
+    table, pe = rnd(V, E, seed=7), rnd(S, E, seed=8)
+    w, b = rnd(N, E, seed=9, scale=0.06), rnd(N, seed=10)
+    x = table[ids.long()] + pe[torch.arange(M) % S]
+    pew = ops.linear(dev(pe), dev(w), dev(b))
+    got = ops.linear(dev(table), dev(w), None, a_ids=dev(ids), res=pew, res_mod=S)
+    assert last_kernel().startswith('gemm_pp_kernel'), last_kernel()
+    check(got, x @ w.t() + b, what='pp gather A + periodic residual')
+    got = ops.linear(dev(table), dev(w), dev(b), a_ids=dev(ids), act='relu')
+    check(got, torch.relu(table[ids.long()] @ w.t() + b), what='pp gather A')
+
+
+@pytest.mark.parametrize('M,S', [(4224, 32), (4200, 128), (5000, 7)])
+def test_linear_pp_gathered_residual_layernorm(ops, M, S):
+    """out_proj: residual = table[ids] + pe[t] rebuilt in the accumulators, LayerNorm epilogue."""
+    V, E, N = 500, 300, 300
+    ids = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(6), dtype=torch.int32)
+    table, pe = rnd(V, E, seed=7), rnd(S, E, seed=8)
+    w, b = rnd(N, E, seed=9, scale=0.06), rnd(N, seed=10)
+    x = table[ids.long()] + pe[torch.arange(M) % S]
+    attn = rnd(M, E, seed=11)
+    g, be = rnd(N, seed=12) + 1.5, rnd(N, seed=13)
+    got = ops.linear(dev(attn), dev(w), dev(b), res=dev(table), res_ids=dev(ids), res_pe=dev(pe), res_period=S,
+                     ln=(dev(g), dev(be)))
+    assert last_kernel() == 'gemm_pp_kernel<10, true, false, 2>', last_kernel()
+    check(got, O.layer_norm(x + attn @ w.t() + b, g, be), what='pp gather residual + LN')
+
+
+def test_linear_pp_strided_views_and_untouched_padding(ops):
+    M, N, K = 4500, 300, 300
+    big_a, big_w, big_c = rnd(M, K + 40, seed=4), rnd(N, K + 8, seed=5), torch.full((M, N + 100), 7.0)
+    a, w = big_a[:, 8:8 + K], big_w[:, 4:4 + K]
+    ca, cw, cc = dev(big_a), dev(big_w), dev(big_c)
+    ops.linear(ca[:, 8:8 + K], cw[:, 4:4 + K], None, out=cc[:, 60:60 + N])
+    assert last_kernel().startswith('gemm_pp_kernel'), last_kernel()
+    out = cc.cpu()
+    check(out[:, 60:60 + N], a @ w.t(), what='pp strided')
+    assert (out[:, :60] == 7).all() and (out[:, 60 + N:] == 7).all()
+
+
+@pytest.mark.parametrize('M,S', [(300, 16), (4100, 32)])
+def test_linear_periodic_residual_small_and_misaligned(ops, M, S):
+    """res_mod on the general kernel (small M, and K not a multiple of 4)."""
+    N, K = 130, 50
+    a, w, t = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(S, N, seed=3)
+    got = ops.linear(dev(a), dev(w), None, res=dev(t), res_mod=S)
+    check(got, a @ w.t() + t[torch.arange(M) % S], what='res_mod')
+    assert last_kernel().startswith('gemm_f32_kernel'), last_kernel()
+
+
+def test_linear_pp_is_deterministic(ops):
+    M, N, K = 20000, 300, 300
+    a, w, b, r = dev(rnd(M, K, seed=1)), dev(rnd(N, K, seed=2, scale=0.05)), dev(rnd(N, seed=3)), dev(rnd(M, N, seed=4))
+    g, be = dev(rnd(N, seed=5) + 1.5), dev(rnd(N, seed=6))
+    first = ops.linear(a, w, b, res=r, ln=(g, be)).clone()
+    for _ in range(5):
+        assert torch.equal(ops.linear(a, w, b, res=r, ln=(g, be)), first)
+
+
 def test_linear_rejects_bad_shapes(ops):
     from lime_cikm25_amd._lib import LimeHipError
     a, w = dev(rnd(8, 16)), dev(rnd(4, 16))

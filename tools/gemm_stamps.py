@@ -14,12 +14,13 @@ from lime_cikm25_amd import _lib, ops  # noqa: E402
 
 SO = os.path.join(ROOT, 'tools', 'probes', 'liblime_stamps.so')
 SEG = ['acc_init', 'issue', 'mfma', 'commit', 'barrier', 'switch+tail', 'epilogue', 'next commit+barrier']
+SEG_PP = ['acc_init', 'dma issue', 'reads+mfma', 'dma wait', 'barrier', 'switch', 'epilogue', '-']
 
 
 def build():
     src = os.path.join(ROOT, 'lime_cikm25_amd', 'csrc')
     subprocess.run(['hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', '-DLIME_STAMPS', '-o', SO,
-                    os.path.join(src, 'gemm_f32.hip'), os.path.join(src, 'common.cpp')], check=True)
+                    os.path.join(src, 'gemm_f32.hip'), os.path.join(src, 'gemm_pp_f32.hip'), os.path.join(src, 'common.cpp')], check=True)
 
 
 def main():
@@ -31,10 +32,13 @@ def main():
     lib.lime_linear_f32.argtypes = [ctypes.POINTER(_lib.LinearArgs), ctypes.c_void_p]
     lib.lime_last_error_string.restype = ctypes.c_char_p
     lib.lime_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
+    lib.lime_debug_set_pp_stamp_buffer.argtypes = [ctypes.c_void_p]
+    lib.lime_last_linear_kernel.restype = ctypes.c_char_p
 
     class Shim:
         lime_linear_f32 = lib.lime_linear_f32
         lime_last_error_string = lib.lime_last_error_string
+        lime_last_linear_kernel = lib.lime_last_linear_kernel
     _lib._lib = Shim
     dev = 'cuda'
     g = torch.Generator().manual_seed(0)
@@ -44,25 +48,35 @@ def main():
     ids = torch.randint(0, V, (tok,), generator=g, dtype=torch.int32).to(dev)
     x, h = rnd(tok, E), rnd(tok, F)
     ln = (rnd(E) + 1, rnd(E))
+    pew = rnd(S, 960)
     cases = {
-        'qkv_body': lambda: ops.linear(table, rnd(3 * E, E), rnd(3 * E), a_ids=ids, a_pe=pe, a_period=S),
+        'qkv_body': lambda: ops.linear(table, rnd(960, E), None, a_ids=ids, res=pew, res_mod=S),
         'ffn1_body': lambda: ops.linear(x, rnd(F, E), rnd(F), act='relu'),
         'ffn2_body': lambda: ops.linear(h, rnd(E, F), rnd(E), res=x, ln=ln),
         'out_body': lambda: ops.linear(x, rnd(E, E), rnd(E), res=table, res_ids=ids, res_pe=pe, res_period=S, ln=ln),
     }
     for name, fn in cases.items():
-        buf = torch.zeros(256 * 8 * 8, dtype=torch.int64, device=dev)
+        buf = torch.zeros(512 * 8 * 8, dtype=torch.int64, device=dev)
         lib.lime_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+        lib.lime_debug_set_pp_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
         fn()
         torch.cuda.synchronize()
         buf.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         fn()
+        e1.record()
         torch.cuda.synchronize()
-        t = buf.view(256, 8, 8).double()
-        tot = t.sum(dim=2)
-        share = t.sum(dim=(0, 1)) / tot.sum()
-        print('%-10s wave total %.0f cycles  ' % (name, tot.mean().item()) + '  '.join('%s %.1f%%' % (s, 100 * v) for s, v in zip(SEG, share.tolist())))
+        us = e0.elapsed_time(e1) * 1e3
+        kern = lib.lime_last_linear_kernel().decode()
+        t = buf.view(-1, 8).double()
+        t = t[t.sum(dim=1) > 0]
+        share = t.sum(dim=0) / t.sum()
+        seg = SEG_PP if kern.startswith('gemm_pp') else SEG
+        print('%-10s %s  waves %d  wave total %.0f s_memtime ticks  ' % (name, kern, t.shape[0], t.sum(dim=1).mean().item()) +
+              '  '.join('%s %.1f%%' % (s, 100 * v) for s, v in zip(seg, share.tolist())))
     lib.lime_debug_set_stamp_buffer(None)
+    lib.lime_debug_set_pp_stamp_buffer(None)
 
 
 if __name__ == '__main__':

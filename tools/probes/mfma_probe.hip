@@ -70,6 +70,31 @@ __global__ __launch_bounds__(256) void k_lds32(float* out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// V3: sustained-clock probe.  Operands are 8 random values per lane in [-1, 1) (data-dependent switching power), four
+// independent accumulators, s_memtime around the loop: cycles / wall time = the shader clock the chip actually holds under
+// fp32 MFMA load, which is what the 157.3 TFLOP/s figure (2.4 GHz) has to be scaled by.
+__global__ __launch_bounds__(256) void k_rand32(float* out, unsigned long long* cyc, const float* rnd, int iters, int zero) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float a[8], b[8];
+    for (int u = 0; u < 8; ++u) {
+        a[u] = zero ? 0.f : rnd[(threadIdx.x * 16 + u) & 4095];
+        b[u] = zero ? 0.f : rnd[(threadIdx.x * 16 + 8 + u) & 4095];
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[(u + i) & 7], acc[i], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
 template <typename F>
 double time_it(F launch, int reps) {
     hipEvent_t e0, e1;
@@ -85,6 +110,24 @@ double time_it(F launch, int reps) {
 int main() {
     float* out; hipMalloc(&out, 4096 * 256 * 4);
     const int iters = 2000;
+    {
+        float h[4096];
+        unsigned x = 12345;
+        for (int i = 0; i < 4096; ++i) { x = x * 1664525u + 1013904223u; h[i] = (float)(x >> 8) / 8388608.0f - 1.0f; }
+        float* rnd; hipMalloc(&rnd, sizeof(h)); hipMemcpy(rnd, h, sizeof(h), hipMemcpyHostToDevice);
+        unsigned long long* cyc; hipMalloc(&cyc, 1024 * 8);
+        for (int zero = 1; zero >= 0; --zero) {
+            for (int reps : {5, 400}) {                 // a burst, then ~0.5 s of back-to-back launches
+                const int blocks = 1024, it2 = 1000;
+                double t = time_it([&] { hipLaunchKernelGGL(k_rand32, dim3(blocks), dim3(256), 0, 0, out, cyc, rnd, it2, zero); }, reps);
+                unsigned long long hc[1024]; hipMemcpy(hc, cyc, sizeof(hc), hipMemcpyDeviceToHost);
+                double mean = 0; for (int i = 0; i < blocks; ++i) mean += hc[i]; mean /= blocks;
+                // per wave: it2 * 32 MFMAs of 64 cycles when the pipe is never idle; 4 waves per SIMD take turns
+                printf("rand32 %s reps=%3d: %.2f TF   %.0f s_memtime cycles per wave loop, %.1f us per launch\n", zero ? "zeros " : "random", reps,
+                       (double)blocks * 4 * it2 * 32 * 4096 / t / 1e12, mean, t * 1e6);
+            }
+        }
+    }
     for (int blocks : {256, 512, 1024}) {
         double t;
         t = time_it([&] { hipLaunchKernelGGL((k_pure32<1>), dim3(blocks), dim3(256), 0, 0, out, iters, 1.f, 2.f); }, 5);
