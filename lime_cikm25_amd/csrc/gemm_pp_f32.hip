@@ -18,9 +18,14 @@
 //     [row][16 floats] with the 16-byte segment index XOR-swizzled by (row >> 2) & 3 -- applied to the per-lane SOURCE
 //     address when staging and to the ds_read_b128 address when reading fragments (conflict free: the 16 lanes of a
 //     read phase cover all 16 bank groups).
-//   * a wave owns 32 output rows x all tile columns of the transposed product D^T = W A^T: an output row is a lane (two
-//     lanes, one per half-wave), its columns are that lane's registers -- residual loads / result stores are 16-byte
-//     accesses, and LayerNorm needs no cross-wave exchange at all (in-lane sums + one cross-half shuffle).
+//   * the MFMA is v_mfma_f32_16x16x4_f32, not 32x32x2: same nominal rate, same LDS traffic per flop here, but half the
+//     accumulator-register traffic per flop -- and the fp32 matrix rate of this chip is POWER limited on real data:
+//     tools/probes/mfma_probe (registers only, random operands, sustained) holds 122 TFLOP/s with 32x32x2 against 154
+//     with 16x16x4 (both 155 on zeros).
+//   * a wave owns 32 output rows x all tile columns of the transposed product D^T = W A^T: an output row lives in the
+//     four lanes (i, i + 16, i + 32, i + 48), each holding 4 of every 16 columns as consecutive registers -- residual
+//     loads / result stores are 16-byte accesses, and LayerNorm needs no cross-wave exchange at all (in-lane sums +
+//     two shuffles).
 //   * k beyond K, rows beyond M and weight rows beyond N are out-of-range buffer offsets: the DMA writes zeros.
 #include "common.h"
 #include "gemm_pp.h"
@@ -85,10 +90,19 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fi = lane & 31, fh = lane >> 5;
-    const int nwg = gridDim.x;
-    const int wg = xcd_remap(blockIdx.x, nwg);
+    const int fi = lane & 15, kg = lane >> 4;          // MFMA 16x16x4: lane (i, kg) supplies row i, k slot kg
     const int ntiles = p.n_row_blocks * p.n_col_blocks;
+    // Tile -> workgroup assignment.  Workgroups go to the 8 XCDs round-robin by blockIdx, and (measured,
+    // tools/probes/wg_map_probe) blockIdx b and b + 256 of a 512-workgroup launch share a CU.  Each XCD walks ONE contiguous
+    // range of tiles (neighbouring row panels share its L2); inside the range tiles are dealt round-robin to the XCD's
+    // workgroups in blockIdx order, so the workgroups that get one tile more than the rest are the first ones -- first
+    // residency slots, one per CU.  (A plain `tile = remapped id + k * grid` puts every such extra tile on the first XCDs:
+    // 8 tiles on some CUs, 6 on others, 14 % of the launch spent waiting for them.)
+    const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;                  // this workgroup's XCD and its index there
+    const int nw_x = ((int)gridDim.x - xcd + 7) >> 3;                        // workgroups on this XCD
+    const int qt = ntiles >> 3, rt = ntiles & 7;
+    const int tbase = xcd * qt + (xcd < rt ? xcd : rt);                     // first tile of this XCD's range
+    const int tcount = qt + (xcd < rt ? 1 : 0);                             // tiles in the range
 
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w);
     const bool gather_a = p.a_ids != nullptr;
@@ -101,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
     const int lseg = (lane & 3) ^ ((lane >> 4) & 3);
     unsigned a_voff[2], w_voff[NWI];
     int aid_next[2];                                   // gathered row ids of the NEXT tile (loaded a tile ahead)
-    int rid_next = 0;                                  // RES == 2: residual row id of this lane's output row, next tile
+    int rid_next[2] = {0, 0};                          // RES == 2: residual row ids of this lane's two output rows, next tile
     __amdgpu_buffer_rsrc_t rs_a = make_rsrc(p.a);
 
     auto tile_rc = [&](int tile, int& row0, int& col0) {
@@ -112,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
     auto prefetch_ids = [&](int tile) {                // ids of `tile` -> registers (any tile index: out of range reads 0)
         int row0, col0;
         tile_rc(tile, row0, col0);
-        const bool live = tile < ntiles;
+        const bool live = tile >= 0;
         const __amdgpu_buffer_rsrc_t rs_aids = make_rsrc(p.a_ids ? (const void*)p.a_ids : (const void*)p.w);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -120,9 +134,12 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
             aid_next[j] = buf_load_i32(rs_aids, (gather_a && live && row < p.M) ? (unsigned)row * 4u : OOB);
         }
         if constexpr (RES == 2) {
-            const int row = row0 + 32 * wave + fi;
             const __amdgpu_buffer_rsrc_t rs_rids = make_rsrc(p.res_ids ? (const void*)p.res_ids : (const void*)p.w);
-            rid_next = buf_load_i32(rs_rids, (live && row < p.M) ? (unsigned)row * 4u : OOB);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int row = row0 + 32 * wave + 16 * tt + fi;
+                rid_next[tt] = buf_load_i32(rs_rids, (live && row < p.M) ? (unsigned)row * 4u : OOB);
+            }
         }
     };
     auto loader_set_tile = [&](int tile) {             // consumes aid_next
@@ -143,6 +160,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
         }
     };
     auto issue = [&](int stage, int k0) {              // DMA of chunk k0 .. k0 + 15 into `stage`
+#if defined(LIME_PP_ABLATE) && LIME_PP_ABLATE == 2       // tools/pp_ablate.py: no operand traffic (results are garbage)
+        return;
+#endif
         const bool kin = k0 + lseg * 4 < p.K;          // K % 4 == 0: a segment is valid or not as a whole
         float* const sb = lds + stage * STAGE;
 #pragma unroll
@@ -154,86 +174,90 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
     };
 
     // ---- compute state ---------------------------------------------------------------------------------------------
-    // fragment of k-step s (k = 8 s + 4 h .. + 3 of the chunk): logical segment 2 s + h of row i
-    const int sw = (fi >> 2) & 3;
-    const int a_off = (32 * wave + fi) * BK, w_off = A_ST + fi * BK;
-    const int seg0 = ((0 + fh) ^ sw) * 4, seg1 = ((2 + fh) ^ sw) * 4;
-    f32x16 acc[NTL];
+    // v_mfma_f32_16x16x4_f32: lane (i, kg) supplies A[i][k = kg] and B[k = kg][j = i]; the MFMA's k index is only a
+    // summation label, so a lane reads ONE b128 = k 4 kg .. 4 kg + 3 of its row (logical segment kg) per operand tile and
+    // chunk, and the four MFMAs q = 0..3 of a tile pair element q of both fragments: together they cover the chunk's 16 k.
+    constexpr int NT16 = 2 * NTL;                                  // 16-column tiles per wave
+    constexpr int GRP = NT16 / 4;                                  // weight fragments are read a quarter slab at a time
+    const int pseg = (kg ^ ((fi >> 2) & 3)) * 4;
+    const int a_off = (32 * wave + fi) * BK + pseg, w_off = A_ST + fi * BK + pseg;
+    f32x4 acc[2][NT16];
 
     auto compute = [&](int stage) {
+#if defined(LIME_PP_ABLATE) && LIME_PP_ABLATE == 1       // tools/pp_ablate.py: no fragment reads, no MFMAs
+        return;
+#endif
         const float* sb = lds + stage * STAGE;
-        constexpr int HT = NTL / 2;                    // weight fragments are read half a slab at a time (register budget)
+        f32x4 af[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int sg = s == 0 ? seg0 : seg1;
-            const f32x4 af = *reinterpret_cast<const f32x4*>(sb + a_off + sg);
+        for (int tt = 0; tt < 2; ++tt) af[tt] = *reinterpret_cast<const f32x4*>(sb + a_off + tt * 16 * BK);
 #pragma unroll
-            for (int hb = 0; hb < 2; ++hb) {
-                f32x4 wf[HT];
+        for (int gb = 0; gb < 4; ++gb) {
+            f32x4 wf[GRP];
 #pragma unroll
-                for (int t = 0; t < HT; ++t) wf[t] = *reinterpret_cast<const f32x4*>(sb + w_off + (hb * HT + t) * 32 * BK + sg);
+            for (int t = 0; t < GRP; ++t) wf[t] = *reinterpret_cast<const f32x4*>(sb + w_off + (gb * GRP + t) * 16 * BK);
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int t = 0; t < HT; ++t)
-                        acc[hb * HT + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[t][q], af[q], acc[hb * HT + t], 0, 0, 0);
-            }
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int t = 0; t < GRP; ++t)
+                        acc[tt][gb * GRP + t] =
+                            __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][q], af[tt][q], acc[tt][gb * GRP + t], 0, 0, 0);
         }
     };
 
-    // C layout of D^T: lane (i, h) holds output row (token) i of the wave's 32, columns 32 t + 8 g + 4 h + j in acc[t][4 g + j].
-    auto acc_init = [&](int tile, int par, int rid) {
+    // C layout of D^T (16x16 tile): lane (i, kg) holds output row (token) 16 tt + i of the wave's 32, columns
+    // 16 t + 4 kg + r in acc[tt][t][r].
+    auto acc_init = [&](int tile, int par, const int* rid) {
         int row0, col0;
         tile_rc(tile, row0, col0);
         float* const bs = Bs + (par ? BN : 0);
         for (int c = tid; c < BN; c += 256) bs[c] = (p.bias && col0 + c < p.N) ? p.bias[col0 + c] : 0.f;
         if constexpr (RES == 0) {
 #pragma unroll
-            for (int t = 0; t < NTL; ++t)
+            for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+                for (int t = 0; t < NT16; ++t) acc[tt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
-            const int row = row0 + 32 * wave + fi;
-            unsigned ro = OOB, po = OOB;
             const __amdgpu_buffer_rsrc_t rs_rpe = make_rsrc(p.res_pe ? p.res_pe : p.w);
             __amdgpu_buffer_rsrc_t rs_res;
-            if constexpr (RES == 1) {
-                if (p.res_mod > 0) {
-                    rs_res = make_rsrc(p.res);
-                    if (row < p.M) ro = (unsigned)(row % p.res_mod) * (unsigned)ldr4;
-                } else {
-                    rs_res = make_rsrc(p.res + (long)row0 * p.ldr);
-                    if (row < p.M) ro = (unsigned)(32 * wave + fi) * (unsigned)ldr4;
-                }
-            } else {
-                rs_res = make_rsrc(p.res);
+            if (RES == 1 && p.res_mod <= 0) rs_res = make_rsrc(p.res + (long)row0 * p.ldr);
+            else rs_res = make_rsrc(p.res);
+            // Column validity is only tested in the last 64 columns (the dispatcher guarantees N - col0 >= BN - 64):
+            // elsewhere the offset is `row offset + literal`, which hipcc cannot hoist out of the tile loop (hoisted
+            // offsets and lane masks cost 100+ spilled registers).
+            unsigned rof[2], pof[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int rl = 32 * wave + 16 * tt + fi, row = row0 + rl;
+                unsigned ro = OOB, po = OOB;
                 if (row < p.M) {
-                    ro = (unsigned)rid * (unsigned)ldr4;
-                    if (p.res_pe) po = (unsigned)(row % p.res_period) * (unsigned)((int)p.ldr_pe * 4);
+                    if constexpr (RES == 1) {
+                        ro = (p.res_mod > 0 ? (unsigned)(row % p.res_mod) : (unsigned)rl) * (unsigned)ldr4;
+                    } else {
+                        ro = (unsigned)rid[tt] * (unsigned)ldr4;
+                        if (p.res_pe) po = (unsigned)(row % p.res_period) * (unsigned)((int)p.ldr_pe * 4);
+                    }
                 }
+                rof[tt] = ro == OOB ? OOB : ro + (unsigned)kg * 16u;
+                pof[tt] = po == OOB ? OOB : po + (unsigned)kg * 16u;
             }
-            // Column validity is only tested in the last two 32-column tiles (the dispatcher guarantees N - col0 >= BN - 64):
-            // elsewhere the offset is `row offset + literal`, which hipcc cannot hoist out of the tile loop (40 hoisted
-            // offsets and 40 hoisted lane masks cost 100+ spilled registers).
-            const unsigned rof = ro == OOB ? OOB : ro + (unsigned)fh * 16u;
-            const unsigned pof = po == OOB ? OOB : po + (unsigned)fh * 16u;
 #pragma unroll
-            for (int t = 0; t < NTL; ++t) {
+            for (int t = 0; t < NT16; ++t) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int cc = 32 * t + 8 * g;                 // + 4 fh
-                    unsigned o1 = rof + (unsigned)cc * 4u, o2 = pof + (unsigned)cc * 4u;
-                    if (t >= NTL - 2) {
-                        const bool ok = col0 + cc + 4 * fh < p.N;
+                for (int tt = 0; tt < 2; ++tt) {
+                    unsigned o1 = rof[tt] + (unsigned)t * 64u, o2 = pof[tt] + (unsigned)t * 64u;
+                    if (t >= NT16 - 4) {
+                        const bool ok = col0 + 16 * t + 4 * kg < p.N;
                         o1 = ok ? o1 : OOB;
                         o2 = ok ? o2 : OOB;
                     }
                     f32x4 x = buf_load4(rs_res, o1, col0 * 4);
                     if constexpr (RES == 2) x += buf_load4(rs_rpe, o2, col0 * 4);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[t][4 * g + j] = x[j];
+                    acc[tt][t] = x;
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if ((t & 1) == 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -241,52 +265,59 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
     auto epilogue = [&](int tile, int par) {
         int row0, col0;
         tile_rc(tile, row0, col0);
-        const float* const bs = Bs + (par ? BN : 0);
-        const int row = row0 + 32 * wave + fi;
+        const float* const bs = Bs + (par ? BN : 0) + 4 * kg;
         const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(p.c + (long)row0 * p.ldc + col0);
-        const unsigned co = (row < p.M) ? (unsigned)(32 * wave + fi) * (unsigned)ldc4 : OOB;
-        float mean = 0.f, rstd = 0.f;
-        float sum = 0.f, sq = 0.f;
+        float sum[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < NTL; ++t) {
+        for (int t = 0; t < NT16; ++t) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bs + 16 * t);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(bs + 4 * fh + 32 * t + 8 * g);
+            for (int tt = 0; tt < 2; ++tt) {
+                f32x4 v = acc[tt][t] + b;
+                if constexpr (RELU) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = acc[t][4 * g + j] + b[j];
-                    if constexpr (RELU) v = fmaxf(v, 0.f);
-                    acc[t][4 * g + j] = v;
-                    if constexpr (LN) { sum += v; sq += v * v; }      // columns beyond N are exact zeros (zero weights, zero bias)
+                    for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+                acc[tt][t] = v;
+                if constexpr (LN) {                    // columns beyond N are exact zeros (zero weights, zero bias)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { sum[tt] += v[j]; sq[tt] += v[j] * v[j]; }
                 }
             }
         }
+        float mean[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f};
         if constexpr (LN) {
-            sum += __shfl_xor(sum, 32);
-            sq += __shfl_xor(sq, 32);
             const float inv_n = 1.0f / (float)p.N;
-            mean = sum * inv_n;
-            const float var = fmaxf(sq * inv_n - mean * mean, 0.f);
-            rstd = rsqrtf(var + p.ln_eps);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                float s1 = sum[tt], s2 = sq[tt];
+                s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                mean[tt] = s1 * inv_n;
+                rstd[tt] = rsqrtf(fmaxf(s2 * inv_n - mean[tt] * mean[tt], 0.f) + p.ln_eps);
+            }
         }
-        const unsigned cof = co == OOB ? OOB : co + (unsigned)fh * 16u;
-        const float* const gs = Gs + 4 * fh;
-        const float* const es = Es + 4 * fh;
+        unsigned cof[2];
 #pragma unroll
-        for (int t = 0; t < NTL; ++t) {
+        for (int tt = 0; tt < 2; ++tt) {
+            const int rl = 32 * wave + 16 * tt + fi;
+            cof[tt] = (row0 + rl < p.M) ? (unsigned)rl * (unsigned)ldc4 + (unsigned)kg * 16u : OOB;
+        }
+        const float* const gs = Gs + 4 * kg;
+        const float* const es = Es + 4 * kg;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int cc = 32 * t + 8 * g;                     // + 4 fh
-                f32x4 y;
+        for (int t = 0; t < NT16; ++t) {
+            f32x4 ga, be;
+            if constexpr (LN) {
+                ga = *reinterpret_cast<const f32x4*>(gs + 16 * t);
+                be = *reinterpret_cast<const f32x4*>(es + 16 * t);
+            }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) y[j] = acc[t][4 * g + j];
-                if constexpr (LN) {
-                    const f32x4 ga = *reinterpret_cast<const f32x4*>(gs + cc);
-                    const f32x4 be = *reinterpret_cast<const f32x4*>(es + cc);
-                    y = (y - mean) * rstd * ga + be;
-                }
-                unsigned o = cof + (unsigned)cc * 4u;
-                if (t >= NTL - 2) o = (col0 + cc + 4 * fh < p.N) ? o : OOB;
+            for (int tt = 0; tt < 2; ++tt) {
+                f32x4 y = acc[tt][t];
+                if constexpr (LN) y = (y - mean[tt]) * rstd[tt] * ga + be;
+                unsigned o = cof[tt] + (unsigned)t * 64u;
+                if (t >= NT16 - 4) o = (col0 + 16 * t + 4 * kg < p.N) ? o : OOB;
                 buf_store4(y, rs_c, o, 0);
             }
         }
@@ -300,12 +331,14 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
         }
     }
     const int nchunk = (p.K + BK - 1) / BK;
-    int tile = wg;
-    if (tile >= ntiles) return;
+    int ti = wl;                                       // index inside the XCD's range; tile = tbase + ti
+    auto tile_at = [&](int i) { return i < tcount ? tbase + i : -1; };
+    int tile = tile_at(ti);
+    if (tile < 0) return;
     prefetch_ids(tile);
-    int rid_cur = rid_next;
+    int rid_cur[2] = {rid_next[0], rid_next[1]};
     loader_set_tile(tile);
-    prefetch_ids(tile + nwg);
+    prefetch_ids(tile_at(ti + nw_x));
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
@@ -315,14 +348,15 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
     unsigned long long tlast = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-    for (; tile < ntiles; tile += nwg, par ^= 1) {
-        const bool more = tile + nwg < ntiles;
+    for (; tile >= 0; ti += nw_x, tile = tile_at(ti), par ^= 1) {
+        const bool more = ti + nw_x < tcount;
         acc_init(tile, par, rid_cur);
         PSTAMP(0)                                     // 0: accumulator init (residual loads issued)
         for (int c = 0; c + 1 < nchunk; ++c) {
             issue(stage ^ 1, (c + 1) * BK);
             PSTAMP(1)                                 // 1: DMA issue
             compute(stage);
+            __builtin_amdgcn_sched_barrier(0);        // MFMAs touch no memory: hipcc otherwise sinks them below the wait + barrier
             PSTAMP(2)                                 // 2: fragment reads + MFMA issue
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PSTAMP(3)                                 // 3: DMA landed
@@ -332,13 +366,15 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
         }
         // last chunk of the tile: the loader moves on to the next tile first
         if (more) {
-            rid_cur = rid_next;
-            loader_set_tile(tile + nwg);
-            prefetch_ids(tile + 2 * nwg);
+            rid_cur[0] = rid_next[0];
+            rid_cur[1] = rid_next[1];
+            loader_set_tile(tbase + ti + nw_x);
+            prefetch_ids(tile_at(ti + 2 * nw_x));
             issue(stage ^ 1, 0);
         }
         PSTAMP(5)                                     // 5: loader switch
         compute(stage);
+        __builtin_amdgcn_sched_barrier(0);
         PSTAMP(2)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PSTAMP(3)

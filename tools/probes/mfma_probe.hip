@@ -95,6 +95,44 @@ __global__ __launch_bounds__(256) void k_rand32(float* out, unsigned long long* 
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// V4: the same sustained probe on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16: 8 bf16 per lane and operand)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void k_rand_bf16(float* out, const float* rnd, int iters, int zero) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    bf16x8 a[4], b[4];
+    for (int u = 0; u < 4; ++u)
+        for (int e = 0; e < 8; ++e) {
+            a[u][e] = (__bf16)(zero ? 0.f : rnd[(threadIdx.x * 64 + u * 8 + e) & 4095]);
+            b[u][e] = (__bf16)(zero ? 0.f : rnd[(threadIdx.x * 64 + 32 + u * 8 + e) & 4095]);
+        }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[(u + i) & 3], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+// V5: 16x16x4 fp32 with random operands (is the small tile cheaper or dearer in power?)
+__global__ __launch_bounds__(256) void k_rand16(float* out, const float* rnd, int iters) {
+    f32x4 acc[8];
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    float a[8], b[8];
+    for (int u = 0; u < 8; ++u) { a[u] = rnd[(threadIdx.x * 16 + u) & 4095]; b[u] = rnd[(threadIdx.x * 16 + 8 + u) & 4095]; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[(u + i) & 7], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 4; ++r) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 template <typename F>
 double time_it(F launch, int reps) {
     hipEvent_t e0, e1;
@@ -127,8 +165,19 @@ int main() {
                        (double)blocks * 4 * it2 * 32 * 4096 / t / 1e12, mean, t * 1e6);
             }
         }
+        for (int zero = 1; zero >= 0; --zero) {
+            const int blocks = 1024, it2 = 4000;
+            double t = time_it([&] { hipLaunchKernelGGL(k_rand_bf16, dim3(blocks), dim3(256), 0, 0, out, rnd, it2, zero); }, 200);
+            printf("bf16 32x32x16 %s sustained: %.1f TF  (%.1f us per launch)\n", zero ? "zeros " : "random",
+                   (double)blocks * 4 * it2 * 16 * 32768 / t / 1e12, t * 1e6);
+        }
+        {
+            const int blocks = 1024, it2 = 1000;
+            double t = time_it([&] { hipLaunchKernelGGL(k_rand16, dim3(blocks), dim3(256), 0, 0, out, rnd, it2); }, 200);
+            printf("f32 16x16x4 random sustained: %.2f TF\n", (double)blocks * 4 * it2 * 64 * 2048 / t / 1e12);
+        }
     }
-    for (int blocks : {256, 512, 1024}) {
+    for (int blocks : {256}) {
         double t;
         t = time_it([&] { hipLaunchKernelGGL((k_pure32<1>), dim3(blocks), dim3(256), 0, 0, out, iters, 1.f, 2.f); }, 5);
         printf("pure32 nacc=1 blocks=%4d: %.2f TF\n", blocks, (double)blocks * 4 * iters * 4 * 1 * 4096 / t / 1e12);
