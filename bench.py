@@ -67,8 +67,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='cfg2b', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--serial-streams', action='store_true',
-                    help='also run the timed region with the title / body / freshness branches on ONE stream (profiling aid)')
+    ap.add_argument('--overlap-streams', action='store_true',
+                    help='fork the title / body / freshness / attention-weight branches onto side streams in the timed region')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -89,7 +89,7 @@ def main():
         D.init(backend=backend, device_id=torch.device('cuda', local_rank) if backend == 'nccl' else None)
 
     from lime_cikm25_amd import Model, make_config, newsEncoders, ops, synth
-    newsEncoders.SERIAL_STREAMS = bool(args.serial_streams)
+    newsEncoders.SERIAL_STREAMS = not args.overlap_streams
     overrides, B, N, desc = WORKLOADS[args.workload]
     cfg = make_config(**overrides)
     model = Model(cfg)
@@ -120,11 +120,9 @@ def main():
     dt = D.max_over_ranks(dt, device='cuda')                     # the slowest rank's time
     assert torch.isfinite(logits).all()
     # Per-kernel durations: the same K steps again, launched eagerly with a HIP event pair recorded on the launch
-    # stream around every lime_linear_f32 launch (events cannot be recorded inside a graph replay).  In the timed region
-    # the title chain, the body chain and the freshness branch run on separate streams and their persistent grids share
-    # the CUs, so a kernel's wall duration there is not its rate; here every branch is launched on ONE stream and each
-    # kernel owns the device (`--serial-streams` runs the timed region the same way: the rocprofv3 summary under
-    # profiles/ is taken with it, so that its per-kernel averages are the same quantity as `avg_launch_us`).
+    # stream around every lime_linear_f32 launch (events cannot be recorded inside a graph replay).  Every branch of the
+    # forward runs on ONE stream here, as in the timed region by default, so each kernel owns the device and these
+    # durations are the quantity rocprofv3 --kernel-trace reports for the same command (profiles/).
     prof = []
     if rank == 0:
         ops.PROFILE = prof
@@ -132,7 +130,7 @@ def main():
         for _ in range(args.steps):
             model(*batch)
         torch.cuda.synchronize()
-        newsEncoders.SERIAL_STREAMS = bool(args.serial_streams)
+        newsEncoders.SERIAL_STREAMS = not args.overlap_streams
         ops.PROFILE = None
     if dist is not None:
         dist.barrier()
@@ -169,7 +167,7 @@ def main():
             'config': {'workload': desc, 'batch_per_gpu': B, 'history': cfg.max_history_num, 'candidates': N,
                        'title_len': cfg.max_title_length, 'body_len': cfg.max_abstract_length,
                        'parallelism': 'rows sharded over %d GPU(s), no data-path collective' % world,
-                       'streams': 'serial' if args.serial_streams else 'title / body / freshness branches overlapped'},
+                       'streams': 'title / body / freshness branches overlapped' if args.overlap_streams else 'one stream'},
             'roofline': roof,
             'end_to_end': {'flops_per_impression': fimp, 'achieved_tflops': round(value * fimp / 1e12, 2),
                            'frac_of_f32_mfma_peak': round(value * fimp / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4)},

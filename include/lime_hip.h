@@ -217,6 +217,21 @@ int lime_row_scale_f32(const float* x, const float* scale, float* out, int64_t r
 int lime_gather_rows_f32(const int32_t* idx, const float* table, int64_t ld_table, float* out, int64_t ldo, int64_t rows,
                          int32_t dim, void* stream);
 
+/*
+ * lime_multi_copy: dst_i[0:bytes_i) = src_i[0:bytes_i) for up to LIME_MAX_COPIES device buffers in ONE launch.
+ * The drop-in Model replays a HIP graph captured on its own input buffers; the caller's 17 input tensors
+ * (model.py:151-154) are moved there with this instead of 17 separate copies (5 us of launch floor each).
+ * `descs` is a HOST array (the only host pointer of this ABI; it is copied into the kernel arguments before the call
+ * returns).  Buffers must not overlap.
+ */
+#define LIME_MAX_COPIES 32
+typedef struct {
+    const void* src;
+    void* dst;
+    int64_t bytes;
+} lime_copy_desc;
+int lime_multi_copy(const lime_copy_desc* descs, int32_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,13 @@ class LinearArgs(Structure):
     ]
 
 
+class CopyDesc(ctypes.Structure):
+    """lime_copy_desc of include/lime_hip.h."""
+    _fields_ = [('src', c_void_p), ('dst', c_void_p), ('bytes', c_int64)]
+
+
+MAX_COPIES = 32
+
 # name -> (restype, argtypes); every symbol include/lime_hip.h declares
 SIGNATURES = {
     'lime_abi_version': (c_int32, []),
@@ -61,6 +68,7 @@ SIGNATURES = {
                                           c_int32, c_int32, c_void_p]),
     'lime_row_scale_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     'lime_gather_rows_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p]),
+    'lime_multi_copy': (c_int32, [ctypes.POINTER(CopyDesc), c_int32, c_void_p]),
 }
 
 _lib = None

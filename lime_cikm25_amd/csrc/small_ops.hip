@@ -679,6 +679,50 @@ extern "C" int lime_gather_rows_f32(const int32_t* idx, const float* table, int6
     return lime_check_launch("lime_gather_rows_f32");
 }
 
+// ---------------------------------------------------------------------------------------------------
+// multi-copy: blockIdx.y = buffer, blockIdx.x = 16 KB piece of it
+// ---------------------------------------------------------------------------------------------------
+struct CopyTable {
+    lime_copy_desc d[LIME_MAX_COPIES];
+};
+constexpr long COPY_PIECE = 16384;
+
+__global__ __launch_bounds__(256) void multi_copy_kernel(const CopyTable t) {
+    const lime_copy_desc d = t.d[blockIdx.y];
+    const long b0 = (long)blockIdx.x * COPY_PIECE;
+    if (b0 >= d.bytes) return;
+    const long n = d.bytes - b0 < COPY_PIECE ? d.bytes - b0 : COPY_PIECE;
+    const char* src = (const char*)d.src + b0;
+    char* dst = (char*)d.dst + b0;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        const long nv = n >> 4;
+        for (long i = threadIdx.x; i < nv; i += 256) reinterpret_cast<f32x4*>(dst)[i] = reinterpret_cast<const f32x4*>(src)[i];
+        for (long i = (nv << 4) + threadIdx.x; i < n; i += 256) dst[i] = src[i];
+    } else {
+        for (long i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+    }
+}
+
+extern "C" int lime_multi_copy(const lime_copy_desc* descs, int32_t n, void* stream) {
+    LIME_REQUIRE(n >= 0 && n <= LIME_MAX_COPIES, LIME_ERR_BAD_ARG, "lime_multi_copy: n = %d outside [0, %d]", n, LIME_MAX_COPIES);
+    LIME_REQUIRE(n == 0 || descs, LIME_ERR_BAD_ARG, "lime_multi_copy: NULL descriptor table");
+    CopyTable t;
+    long most = 0;
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        LIME_REQUIRE(descs[i].bytes >= 0, LIME_ERR_BAD_ARG, "lime_multi_copy: negative size");
+        if (descs[i].bytes == 0) continue;
+        LIME_REQUIRE(descs[i].src && descs[i].dst, LIME_ERR_BAD_ARG, "lime_multi_copy: NULL buffer");
+        t.d[m++] = descs[i];
+        most = descs[i].bytes > most ? descs[i].bytes : most;
+    }
+    if (m == 0) return LIME_OK;
+    const long pieces = (most + COPY_PIECE - 1) / COPY_PIECE;
+    LIME_REQUIRE(pieces <= 0x7FFFFFFF, LIME_ERR_UNSUPPORTED, "lime_multi_copy: buffer too large");
+    hipLaunchKernelGGL(multi_copy_kernel, dim3((unsigned)pieces, (unsigned)m), dim3(256), 0, (hipStream_t)stream, t);
+    return lime_check_launch("lime_multi_copy");
+}
+
 extern "C" int lime_topic_rep_f32(const int32_t* cat, const int32_t* sub, const float* cat_table, const float* sub_table,
                                   int32_t dc, int32_t ds, const float* w, const float* bias, int32_t dout, float* out,
                                   int64_t ldo, float* emb_out, int64_t ld_emb, int64_t rows, void* stream) {

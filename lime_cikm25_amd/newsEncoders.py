@@ -35,7 +35,11 @@ def _no_train_dropout(module, p):
 _SIDE = {}
 
 
-SERIAL_STREAMS = bool(int(os.environ.get('LIME_SERIAL_STREAMS', '0')))     # measurement aid: every branch on the caller's stream
+# Independent branches of the forward (freshness encoder, candidate-aware attention weights, title chain vs body chain)
+# CAN be forked onto side streams (LIME_OVERLAP_STREAMS=1).  Off by default: the big GEMMs hold two workgroups of 256
+# VGPRs x 4 waves and 61 KB LDS on every CU, so nothing else becomes resident beside them and the forked forward
+# measured no faster than the single-stream one (4.61 vs 4.58 ms) while making per-kernel timings ambiguous.
+SERIAL_STREAMS = not bool(int(os.environ.get('LIME_OVERLAP_STREAMS', '0')))
 
 
 def _side_stream(device, which=0):
@@ -47,6 +51,25 @@ def _side_stream(device, which=0):
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=device)
     return _SIDE[key]
+
+
+def _cat_rows(ts):
+    """torch.cat(ts, dim=0) -- as a VIEW when the pieces already sit back to back in one storage (the Model's packed
+    graph inputs are laid out that way), so the per-forward concatenation of candidates and history costs no kernel."""
+    t0 = ts[0]
+    ok = all(t.is_contiguous() and t.dtype == t0.dtype and t.shape[1:] == t0.shape[1:] and
+             t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr() for t in ts)
+    if ok:
+        end = t0.storage_offset()
+        for t in ts:
+            ok = ok and t.storage_offset() == end
+            end += t.numel()
+    if not ok:
+        return torch.cat(ts, dim=0)
+    rows = sum(t.shape[0] for t in ts)
+    size = (rows,) + tuple(t0.shape[1:])
+    stride = t0.stride() if t0.dim() > 1 else (1,)
+    return t0.as_strided(size, stride, t0.storage_offset())
 
 
 def _i32(t):
@@ -171,7 +194,7 @@ class LIME(nn.Module):
             for dst, t in zip(flat, (_i32(tt).reshape(B * n, -1), tm.reshape(B * n, -1), _i32(ct).reshape(B * n, -1),
                                      _i32(cat).reshape(-1), _i32(sub).reshape(-1), fr.float().reshape(-1), lt.float().reshape(-1))):
                 dst.append(t)
-        cat_all = [t[0].contiguous() if len(t) == 1 else torch.cat(t, dim=0) for t in flat]
+        cat_all = [t[0].contiguous() if len(t) == 1 else _cat_rows(t) for t in flat]
         out = self.encode_flat(*cat_all)
         res, r0 = [], 0
         for (B, n) in shapes:
@@ -397,9 +420,10 @@ class CROWN(NewsEncoder):
         ops.topic_rep(category, subCategory, self.category_embedding.weight, sub_table, self.category_affine.weight,
                       self.category_affine.bias, out=xin[M:, E:kin])
         # k intent layers (:284-295): [2M, 350] x [400, 350]^T each, ReLU fused, written side by side
-        intents = torch.empty((2 * M, k * D), dtype=torch.float32, device=dev)
-        for i, lin in enumerate(self.intent_layers):
-            ops.linear(xin[:, :kin], lin.weight, lin.bias, act='relu', out=intents[:, i * D:(i + 1) * D])
+        # (one GEMM against the k weight matrices stacked row-wise: the k layers share their input)
+        w_int = torch.cat([lin.weight for lin in self.intent_layers], dim=0)
+        b_int = torch.cat([lin.bias for lin in self.intent_layers], dim=0)
+        intents = ops.linear(xin[:, :kin], w_int, b_int, act='relu')
         # intent attention (:355-356): tanh(affine1) on the GEMM, the rest in the fuse kernel
         A = self.title_intent_attention.affine1.out_features
         hidden = torch.empty((2 * M * k, A), dtype=torch.float32, device=dev)

@@ -363,3 +363,26 @@ def row_scale(x, scale):
 
 def inv_sqrt(x):
     return 1.0 / math.sqrt(float(x))
+
+
+def multi_copy(pairs):
+    """dst.copy_(src) for every (dst, src) pair in ONE launch per 32 pairs (same dtype / shape, both contiguous CUDA)."""
+    lib = _lib.load()
+    todo = []
+    for dst, src in pairs:
+        if dst.shape != src.shape or dst.dtype != src.dtype or not dst.is_cuda or not src.is_cuda:
+            raise ValueError('multi_copy: shape / dtype / device mismatch (%s %s vs %s %s)' % (tuple(dst.shape), dst.dtype,
+                                                                                              tuple(src.shape), src.dtype))
+        if not dst.is_contiguous():
+            raise ValueError('multi_copy: destinations must be contiguous')
+        if not src.is_contiguous():
+            src = src.contiguous()
+        if dst.data_ptr() != src.data_ptr() and dst.numel():
+            todo.append((dst, src))
+    for i in range(0, len(todo), _lib.MAX_COPIES):
+        part = todo[i:i + _lib.MAX_COPIES]
+        table = (_lib.CopyDesc * len(part))()
+        for d, (dst, src) in zip(table, part):
+            d.src, d.dst, d.bytes = src.data_ptr(), dst.data_ptr(), dst.numel() * dst.element_size()
+        check(lib.lime_multi_copy(table, len(part), _stream()), 'lime_multi_copy')
+    return todo            # keeps the sources referenced until the caller drops the list (the copy is asynchronous)

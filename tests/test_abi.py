@@ -66,6 +66,9 @@ def test_bad_arguments_are_rejected_without_a_launch(lib):
     assert lib.lime_bucketize_f32(None, None, 4, None) == -1
     assert lib.lime_token_attention_f32(None, None, None, 0, None, None, 0, 1, 1, 1, 1, 1, 1.0, None) == -1
     assert lib.lime_pad_heads_f32(None, 1, None, 1, 1, 1, 1, 1, None) == -1
+    assert lib.lime_multi_copy(None, 3, None) == -1
+    assert lib.lime_multi_copy(None, 0, None) == 0
+    assert lib.lime_multi_copy(None, 33, None) == -1
     assert lib.lime_sage_mean_f32(None, None, None, 1, 1, 1, 1, 1, None) == -1
     with pytest.raises(_lib.LimeHipError):
         _lib.check(-1, 'x')

@@ -454,3 +454,25 @@ def test_row_scale_and_gather_rows(ops):
     out = torch.zeros(64, 1000).cuda()
     ops.gather_rows(dev(idx), dev(table), out[:, 500:])
     assert torch.equal(out.cpu()[:, 500:], table[idx.long()])
+
+
+def test_multi_copy(ops):
+    g = torch.Generator().manual_seed(5)
+    shapes = [((7,), torch.int32), ((3, 5), torch.float32), ((1000, 33), torch.uint8), ((0,), torch.float32),
+              ((32, 50, 128), torch.int32), ((11,), torch.bool), ((4099,), torch.int64)] * 6           # 42 pairs: two launches
+    srcs = []
+    for shp, dt in shapes:
+        t = torch.randint(0, 100, shp, generator=g)
+        srcs.append(dev(t.to(dt)))
+    big = torch.zeros(sum(s.numel() * s.element_size() + 7 for s in srcs) + 64, dtype=torch.uint8, device='cuda')
+    dsts, off = [], 1                                       # deliberately misaligned destinations
+    for s in srcs:
+        nb = s.numel() * s.element_size()
+        off = (off + s.element_size() - 1) // s.element_size() * s.element_size()
+        dsts.append(big[off:off + nb].view(s.dtype).view(s.shape))
+        off += nb + 3
+    ops.multi_copy(list(zip(dsts, srcs)))
+    for d, s in zip(dsts, srcs):
+        assert torch.equal(d, s)
+    with pytest.raises(ValueError):
+        ops.multi_copy([(dsts[0], srcs[1])])
