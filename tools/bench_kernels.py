@@ -44,13 +44,14 @@ def main():
         w_in_p = ops.pad_heads(w_in, 30, 30, 32)
         b_in_p = ops.pad_heads(b_in, 30, 30, 32)
         qkv = torch.empty(tok, 3 * W, device=dev)
+        pew = ops.linear(pe, w_in_p, b_in_p)                 # the positional term of in_proj, [S, 3W]
         attn = torch.empty(tok, E, device=dev)
         x1 = torch.empty(tok, E, device=dev)
         h = torch.empty(tok, F, device=dev)
         x2 = torch.empty(tok, E, device=dev)
         cases = [
             ('qkv_' + name, 2.0 * tok * 3 * E * E,
-             lambda: ops.linear(table, w_in_p, b_in_p, a_ids=ids, a_pe=pe, a_period=S, out=qkv)),
+             lambda: ops.linear(table, w_in_p, None, a_ids=ids, res=pew, res_mod=S, out=qkv)),
             ('attn_' + name, 4.0 * tok * S * E,
              lambda: ops.token_attention(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, 10, 30, 1 / math.sqrt(30), out=attn,
                                          head_stride=32)),
