@@ -42,6 +42,10 @@ WORKLOADS = {
              'MIND-small synthetic, batch=8, history=10, title_len=16, K=1+1 (BASELINE.json configs[0])'),
     'cfg3shape': (dict(batch_size=256), 256, 5, 'MIND-shape synthetic, batch=256, history=50, title 32 + body 128, K=1+4, '
                                                 'fp32 arithmetic (configs[2] shape)'),
+    'cfg3': (dict(batch_size=256, compute_dtype='bf16'), 256, 5,
+             'MIND-shape synthetic, batch=256, history=50, title 32 + body 128, K=1+4, bf16 MFMA token encoders with fp32 '
+             'accumulate / softmax / LayerNorm (BASELINE.json configs[2])'),
+    'cfg2b_bf16': (dict(compute_dtype='bf16'), 32, 5, 'configs[1] shape (batch=32) with the bf16 token encoders of configs[2]'),
 }
 
 
@@ -163,7 +167,8 @@ def main():
         out = {
             'metric': 'impressions scored/sec', 'value': round(value, 2), 'unit': 'impressions/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16' if getattr(cfg, 'compute_dtype', 'fp32') == 'bf16' else 'f32', 'data': 'synthetic',
             'config': {'workload': desc, 'batch_per_gpu': B, 'history': cfg.max_history_num, 'candidates': N,
                        'title_len': cfg.max_title_length, 'body_len': cfg.max_abstract_length,
                        'parallelism': 'rows sharded over %d GPU(s), no data-path collective' % world,

@@ -92,6 +92,45 @@ int lime_linear_f32(const lime_linear_args* args, void* stream);
 const char* lime_last_linear_kernel(void);
 
 /*
+ * lime_linear_bf16: the same operation on the bf16 matrix cores (BASELINE config 3: "bf16 MFMA with fp32
+ * accumulate / softmax / LayerNorm").  A (or the gathered table), W and C are bf16 (uint16 storage, row-major);
+ * accumulation, bias, activation, residual add and LayerNorm are fp32; the result is rounded to bf16 (nearest even).
+ *   K % 8 == 0, K >= 64, lda % 8 == 0, ldw % 8 == 0 (16-byte rows); N % 4 == 0, ldc % 4 == 0.  K = 300 / N = 300 of the
+ *   encoder layers are passed as 304 with zero columns / zero weight rows (lime_to_bf16 pads while converting).
+ *   res_kind: 0 none; 1 fp32 rows res[(r or r % res_mod) * ldr + n]; 2 bf16 rows gathered by res_ids (+ fp32
+ *   res_pe[(r % res_period)]); 3 bf16 rows res[r * ldr + n].  Kinds 2 and 3 are built with the LayerNorm epilogue only,
+ *   kind 1 without it; act is none, or ReLU without residual.  ln_count: the number of real columns LayerNorm divides
+ *   by (zero-padded columns must have zero weights, bias, residual, gamma and beta: they come out as zeros).
+ *   Any M works; the kernel is built for M >= 4096 (two 128-row workgroups per CU).
+ */
+typedef struct {
+    const uint16_t* a;    int64_t lda;
+    const int32_t* a_ids;
+    const uint16_t* w;    int64_t ldw;
+    const float* bias;
+    const void* res;      int64_t ldr;   int32_t res_kind; int32_t res_mod;
+    const int32_t* res_ids; const float* res_pe; int64_t ldr_pe; int32_t res_period;
+    const float* ln_gamma; const float* ln_beta; float ln_eps; int32_t ln_count;
+    uint16_t* c;          int64_t ldc;
+    int32_t M, N, K;
+    int32_t act;
+} lime_linear_bf16_args;
+
+int lime_linear_bf16(const lime_linear_bf16_args* args, void* stream);
+
+/*
+ * lime_to_bf16: dst[r, c] = bf16(src[r, c]) for r < rows, c < cols, zero for the padding up to [rows_out, cols_out]
+ * (src fp32 [rows, cols] with leading dimension lds; dst bf16 [rows_out, ldd]).  Converts the word table, the weights
+ * and pads K = 300 -> 304 / N = 300 -> 304 on the way.
+ */
+int lime_to_bf16(const float* src, int64_t lds, int64_t rows, int32_t cols, uint16_t* dst, int64_t ldd, int64_t rows_out,
+                 int32_t cols_out, void* stream);
+
+/* lime_mean_pool_bf16: out[s, 0:dim) = mean_t float(x[(s * S + t), 0:dim))  -- bf16 input, fp32 output */
+int lime_mean_pool_bf16(const uint16_t* x, int64_t ldx, float* out, int64_t ldo, int32_t n_seq, int32_t S, int32_t dim,
+                        void* stream);
+
+/*
  * lime_embed_pe_f32: out[r, :] = table[ids[r], :] + pe[(r % period), :]   (pe may be NULL)
  * The stand-alone word-embedding gather (newsEncoders.py:311-312 + :827); the HBM-bound kernel of the
  * path.  ids int32 [rows]; table [V, dim]; out [rows, ldo].
@@ -112,6 +151,16 @@ int lime_embed_pe_f32(const int32_t* ids, const float* table, int64_t ld_table, 
 int lime_token_attention_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const uint8_t* key_mask,
                              float* out, int64_t ldo, int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim,
                              int32_t head_stride, float scale, void* stream);
+
+/*
+ * lime_token_attention_bf16: the unmasked encoder-layer attention on bf16 storage (config 3): q / k / v bf16 with every
+ * head at 32 columns (64-byte head rows), out bf16 packed [.., n_head * head_dim] plus zero columns up to out_cols (the
+ * K padding the next GEMM reads).  Operands are widened to fp32 on the way in; scores, softmax and P.V are the fp32 path's.
+ * S in {32, 64, 128, 256, 512}.
+ */
+int lime_token_attention_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ld_qkv, uint16_t* out,
+                              int64_t ldo, int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim, float scale,
+                              int32_t out_cols, void* stream);
 
 /*
  * lime_pad_heads_f32: dst[(blk * head_stride + d), :] = d < head_dim ? src[(blk * head_dim + d), :] : 0 for blk < n_blk.

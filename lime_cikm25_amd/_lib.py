@@ -30,6 +30,22 @@ class LinearArgs(Structure):
     ]
 
 
+class LinearBf16Args(ctypes.Structure):
+    """lime_linear_bf16_args of include/lime_hip.h (same field order)."""
+    _fields_ = [
+        ('a', c_void_p), ('lda', c_int64),
+        ('a_ids', c_void_p),
+        ('w', c_void_p), ('ldw', c_int64),
+        ('bias', c_void_p),
+        ('res', c_void_p), ('ldr', c_int64), ('res_kind', c_int32), ('res_mod', c_int32),
+        ('res_ids', c_void_p), ('res_pe', c_void_p), ('ldr_pe', c_int64), ('res_period', c_int32),
+        ('ln_gamma', c_void_p), ('ln_beta', c_void_p), ('ln_eps', c_float), ('ln_count', c_int32),
+        ('c', c_void_p), ('ldc', c_int64),
+        ('M', c_int32), ('N', c_int32), ('K', c_int32),
+        ('act', c_int32),
+    ]
+
+
 class CopyDesc(ctypes.Structure):
     """lime_copy_desc of include/lime_hip.h."""
     _fields_ = [('src', c_void_p), ('dst', c_void_p), ('bytes', c_int64)]
@@ -69,6 +85,11 @@ SIGNATURES = {
     'lime_row_scale_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     'lime_gather_rows_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p]),
     'lime_multi_copy': (c_int32, [ctypes.POINTER(CopyDesc), c_int32, c_void_p]),
+    'lime_linear_bf16': (c_int32, [ctypes.POINTER(LinearBf16Args), c_void_p]),
+    'lime_token_attention_bf16': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32,
+                                            c_int32, c_float, c_int32, c_void_p]),
+    'lime_to_bf16': (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64, c_int64, c_int32, c_void_p]),
+    'lime_mean_pool_bf16': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
 }
 
 _lib = None

@@ -57,6 +57,9 @@ _DEFAULTS = dict(
     category_num=18,
     subCategory_num=270,
     user_num=1000,
+    # not in the reference: arithmetic of the token encoders on the MI355X path.  'fp32' (exact-fp32 MFMA, the parity
+    # configuration) or 'bf16' (BASELINE config 3: bf16 MFMA operands / activations, fp32 accumulate, softmax, LayerNorm)
+    compute_dtype='fp32',
 )
 
 

@@ -11,6 +11,7 @@ struct PPParams {
     const float* res; long ldr; int res_mod; const int* res_ids; const float* res_pe; long ldr_pe; int res_period;
     const float* ln_g; const float* ln_b; float ln_eps;
     float* c; long ldc; int M, N, K;
+    int ln_count;        // LayerNorm divides by this many columns (N unless the caller zero-padded N)
     int n_row_blocks, n_col_blocks;
 #ifdef LIME_STAMPS
     unsigned long long* stamps;

@@ -71,14 +71,46 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, float* lds_base,
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds_base, 16, voff, soff, 0, 0);
 #endif
 }
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// bf16 <-> fp32 (round to nearest even; inputs are finite on this path)
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    unsigned a = __builtin_bit_cast(unsigned, lo), b = __builtin_bit_cast(unsigned, hi);
+    a += 0x7FFFu + ((a >> 16) & 1u);
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xFFFF0000u);
+}
+__device__ __forceinline__ f32x4 unpack_bf16x4(u32x2 v) {
+    f32x4 r;
+    r[0] = __builtin_bit_cast(float, v[0] << 16);
+    r[1] = __builtin_bit_cast(float, v[0] & 0xFFFF0000u);
+    r[2] = __builtin_bit_cast(float, v[1] << 16);
+    r[3] = __builtin_bit_cast(float, v[1] & 0xFFFF0000u);
+    return r;
+}
+__device__ __forceinline__ f32x4 buf_load4_bf16(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {     // 4 bf16 -> 4 floats
+    return unpack_bf16x4(__builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)));
+}
+__device__ __forceinline__ void buf_store4_bf16(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    u32x2 o;
+    o[0] = pack_bf16(v[0], v[1]);
+    o[1] = pack_bf16(v[2], v[3]);
+    __builtin_amdgcn_raw_buffer_store_b64(o, r, voff, soff, 0);
+}
 __device__ __forceinline__ void buf_store4(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
 }
 
 // NTL: 32-column MFMA tiles per wave (tile width 32 * NTL).  LN: LayerNorm epilogue (one column block spans N).
-// RES: 0 none, 1 dense residual rows ((r / 1) % res_mod), 2 gathered rows + positional table.
-template <int NTL, bool LN, bool RELU, int RES>
+// RES: 0 none, 1 dense fp32 residual rows (r, or r % res_mod), 2 gathered rows + fp32 positional table,
+//      3 (BF only) dense bf16 residual rows.
+// BF:  bf16 operands (A rows, gathered table rows, W) and bf16 output, v_mfma_f32_16x16x32_bf16, fp32 accumulation and
+//      epilogue (lime_linear_bf16).  The LDS image is byte-identical: a row's chunk is 64 bytes = 16 floats or 32 bf16.
+template <int NTL, bool LN, bool RELU, int RES, bool BF>
 __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
+    constexpr int ES = BF ? 2 : 4;                 // operand element size
+    constexpr int EPS = 16 / ES;                   // elements per 16-byte segment
+    constexpr int BKE = 64 / ES;                   // elements per chunk
     constexpr int BN = NTL * 32;
     constexpr int A_ST = BM * BK, W_ST = BN * BK, STAGE = A_ST + W_ST;     // floats
     constexpr int NWI = BN / 64;                                            // weight DMA instructions per wave and chunk
@@ -106,7 +138,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
 
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w);
     const bool gather_a = p.a_ids != nullptr;
-    const int lda4 = (int)p.lda * 4, ldw4 = (int)p.ldw * 4, ldc4 = (int)p.ldc * 4, ldr4 = (int)p.ldr * 4;
+    const int lda4 = (int)p.lda * ES, ldw4 = (int)p.ldw * ES, ldc4 = (int)p.ldc * ES;         // row pitches in bytes
+    const int ldr4 = (int)p.ldr * ((RES == 3 || (RES == 2 && BF)) ? 2 : 4);
 
     // ---- loader state: per-lane byte offsets of the rows this lane stages ---------------------------------------------
     // DMA instruction `idx` of an operand covers image rows 16 idx .. 16 idx + 15; lane l fills row 16 idx + (l >> 2),
@@ -146,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
         int row0, col0;
         tile_rc(tile, row0, col0);
         // dense A: the descriptor base moves to the tile's first row, offsets stay small; gather: base = the table
-        rs_a = make_rsrc(gather_a ? p.a : p.a + (long)row0 * p.lda);
+        rs_a = make_rsrc(gather_a ? (const char*)p.a : (const char*)p.a + (long)row0 * p.lda * ES);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int rl = 16 * (wave * 2 + j) + srow;
@@ -159,18 +192,19 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
             w_voff[j] = (n < p.N) ? (unsigned)n * (unsigned)ldw4 + (unsigned)lseg * 16u : OOB;
         }
     };
-    auto issue = [&](int stage, int k0) {              // DMA of chunk k0 .. k0 + 15 into `stage`
+    auto issue = [&](int stage, int c) {               // DMA of chunk c (elements c BKE .. c BKE + BKE - 1) into `stage`
+        const int k0 = c * BKE;
 #if defined(LIME_PP_ABLATE) && LIME_PP_ABLATE == 2       // tools/pp_ablate.py: no operand traffic (results are garbage)
         return;
 #endif
-        const bool kin = k0 + lseg * 4 < p.K;          // K % 4 == 0: a segment is valid or not as a whole
+        const bool kin = k0 + lseg * EPS < p.K;        // K % EPS == 0: a segment is valid or not as a whole
         float* const sb = lds + stage * STAGE;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            dma16(rs_a, sb + (wave * 2 + j) * 256, kin ? a_voff[j] : OOB, k0 * 4);
+            dma16(rs_a, sb + (wave * 2 + j) * 256, kin ? a_voff[j] : OOB, c * 64);
 #pragma unroll
         for (int j = 0; j < NWI; ++j)
-            dma16(rs_w, sb + A_ST + (wave * NWI + j) * 256, kin ? w_voff[j] : OOB, k0 * 4);
+            dma16(rs_w, sb + A_ST + (wave * NWI + j) * 256, kin ? w_voff[j] : OOB, c * 64);
     };
 
     // ---- compute state ---------------------------------------------------------------------------------------------
@@ -196,14 +230,24 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
             f32x4 wf[GRP];
 #pragma unroll
             for (int t = 0; t < GRP; ++t) wf[t] = *reinterpret_cast<const f32x4*>(sb + w_off + (gb * GRP + t) * 16 * BK);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
+            if constexpr (BF) {
+                // one v_mfma_f32_16x16x32_bf16 per tile: the b128 IS the lane's fragment (8 bf16 = k 8 kg .. 8 kg + 7)
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                     for (int t = 0; t < GRP; ++t)
-                        acc[tt][gb * GRP + t] =
-                            __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][q], af[tt][q], acc[tt][gb * GRP + t], 0, 0, 0);
+                        acc[tt][gb * GRP + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, wf[t]), __builtin_bit_cast(bf16x8, af[tt]), acc[tt][gb * GRP + t], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                        for (int t = 0; t < GRP; ++t)
+                            acc[tt][gb * GRP + t] =
+                                __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][q], af[tt][q], acc[tt][gb * GRP + t], 0, 0, 0);
+            }
         }
     };
 
@@ -220,9 +264,11 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
 #pragma unroll
                 for (int t = 0; t < NT16; ++t) acc[tt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
         } else {
+            constexpr bool RBF = RES == 3 || (RES == 2 && BF);                 // residual rows are bf16
+            constexpr int RB = RBF ? 2 : 4;
             const __amdgpu_buffer_rsrc_t rs_rpe = make_rsrc(p.res_pe ? p.res_pe : p.w);
             __amdgpu_buffer_rsrc_t rs_res;
-            if (RES == 1 && p.res_mod <= 0) rs_res = make_rsrc(p.res + (long)row0 * p.ldr);
+            if ((RES == 1 && p.res_mod <= 0) || RES == 3) rs_res = make_rsrc((const char*)p.res + (long)row0 * p.ldr * RB);
             else rs_res = make_rsrc(p.res);
             // Column validity is only tested in the last 64 columns (the dispatcher guarantees N - col0 >= BN - 64):
             // elsewhere the offset is `row offset + literal`, which hipcc cannot hoist out of the tile loop (hoisted
@@ -235,25 +281,29 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
                 if (row < p.M) {
                     if constexpr (RES == 1) {
                         ro = (p.res_mod > 0 ? (unsigned)(row % p.res_mod) : (unsigned)rl) * (unsigned)ldr4;
+                    } else if constexpr (RES == 3) {
+                        ro = (unsigned)rl * (unsigned)ldr4;
                     } else {
                         ro = (unsigned)rid[tt] * (unsigned)ldr4;
                         if (p.res_pe) po = (unsigned)(row % p.res_period) * (unsigned)((int)p.ldr_pe * 4);
                     }
                 }
-                rof[tt] = ro == OOB ? OOB : ro + (unsigned)kg * 16u;
+                rof[tt] = ro == OOB ? OOB : ro + (unsigned)kg * (4u * RB);
                 pof[tt] = po == OOB ? OOB : po + (unsigned)kg * 16u;
             }
 #pragma unroll
             for (int t = 0; t < NT16; ++t) {
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) {
-                    unsigned o1 = rof[tt] + (unsigned)t * 64u, o2 = pof[tt] + (unsigned)t * 64u;
+                    unsigned o1 = rof[tt] + (unsigned)t * (16u * RB), o2 = pof[tt] + (unsigned)t * 64u;
                     if (t >= NT16 - 4) {
                         const bool ok = col0 + 16 * t + 4 * kg < p.N;
                         o1 = ok ? o1 : OOB;
                         o2 = ok ? o2 : OOB;
                     }
-                    f32x4 x = buf_load4(rs_res, o1, col0 * 4);
+                    f32x4 x;
+                    if constexpr (RBF) x = buf_load4_bf16(rs_res, o1, col0 * RB);
+                    else x = buf_load4(rs_res, o1, col0 * RB);
                     if constexpr (RES == 2) x += buf_load4(rs_rpe, o2, col0 * 4);
                     acc[tt][t] = x;
                 }
@@ -266,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
         int row0, col0;
         tile_rc(tile, row0, col0);
         const float* const bs = Bs + (par ? BN : 0) + 4 * kg;
-        const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(p.c + (long)row0 * p.ldc + col0);
+        const __amdgpu_buffer_rsrc_t rs_c = make_rsrc((char*)p.c + ((long)row0 * p.ldc + col0) * ES);
         float sum[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < NT16; ++t) {
@@ -287,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
         }
         float mean[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f};
         if constexpr (LN) {
-            const float inv_n = 1.0f / (float)p.N;
+            const float inv_n = 1.0f / (float)p.ln_count;        // the real columns (zero-padded ones add nothing to the sums)
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 float s1 = sum[tt], s2 = sq[tt];
@@ -301,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int rl = 32 * wave + 16 * tt + fi;
-            cof[tt] = (row0 + rl < p.M) ? (unsigned)rl * (unsigned)ldc4 + (unsigned)kg * 16u : OOB;
+            cof[tt] = (row0 + rl < p.M) ? (unsigned)rl * (unsigned)ldc4 + (unsigned)kg * (4u * ES) : OOB;
         }
         const float* const gs = Gs + 4 * kg;
         const float* const es = Es + 4 * kg;
@@ -316,9 +366,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
             for (int tt = 0; tt < 2; ++tt) {
                 f32x4 y = acc[tt][t];
                 if constexpr (LN) y = (y - mean[tt]) * rstd[tt] * ga + be;
-                unsigned o = cof[tt] + (unsigned)t * 64u;
+                unsigned o = cof[tt] + (unsigned)t * (16u * ES);
                 if (t >= NT16 - 4) o = (col0 + 16 * t + 4 * kg < p.N) ? o : OOB;
-                buf_store4(y, rs_c, o, 0);
+                if constexpr (BF) buf_store4_bf16(y, rs_c, o, 0);
+                else buf_store4(y, rs_c, o, 0);
             }
         }
     };
@@ -330,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
             Es[c] = c < p.N ? p.ln_b[c] : 0.f;
         }
     }
-    const int nchunk = (p.K + BK - 1) / BK;
+    const int nchunk = (p.K + BKE - 1) / BKE;
     int ti = wl;                                       // index inside the XCD's range; tile = tbase + ti
     auto tile_at = [&](int i) { return i < tcount ? tbase + i : -1; };
     int tile = tile_at(ti);
@@ -353,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
         acc_init(tile, par, rid_cur);
         PSTAMP(0)                                     // 0: accumulator init (residual loads issued)
         for (int c = 0; c + 1 < nchunk; ++c) {
-            issue(stage ^ 1, (c + 1) * BK);
+            issue(stage ^ 1, c + 1);
             PSTAMP(1)                                 // 1: DMA issue
             compute(stage);
             __builtin_amdgcn_sched_barrier(0);        // MFMAs touch no memory: hipcc otherwise sinks them below the wait + barrier
@@ -405,7 +456,7 @@ int num_cus() {
     return n;
 }
 
-template <int NTL, bool LN, bool RELU, int RES>
+template <int NTL, bool LN, bool RELU, int RES, bool BF = false>
 int launch(const PPParams& p0, hipStream_t stream) {
     PPParams p = p0;
     p.n_row_blocks = (p.M + BM - 1) / BM;
@@ -416,8 +467,9 @@ int launch(const PPParams& p0, hipStream_t stream) {
 #ifdef LIME_STAMPS
     p.stamps = g_pp_stamp_buf;
 #endif
-    hipLaunchKernelGGL((gemm_pp_kernel<NTL, LN, RELU, RES>), dim3((unsigned)nwg), dim3(256), 0, stream, p);
-    lime_set_last_linear_kernel("gemm_pp_kernel<%d, %s, %s, %d>", NTL, LN ? "true" : "false", RELU ? "true" : "false", RES);
+    hipLaunchKernelGGL((gemm_pp_kernel<NTL, LN, RELU, RES, BF>), dim3((unsigned)nwg), dim3(256), 0, stream, p);
+    lime_set_last_linear_kernel("gemm_pp_kernel<%d, %s, %s, %d, %s>", NTL, LN ? "true" : "false", RELU ? "true" : "false", RES,
+                                BF ? "true" : "false");
     return lime_check_launch("lime_linear_f32");
 }
 
@@ -458,7 +510,7 @@ int lime_linear_pp(const lime_linear_args* a, hipStream_t s) {
     p.res = a->res; p.ldr = a->ldr; p.res_mod = a->res_mod; p.res_ids = a->res_ids;
     p.res_pe = a->res_pe; p.ldr_pe = a->ldr_pe; p.res_period = a->res_period > 0 ? a->res_period : 1;
     p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps;
-    p.c = a->c; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K;
+    p.c = a->c; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K; p.ln_count = a->N;
     p.n_row_blocks = p.n_col_blocks = 0;
     if (ln) {
         if (!tail_ok(320)) return LIME_PP_NOT_APPLICABLE;
@@ -476,4 +528,64 @@ int lime_linear_pp(const lime_linear_args* a, hipStream_t s) {
     }
     if (res == 1) return launch<8, false, false, 1>(p, s);
     return relu ? launch<8, false, true, 0>(p, s) : launch<8, false, false, 0>(p, s);
+}
+
+// ---- bf16 operands (BASELINE config 3: bf16 MFMA, fp32 accumulate / LayerNorm) ------------------------------------------
+extern "C" int lime_linear_bf16(const lime_linear_bf16_args* a, void* stream) {
+    LIME_REQUIRE(a != nullptr, LIME_ERR_BAD_ARG, "lime_linear_bf16: args is NULL");
+    LIME_REQUIRE(a->a && a->w && a->c, LIME_ERR_BAD_ARG, "lime_linear_bf16: a, w and c must be non-NULL");
+    LIME_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0, LIME_ERR_BAD_ARG, "lime_linear_bf16: bad dims M=%d N=%d K=%d", a->M, a->N, a->K);
+    LIME_REQUIRE(a->K % 8 == 0 && a->K >= 64 && a->N % 4 == 0, LIME_ERR_UNSUPPORTED,
+                 "lime_linear_bf16: K must be a multiple of 8 and >= 64, N a multiple of 4 (pad with zero columns / rows)");
+    LIME_REQUIRE(a->lda >= a->K && a->ldw >= a->K && a->ldc >= a->N, LIME_ERR_BAD_ARG, "lime_linear_bf16: leading dimension < row");
+    auto al = [](const void* ptr, long ld, int elem, int bytes) { return ptr == nullptr || ((uintptr_t)ptr % bytes == 0 && (ld * elem) % bytes == 0); };
+    LIME_REQUIRE(al(a->a, a->lda, 2, 16) && al(a->w, a->ldw, 2, 16), LIME_ERR_BAD_ARG,
+                 "lime_linear_bf16: a / w rows must be 16-byte aligned (lda, ldw multiples of 8)");
+    LIME_REQUIRE(al(a->c, a->ldc, 2, 8), LIME_ERR_BAD_ARG, "lime_linear_bf16: c rows must be 8-byte aligned (ldc multiple of 4)");
+    LIME_REQUIRE(a->res_kind >= 0 && a->res_kind <= 3 && (a->res_kind == 0) == (a->res == nullptr), LIME_ERR_BAD_ARG,
+                 "lime_linear_bf16: res_kind %d does not match res", a->res_kind);
+    LIME_REQUIRE(a->act == LIME_ACT_NONE || (a->act == LIME_ACT_RELU && a->res_kind == 0), LIME_ERR_UNSUPPORTED,
+                 "lime_linear_bf16: activation none, or ReLU without residual");
+    const bool ln = a->ln_gamma != nullptr, relu = a->act == LIME_ACT_RELU;
+    LIME_REQUIRE(!ln || (a->ln_beta && a->N <= 320 && !relu && a->ln_count > 0 && a->ln_count <= a->N), LIME_ERR_UNSUPPORTED,
+                 "lime_linear_bf16: LayerNorm needs beta, N <= 320, no activation, 0 < ln_count <= N");
+    if (a->res_kind == 1) LIME_REQUIRE(al(a->res, a->ldr, 4, 16) && a->ldr >= a->N, LIME_ERR_BAD_ARG, "lime_linear_bf16: fp32 residual misaligned");
+    if (a->res_kind == 2)
+        LIME_REQUIRE(a->res_ids && al(a->res, a->ldr, 2, 8) && a->ldr >= a->N && (!a->res_pe || (al(a->res_pe, a->ldr_pe, 4, 16) &&
+                     a->res_period > 0 && a->ldr_pe >= a->N)), LIME_ERR_BAD_ARG, "lime_linear_bf16: gathered residual needs ids, aligned rows, res_period");
+    if (a->res_kind == 3) LIME_REQUIRE(al(a->res, a->ldr, 2, 8) && a->ldr >= a->N, LIME_ERR_BAD_ARG, "lime_linear_bf16: bf16 residual misaligned");
+    if (a->M == 0) return LIME_OK;
+    const long lim = 0x7FFFFFF0L;
+    LIME_REQUIRE(128L * a->lda * 2 < lim && (long)a->N * a->ldw * 2 < lim && 128L * a->ldc * 2 < lim && 128L * a->ldr * 4 < lim &&
+                 (long)a->M * 4 < lim, LIME_ERR_UNSUPPORTED, "lime_linear_bf16: operand too large for 32-bit offsets");
+    const bool wide = ((a->N + 319) / 320 * 320 - a->N) < ((a->N + 255) / 256 * 256 - a->N);
+    const int bn = (ln || wide) ? 320 : 256;
+    LIME_REQUIRE(a->N - (a->N - 1) / bn * bn >= bn - 64, LIME_ERR_UNSUPPORTED,
+                 "lime_linear_bf16: the last %d-column block of N=%d is narrower than %d columns (pad N)", bn, a->N, bn - 64);
+
+    PPParams p;
+    p.a = (const float*)a->a; p.lda = a->lda; p.a_ids = a->a_ids;
+    p.w = (const float*)a->w; p.ldw = a->ldw; p.bias = a->bias;
+    p.res = (const float*)a->res; p.ldr = a->ldr; p.res_mod = a->res_mod; p.res_ids = a->res_ids;
+    p.res_pe = a->res_pe; p.ldr_pe = a->ldr_pe; p.res_period = a->res_period > 0 ? a->res_period : 1;
+    p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps;
+    p.c = (float*)a->c; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K; p.ln_count = ln ? a->ln_count : a->N;
+    p.n_row_blocks = p.n_col_blocks = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (ln) {
+        switch (a->res_kind) {
+            case 0: return launch<10, true, false, 0, true>(p, s);
+            case 2: return launch<10, true, false, 2, true>(p, s);
+            case 3: return launch<10, true, false, 3, true>(p, s);
+            default: break;
+        }
+        LIME_REQUIRE(false, LIME_ERR_UNSUPPORTED, "lime_linear_bf16: LayerNorm with an fp32 residual is not built");
+    }
+    LIME_REQUIRE(a->res_kind <= 1, LIME_ERR_UNSUPPORTED, "lime_linear_bf16: bf16 / gathered residuals are built with LayerNorm only");
+    if (bn == 320) {
+        if (a->res_kind == 1) return launch<10, false, false, 1, true>(p, s);
+        return relu ? launch<10, false, true, 0, true>(p, s) : launch<10, false, false, 0, true>(p, s);
+    }
+    if (a->res_kind == 1) return launch<8, false, false, 1, true>(p, s);
+    return relu ? launch<8, false, true, 0, true>(p, s) : launch<8, false, false, 0, true>(p, s);
 }

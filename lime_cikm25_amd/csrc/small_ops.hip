@@ -680,6 +680,86 @@ extern "C" int lime_gather_rows_f32(const int32_t* idx, const float* table, int6
 }
 
 // ---------------------------------------------------------------------------------------------------
+// bf16 path helpers (BASELINE config 3)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {          // round to nearest even (finite inputs)
+    unsigned u = __builtin_bit_cast(unsigned, f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+
+// four output columns per thread (cols_out % 4 == 0): 8-byte stores
+__global__ __launch_bounds__(256) void to_bf16_kernel(const float* __restrict__ src, long lds, long rows, int cols,
+                                                      unsigned short* __restrict__ dst, long ldd, long rows_out, int cols_out) {
+    const int q = cols_out >> 2;
+    const long total = rows_out * q;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / q;
+        const int c = (int)(e - r * q) * 4;
+        unsigned short v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (r < rows && c + j < cols) ? f32_to_bf16(src[r * lds + c + j]) : (unsigned short)0;
+        unsigned lo = v[0] | ((unsigned)v[1] << 16), hi = v[2] | ((unsigned)v[3] << 16);
+        *reinterpret_cast<uint2*>(dst + r * ldd + c) = make_uint2(lo, hi);
+    }
+}
+
+// one workgroup per sequence; thread = 4 columns x row group, fixed-order combine through LDS (as mean_pool_vec4_kernel)
+__global__ __launch_bounds__(256) void mean_pool_bf16_kernel(const unsigned short* __restrict__ x, long ldx, float* __restrict__ out,
+                                                              long ldo, int S, int dim) {
+    __shared__ f32x4 part[256];
+    const long s = blockIdx.x;
+    const int nc = (dim + 3) >> 2;                 // 4-column groups (<= 256)
+    const int rg_n = 256 / nc;
+    const int c = threadIdx.x % nc, rg = threadIdx.x / nc;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (rg < rg_n) {
+        const unsigned short* px = x + s * S * ldx + c * 4;
+        for (int t = rg; t < S; t += rg_n) {
+            const uint2 v = *reinterpret_cast<const uint2*>(px + (long)t * ldx);
+            acc[0] += __builtin_bit_cast(float, v.x << 16);
+            acc[1] += __builtin_bit_cast(float, v.x & 0xFFFF0000u);
+            acc[2] += __builtin_bit_cast(float, v.y << 16);
+            acc[3] += __builtin_bit_cast(float, v.y & 0xFFFF0000u);
+        }
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (rg == 0) {
+        for (int g = 1; g < rg_n; ++g) acc += part[g * nc + c];
+        const float inv = 1.0f / (float)S;
+        for (int j = 0; j < 4; ++j)
+            if (c * 4 + j < dim) out[s * ldo + c * 4 + j] = acc[j] * inv;
+    }
+}
+
+extern "C" int lime_to_bf16(const float* src, int64_t lds, int64_t rows, int32_t cols, uint16_t* dst, int64_t ldd, int64_t rows_out,
+                            int32_t cols_out, void* stream) {
+    LIME_REQUIRE(src && dst, LIME_ERR_BAD_ARG, "lime_to_bf16: NULL pointer");
+    LIME_REQUIRE(rows >= 0 && cols > 0 && rows_out >= rows && cols_out >= cols && lds >= cols && ldd >= cols_out, LIME_ERR_BAD_ARG,
+                 "lime_to_bf16: bad dims");
+    LIME_REQUIRE(cols_out % 4 == 0 && ldd % 4 == 0 && (uintptr_t)dst % 8 == 0, LIME_ERR_BAD_ARG,
+                 "lime_to_bf16: cols_out and ldd must be multiples of 4, dst 8-byte aligned");
+    if (rows_out == 0) return LIME_OK;
+    hipLaunchKernelGGL(to_bf16_kernel, dim3(grid_for(rows_out * (cols_out / 4), 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       (long)lds, (long)rows, cols, dst, (long)ldd, (long)rows_out, cols_out);
+    return lime_check_launch("lime_to_bf16");
+}
+
+extern "C" int lime_mean_pool_bf16(const uint16_t* x, int64_t ldx, float* out, int64_t ldo, int32_t n_seq, int32_t S, int32_t dim,
+                                   void* stream) {
+    LIME_REQUIRE(x && out, LIME_ERR_BAD_ARG, "lime_mean_pool_bf16: NULL pointer");
+    LIME_REQUIRE(n_seq >= 0 && S > 0 && dim > 0 && ldo >= dim, LIME_ERR_BAD_ARG, "lime_mean_pool_bf16: bad dims");
+    LIME_REQUIRE(dim <= 1024 && ldx % 4 == 0 && ldx >= (dim + 3) / 4 * 4 && (uintptr_t)x % 8 == 0, LIME_ERR_UNSUPPORTED,
+                 "lime_mean_pool_bf16: dim <= 1024, ldx a multiple of 4 and >= dim rounded up to 4, x 8-byte aligned");
+    if (n_seq == 0) return LIME_OK;
+    hipLaunchKernelGGL(mean_pool_bf16_kernel, dim3((unsigned)n_seq), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, out, (long)ldo,
+                       S, dim);
+    return lime_check_launch("lime_mean_pool_bf16");
+}
+
+// ---------------------------------------------------------------------------------------------------
 // multi-copy: blockIdx.y = buffer, blockIdx.x = 16 KB piece of it
 // ---------------------------------------------------------------------------------------------------
 struct CopyTable {

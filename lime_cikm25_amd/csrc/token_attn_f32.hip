@@ -41,6 +41,7 @@ extern "C" void lime_debug_set_attn_stamp_buffer(unsigned long long* p) { g_attn
 
 namespace {
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int LDH = 36;  // pitch of K rows in LDS (floats): conflict-free ds_read_b128
 // V is staged TRANSPOSED, Vt[head dim][key] with pitch SP + 4: accumulator registers 4g .. 4g+3 of a probability tile
 // are keys 32t + 8g + 4*half + 0..3, so the matching A operands of four consecutive PV MFMAs are one ds_read_b128
@@ -50,6 +51,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 struct AttnP {
     const float* q; const float* k; const float* v; long ld; const unsigned char* mask;
     float* out; long ldo; int n_seq, S, n_head, hd, hs; float scale; int n_pair; int vec2; int n_group;
+    int out_pad;         // BF: zero columns written behind the last head (the next GEMM reads K rounded up to 8)
 #ifdef LIME_STAMPS
     unsigned long long* stamps;
 #endif
@@ -83,12 +85,15 @@ __device__ __forceinline__ f32x2 load2(const float* src, long ld, int r, int c, 
 // FAST: S == NT * 32, no key mask, 8-byte loads -- no flag pass, no bounds branches (the title / body shapes of the
 // encoder layers); otherwise the general path with per-key flags.  The score strip never crosses an if-merge: hipcc
 // copies the whole accumulator array at a merge.
-template <int NT, bool FAST>
+// BF (FAST only): q / k / v / out are bf16 (lime_token_attention_bf16); they are widened to fp32 on the way into LDS /
+// the fragments and the products stay on the exact-fp32 MFMA, so scores, softmax and P V are computed as in the fp32 path.
+template <int NT, bool FAST, bool BF = false>
 __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_attn_kernel(const AttnP p) {
+    static_assert(!BF || FAST, "the bf16 variant exists for the FAST shapes only");
     constexpr int G = (NT >= 3) ? 1 : (4 / NT);   // (sequence, head) pairs per group
     constexpr int WPP = 4 / G;                     // waves per pair
     constexpr int SP = NT * 32;                    // padded sequence length
-    constexpr int NLD = FAST ? G * SP * 8 / 256 : G * SP * 16 / 256;   // 16-byte (FAST) / 8-byte loads per thread and operand
+    constexpr int NLD = BF ? G * SP * 4 / 256 : (FAST ? G * SP * 8 / 256 : G * SP * 16 / 256);   // 16-byte (FAST) / 8-byte loads per thread and operand
     constexpr bool PREFETCH = NT == 3 || NT == 4;  // short sequences are latency-bound either way; long ones need the registers
     __shared__ __attribute__((aligned(16))) float Ks[G * SP * LDH];
     constexpr int LDVT = SP + 4;                   // pitch of Vt rows (keys of one head dim)
@@ -112,7 +117,15 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = tid + i * 256;
-            if constexpr (FAST) {
+            if constexpr (BF) {                    // 8 bf16 = 16 bytes per load: four loads cover a 32-column head row
+                const int c = (e & 3) * 8, r = (e >> 2) % SP, g = (e >> 2) / SP;
+                int pair = group * G + g;
+                pair = pair < p.n_pair ? pair : p.n_pair - 1;
+                const int seq = pair / p.n_head, head = pair - seq * p.n_head;
+                const long off = ((long)seq * S + r) * p.ld + head * hs + c;
+                kreg[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned short*>(p.k) + off);
+                vreg[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned short*>(p.v) + off);
+            } else if constexpr (FAST) {
                 const int c = (e & 7) * 4, r = (e >> 3) % SP, g = (e >> 3) / SP;
                 int pair = group * G + g;
                 pair = pair < p.n_pair ? pair : p.n_pair - 1;
@@ -139,7 +152,25 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = tid + i * 256;
-            if constexpr (FAST) {
+            if constexpr (BF) {
+                const int c = (e & 3) * 8, r = (e >> 2) % SP, g = (e >> 2) / SP;
+                u32x4 kb = __builtin_bit_cast(u32x4, kreg[i]), vb = __builtin_bit_cast(u32x4, vreg[i]);
+                if (group * G + g >= p.n_pair) { kb = u32x4{0u, 0u, 0u, 0u}; vb = kb; }
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    f32x4 kf;
+                    kf[0] = __builtin_bit_cast(float, kb[2 * h2] << 16);
+                    kf[1] = __builtin_bit_cast(float, kb[2 * h2] & 0xFFFF0000u);
+                    kf[2] = __builtin_bit_cast(float, kb[2 * h2 + 1] << 16);
+                    kf[3] = __builtin_bit_cast(float, kb[2 * h2 + 1] & 0xFFFF0000u);
+                    *reinterpret_cast<f32x4*>(&Ks[(g * SP + r) * LDH + c + 4 * h2]) = kf;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned w = vb[j >> 1];
+                    Vs[(g * 32 + c + j) * LDVT + r] = __builtin_bit_cast(float, (j & 1) ? (w & 0xFFFF0000u) : (w << 16));
+                }
+            } else if constexpr (FAST) {
                 const int c = (e & 7) * 4, r = (e >> 3) % SP, g = (e >> 3) / SP;
                 f32x4 kv = kreg[i], vv = vreg[i];
                 if (group * G + g >= p.n_pair) { kv = f32x4{0.f, 0.f, 0.f, 0.f}; vv = kv; }
@@ -178,7 +209,19 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
     q_t qraw[NQ], qnext[NQ];
     auto q_rows = [&](int grp, int qt, q_t* dst) {
         int pr = grp * G + g;
-        if constexpr (FAST) {                         // S == NT * 32: every query row exists
+        if constexpr (BF) {                           // four 8-byte loads of 4 bf16, widened
+            pr = pr < p.n_pair ? pr : p.n_pair - 1;
+            const int sq = pr / p.n_head, hh = pr - sq * p.n_head;
+            const unsigned short* qsrc = reinterpret_cast<const unsigned short*>(p.q) + ((long)sq * S + qt * 32 + fi) * p.ld + hh * hs + fh * 4;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const uint2 w = *reinterpret_cast<const uint2*>(qsrc + kk * 8);
+                f32x4 f;
+                f[0] = __builtin_bit_cast(float, w.x << 16); f[1] = __builtin_bit_cast(float, w.x & 0xFFFF0000u);
+                f[2] = __builtin_bit_cast(float, w.y << 16); f[3] = __builtin_bit_cast(float, w.y & 0xFFFF0000u);
+                dst[kk] = f;
+            }
+        } else if constexpr (FAST) {                  // S == NT * 32: every query row exists
             pr = pr < p.n_pair ? pr : p.n_pair - 1;
             const int sq = pr / p.n_head, hh = pr - sq * p.n_head;
             const float* qsrc = p.q + ((long)sq * S + qt * 32 + fi) * p.ld + hh * hs + fh * 4;
@@ -309,7 +352,23 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) scr[fi * LDO + (r & 3) + 8 * (r >> 2) + krow] = o[r] * inv;
                 lds_fence();
-                if (fi < hd) {
+                if constexpr (BF) {
+                    unsigned short* ob = reinterpret_cast<unsigned short*>(p.out);
+                    if (fi < hd) {
+#pragma unroll
+                        for (int it = 0; it < 16; ++it) {
+                            const int row = it * 2 + fh;
+                            unsigned u = __builtin_bit_cast(unsigned, scr[row * LDO + fi]);
+                            u += 0x7FFFu + ((u >> 16) & 1u);                                       // round to nearest even
+                            ob[((long)seq * S + qt * 32 + row) * p.ldo + head * hd + fi] = (unsigned short)(u >> 16);
+                        }
+                    }
+                    if (head == p.n_head - 1 && fi < p.out_pad) {                                  // zero columns behind the last head
+#pragma unroll
+                        for (int it = 0; it < 16; ++it)
+                            ob[((long)seq * S + qt * 32 + it * 2 + fh) * p.ldo + p.n_head * hd + fi] = (unsigned short)0;
+                    }
+                } else if (fi < hd) {
 #pragma unroll
                     for (int it = 0; it < 16; ++it) {
                         const int row = it * 2 + fh;
@@ -340,6 +399,17 @@ int attn_num_cus() {
         if (n <= 0) n = 256;
     }
     return n;
+}
+
+template <int NT>
+int launch_bf16(AttnP p, hipStream_t s) {
+    constexpr int G = (NT >= 3) ? 1 : (4 / NT);
+    p.n_group = (p.n_pair + G - 1) / G;
+    const int per_cu = NT <= 2 ? 3 : (NT <= 4 ? 2 : 1);
+    long blocks = (long)attn_num_cus() * per_cu;
+    if (blocks > p.n_group) blocks = p.n_group;
+    hipLaunchKernelGGL((token_attn_kernel<NT, true, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    return lime_check_launch("lime_token_attention_bf16");
 }
 
 template <int NT>
@@ -378,7 +448,7 @@ extern "C" int lime_token_attention_f32(const float* q, const float* k, const fl
     // 8-byte loads need an even head_dim and leading dimension and 8-byte aligned bases
     const int vec2 = (head_dim % 2 == 0) && (head_stride % 2 == 0) && (ld_qkv % 2 == 0) &&
                      (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 8 == 0);
-    AttnP p{q, k, v, (long)ld_qkv, key_mask, out, (long)ldo, n_seq, S, n_head, head_dim, head_stride, scale, n_seq * n_head, vec2, 0};
+    AttnP p{q, k, v, (long)ld_qkv, key_mask, out, (long)ldo, n_seq, S, n_head, head_dim, head_stride, scale, n_seq * n_head, vec2, 0, 0};
     hipStream_t s = (hipStream_t)stream;
     const int nt = (S + 31) / 32;
     if (nt <= 1) return launch<1>(p, s);
@@ -387,4 +457,30 @@ extern "C" int lime_token_attention_f32(const float* q, const float* k, const fl
     if (nt <= 4) return launch<4>(p, s);
     if (nt <= 8) return launch<8>(p, s);
     return launch<16>(p, s);
+}
+
+extern "C" int lime_token_attention_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ld_qkv, uint16_t* out,
+                                         int64_t ldo, int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim, float scale,
+                                         int32_t out_cols, void* stream) {
+    LIME_REQUIRE(q && k && v && out, LIME_ERR_BAD_ARG, "lime_token_attention_bf16: NULL pointer");
+    LIME_REQUIRE(n_seq >= 0 && S > 0 && n_head > 0 && head_dim > 0 && head_dim <= 32, LIME_ERR_BAD_ARG,
+                 "lime_token_attention_bf16: bad dims n_seq=%d S=%d n_head=%d head_dim=%d", n_seq, S, n_head, head_dim);
+    LIME_REQUIRE(S == 32 || S == 64 || S == 128 || S == 256 || S == 512, LIME_ERR_UNSUPPORTED,
+                 "lime_token_attention_bf16: S must be 32, 64, 128, 256 or 512 (got %d)", S);
+    LIME_REQUIRE(ld_qkv >= (int64_t)n_head * 32 && ld_qkv % 8 == 0 && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0),
+                 LIME_ERR_BAD_ARG, "lime_token_attention_bf16: heads are 32 bf16 columns apart, rows 16-byte aligned");
+    const int pad = out_cols - n_head * head_dim;
+    LIME_REQUIRE(pad >= 0 && pad <= 32 && ldo >= out_cols, LIME_ERR_BAD_ARG,
+                 "lime_token_attention_bf16: out_cols must be in [n_head * head_dim, n_head * head_dim + 32] and <= ldo");
+    if (n_seq == 0) return LIME_OK;
+    AttnP p{(const float*)q, (const float*)k, (const float*)v, (long)ld_qkv, nullptr, (float*)out, (long)ldo, n_seq, S, n_head,
+            head_dim, 32, scale, n_seq * n_head, 1, 0, pad};
+    hipStream_t s = (hipStream_t)stream;
+    switch (S / 32) {
+        case 1: return launch_bf16<1>(p, s);
+        case 2: return launch_bf16<2>(p, s);
+        case 4: return launch_bf16<4>(p, s);
+        case 8: return launch_bf16<8>(p, s);
+        default: return launch_bf16<16>(p, s);
+    }
 }

@@ -336,6 +336,51 @@ def encode_tokens(ids, table, pe, transformer, nhead):
     return x
 
 
+def encode_tokens_bf16(ids, table_bf16, pe, transformer, nhead, pooled_out):
+    """encode_tokens + mean pool on the bf16 matrix cores (BASELINE config 3).
+
+    table_bf16: the word table converted with ``ops.to_bf16`` ([V, E rounded up to 8], zero padded).  Activations between
+    the launches are bf16; accumulation, bias, residual adds, softmax and LayerNorm are fp32.  E = 300 is carried as 304
+    columns (zero weights / bias / gamma / beta in the pad, so the pad stays exactly zero through the layer).
+    """
+    M, S = ids.shape
+    EP = table_bf16.shape[1]
+    E = pe.shape[1]
+    hd = E // nhead
+    if hd > 32 or S % 32 != 0:
+        raise NotImplementedError('the bf16 encoder path needs head_dim <= 32 and S a multiple of 32 (got %d, %d)' % (hd, S))
+    W = nhead * 32
+    flat = ids.reshape(-1)
+    dev = ids.device
+    padv = lambda v: torch.cat([v, v.new_zeros(EP - E)])
+    x = None
+    for li, layer in enumerate(transformer.layers):
+        sa = layer.self_attn
+        w_in = ops.pad_heads(sa.in_proj_weight, 3 * nhead, hd, 32)                  # fp32 [3W, E]
+        b_in = ops.pad_heads(sa.in_proj_bias, 3 * nhead, hd, 32)
+        w_in_b = ops.to_bf16(w_in, cols_out=EP)
+        if li == 0:
+            pew = ops.linear(pe[:S], w_in, b_in)                                     # fp32 [S, 3W]: positional term + bias
+            qkv = ops.linear_bf16(table_bf16, w_in_b, None, a_ids=flat, res=pew, res_kind=1, res_mod=S)
+        else:
+            qkv = ops.linear_bf16(x, w_in_b, b_in)
+        attn = ops.token_attention_bf16(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, 1.0 / math.sqrt(hd), out_cols=EP)
+        w_o = ops.to_bf16(sa.out_proj.weight, rows_out=EP, cols_out=EP)
+        ln1 = (padv(layer.norm1.weight), padv(layer.norm1.bias))
+        if li == 0:
+            pe_p = torch.cat([pe[:S], pe.new_zeros(S, EP - E)], dim=1)
+            x1 = ops.linear_bf16(attn, w_o, padv(sa.out_proj.bias), res=table_bf16, res_kind=2, res_ids=flat, res_pe=pe_p,
+                                 res_period=S, ln=ln1, ln_eps=layer.norm1.eps, ln_count=E)
+        else:
+            x1 = ops.linear_bf16(attn, w_o, padv(sa.out_proj.bias), res=x, res_kind=3, ln=ln1, ln_eps=layer.norm1.eps, ln_count=E)
+        h = ops.linear_bf16(x1, ops.to_bf16(layer.linear1.weight, cols_out=EP), layer.linear1.bias, act='relu')
+        x = ops.linear_bf16(h, ops.to_bf16(layer.linear2.weight, rows_out=EP), padv(layer.linear2.bias), res=x1, res_kind=3,
+                            ln=(padv(layer.norm2.weight), padv(layer.norm2.bias)), ln_eps=layer.norm2.eps, ln_count=E)
+    if transformer.norm is not None:
+        raise NotImplementedError('a final encoder norm is not used by the reference (newsEncoders.py:245,247)')
+    return ops.mean_pool_bf16(x, M, S, E, out=pooled_out)
+
+
 class CROWN(NewsEncoder):
     """newsEncoders.py:228-373: title/body transformer encoders, mean pooling, category-aware k-intent
     disentanglement, intent attention, title-body similarity, feature fusion.  -> [B, n, 900]."""
@@ -344,6 +389,9 @@ class CROWN(NewsEncoder):
         super().__init__(config)
         self.max_title_length = config.max_title_length
         self.max_body_length = config.max_abstract_length
+        self.compute_dtype = getattr(config, 'compute_dtype', 'fp32')            # 'fp32' | 'bf16' (not a reference option)
+        if self.compute_dtype not in ('fp32', 'bf16'):
+            raise ValueError('compute_dtype must be fp32 or bf16')
         self.max_history_num = config.max_history_num
         self.category_embedding_dim = config.category_embedding_dim
         self.intent_embedding_dim = config.intent_embedding_dim
@@ -397,10 +445,11 @@ class CROWN(NewsEncoder):
         ldx = (kin + 3) // 4 * 4                                   # 352: keeps the rows 16-byte aligned
         # rows [0, M): [title_pooled | category_rep], rows [M, 2M): [body_pooled | category_rep]   (:343-344)
         xin = torch.empty((2 * M, ldx), dtype=torch.float32, device=dev)
-        # The title and body encoders are independent chains of five GEMM / attention launches each.  They run on two
-        # streams: every launch is a persistent grid of one workgroup per CU, so the second chain's workgroups move in as
-        # the first chain's last, partially filled round of tiles drains (the title GEMMs have only 1.7 .. 5.2 tiles per
-        # CU: up to 14 % of a launch is such a tail).
+        # The title and body encoders are independent chains of five GEMM / attention launches each (optionally on two
+        # streams, see SERIAL_STREAMS).
+        bf16 = self.compute_dtype == 'bf16'
+        if bf16:                                                   # the word table in bf16, rows padded to 8 columns
+            table_b = ops.to_bf16(table, cols_out=(E + 7) // 8 * 8)
         main = torch.cuda.current_stream()
         side = _side_stream(dev, 1)
         side.wait_stream(main)
@@ -410,6 +459,10 @@ class CROWN(NewsEncoder):
             with torch.cuda.stream(side if half == 0 else main):
                 for m0 in range(0, M, step):
                     m1 = min(M, m0 + step)
+                    if bf16:
+                        encode_tokens_bf16(ids[m0:m1], table_b, pos.table(), tr, self.head_num,
+                                           xin[half * M + m0:half * M + m1, :E])
+                        continue
                     y = encode_tokens(ids[m0:m1], table, pos.table(), tr, self.head_num)                 # :311-320
                     ops.mean_pool(y, m1 - m0, S, out=xin[half * M + m0:half * M + m1, :E])                # :317,:321
         main.wait_stream(side)

@@ -386,3 +386,110 @@ def multi_copy(pairs):
             d.src, d.dst, d.bytes = src.data_ptr(), dst.data_ptr(), dst.numel() * dst.element_size()
         check(lib.lime_multi_copy(table, len(part), _stream()), 'lime_multi_copy')
     return todo            # keeps the sources referenced until the caller drops the list (the copy is asynchronous)
+
+
+# ---- bf16 matrix-core path (BASELINE config 3) ---------------------------------------------------------------------------
+def to_bf16(src, rows_out=None, cols_out=None, out=None):
+    """fp32 [rows, cols] (or a vector) -> bf16 [rows_out, cols_out], zero padded; cols_out a multiple of 4."""
+    lib = _lib.load()
+    vec = src.dim() == 1
+    s2 = src.view(-1, 1) if vec else src
+    _mat(s2, 'src')
+    rows, cols = s2.shape
+    if vec:                                       # a vector is padded along its only axis
+        s2 = src.view(1, -1)
+        rows, cols = 1, src.numel()
+        rows_out = 1
+    rows_out = rows if rows_out is None else rows_out
+    cols_out = (cols + 7) // 8 * 8 if cols_out is None else cols_out
+    if out is None:
+        out = torch.empty((rows_out, cols_out), dtype=torch.bfloat16, device=src.device)
+    _mat(out, 'out', dtype=torch.bfloat16)
+    check(lib.lime_to_bf16(_p(s2), _ld(s2), rows, cols, _p(out), _ld(out), rows_out, cols_out, _stream()), 'lime_to_bf16')
+    return out.view(-1) if vec else out
+
+
+def linear_bf16(a, w, bias=None, act=None, out=None, a_ids=None, res=None, res_kind=0, res_mod=0, res_ids=None, res_pe=None,
+                res_period=0, ln=None, ln_eps=1e-5, ln_count=None):
+    """``lime_linear_bf16``: a / w / out (and residual kinds 2, 3) bfloat16, bias / LayerNorm / residual kind 1 fp32."""
+    lib = _lib.load()
+    _mat(a, 'a', dtype=torch.bfloat16)
+    _mat(w, 'w', dtype=torch.bfloat16)
+    N, K = w.shape
+    if a.shape[1] != K:
+        raise ValueError('a has %d columns, w has K=%d' % (a.shape[1], K))
+    M = a_ids.numel() if a_ids is not None else a.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    _mat(out, 'out', dtype=torch.bfloat16)
+    if tuple(out.shape) != (M, N):
+        raise ValueError('out must be [%d, %d], got %s' % (M, N, tuple(out.shape)))
+    args = _lib.LinearBf16Args()
+    args.a, args.lda = a.data_ptr(), _ld(a)
+    args.a_ids = _vec(a_ids, 'a_ids', dtype=torch.int32).data_ptr() if a_ids is not None else None
+    args.w, args.ldw = w.data_ptr(), _ld(w)
+    args.bias = _vec(bias, 'bias', N).data_ptr() if bias is not None else None
+    if res is not None:
+        if res_kind not in (1, 2, 3):
+            raise ValueError('res_kind must be 1 (fp32 rows), 2 (gathered bf16 rows) or 3 (bf16 rows)')
+        _mat(res, 'res', dtype=torch.float32 if res_kind == 1 else torch.bfloat16)
+        if res.shape[1] != N:
+            raise ValueError('res must have N=%d columns' % N)
+        args.res, args.ldr, args.res_kind, args.res_mod = res.data_ptr(), _ld(res), res_kind, res_mod
+        if res_kind == 1 and res.shape[0] < (res_mod if res_mod > 0 else M):
+            raise ValueError('res has too few rows')
+        if res_kind == 3 and res.shape[0] < M:
+            raise ValueError('res has too few rows')
+        if res_kind == 2:
+            args.res_ids = _vec(res_ids, 'res_ids', M, dtype=torch.int32).data_ptr()
+            if res_pe is not None:
+                _mat(res_pe, 'res_pe')
+                if res_pe.shape[1] != N or res_pe.shape[0] < res_period or res_period <= 0:
+                    raise ValueError('res_pe must be [>=res_period, N]')
+                args.res_pe, args.ldr_pe, args.res_period = res_pe.data_ptr(), _ld(res_pe), res_period
+    if ln is not None:
+        args.ln_gamma = _vec(ln[0], 'ln gamma', N).data_ptr()
+        args.ln_beta = _vec(ln[1], 'ln beta', N).data_ptr()
+        args.ln_eps, args.ln_count = ln_eps, (N if ln_count is None else ln_count)
+    args.c, args.ldc = out.data_ptr(), _ld(out)
+    args.M, args.N, args.K = M, N, K
+    args.act = LIME_ACT[act]
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.lime_linear_bf16(ctypes.byref(args), _stream()), 'lime_linear_bf16')
+        e1.record()
+        PROFILE.append((lib.lime_last_linear_kernel().decode(), M, N, K, e0, e1))
+        return out
+    check(lib.lime_linear_bf16(ctypes.byref(args), _stream()), 'lime_linear_bf16')
+    return out
+
+
+def mean_pool_bf16(x, n_seq, S, dim, out=None):
+    lib = _lib.load()
+    _mat(x, 'x', dtype=torch.bfloat16)
+    if x.shape[0] != n_seq * S:
+        raise ValueError('x must have n_seq * S rows')
+    if out is None:
+        out = torch.empty((n_seq, dim), dtype=torch.float32, device=x.device)
+    _mat(out, 'out')
+    check(lib.lime_mean_pool_bf16(_p(x), _ld(x), _p(out), _ld(out), n_seq, S, dim, _stream()), 'lime_mean_pool_bf16')
+    return out
+
+
+def token_attention_bf16(q, k, v, n_seq, S, n_head, head_dim, scale, out_cols=None, out=None):
+    """Unmasked encoder attention on bf16 storage: q / k / v [n_seq * S, n_head * 32] bf16 views of one qkv buffer."""
+    lib = _lib.load()
+    for t, name in ((q, 'q'), (k, 'k'), (v, 'v')):
+        _mat(t, name, dtype=torch.bfloat16)
+        if t.shape[0] != n_seq * S or t.shape[1] != n_head * 32:
+            raise ValueError('%s must be [n_seq * S, n_head * 32]' % name)
+    if not (_ld(q) == _ld(k) == _ld(v)):
+        raise ValueError('q, k, v must share one leading dimension')
+    out_cols = n_head * head_dim if out_cols is None else out_cols
+    if out is None:
+        out = torch.empty((n_seq * S, out_cols), dtype=torch.bfloat16, device=q.device)
+    _mat(out, 'out', dtype=torch.bfloat16)
+    check(lib.lime_token_attention_bf16(_p(q), _p(k), _p(v), _ld(q), _p(out), _ld(out), n_seq, S, n_head, head_dim, scale, out_cols,
+                                        _stream()), 'lime_token_attention_bf16')
+    return out

@@ -150,10 +150,10 @@ def test_linear_pp_residual_layernorm(ops, M, N, K):
     a, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3), rnd(M, N, seed=4)
     g, be = rnd(N, seed=5) + 1.5, rnd(N, seed=6)
     got = ops.linear(dev(a), dev(w), dev(b), res=dev(r), ln=(dev(g), dev(be)))
-    assert last_kernel() == 'gemm_pp_kernel<10, true, false, 1>', last_kernel()
+    assert last_kernel() == 'gemm_pp_kernel<10, true, false, 1, false>', last_kernel()
     check(got, O.layer_norm(r + a @ w.t() + b, g, be), what='pp res + LN')
     got = ops.linear(dev(a), dev(w), dev(b), ln=(dev(g), dev(be)))
-    assert last_kernel() == 'gemm_pp_kernel<10, true, false, 0>', last_kernel()
+    assert last_kernel() == 'gemm_pp_kernel<10, true, false, 0, false>', last_kernel()
     check(got, O.layer_norm(a @ w.t() + b, g, be), what='pp LN')
     got = ops.linear(dev(a), dev(w), dev(b), res=dev(r))
     assert last_kernel().startswith('gemm_pp_kernel'), last_kernel()
@@ -188,7 +188,7 @@ def test_linear_pp_gathered_residual_layernorm(ops, M, S):
     g, be = rnd(N, seed=12) + 1.5, rnd(N, seed=13)
     got = ops.linear(dev(attn), dev(w), dev(b), res=dev(table), res_ids=dev(ids), res_pe=dev(pe), res_period=S,
                      ln=(dev(g), dev(be)))
-    assert last_kernel() == 'gemm_pp_kernel<10, true, false, 2>', last_kernel()
+    assert last_kernel() == 'gemm_pp_kernel<10, true, false, 2, false>', last_kernel()
     check(got, O.layer_norm(x + attn @ w.t() + b, g, be), what='pp gather residual + LN')
 
 
@@ -476,3 +476,98 @@ def test_multi_copy(ops):
         assert torch.equal(d, s)
     with pytest.raises(ValueError):
         ops.multi_copy([(dsts[0], srcs[1])])
+
+
+# ---------------------------------------------------------------------------------------------------
+# bf16 matrix-core path (BASELINE config 3).  Reference: the same operands rounded to bf16, fp32 arithmetic, result
+# rounded to bf16 -- so the only differences are accumulation order and double rounding: tolerance 2 bf16 ulps (1.6e-2
+# relative to the row scale, observed ~4e-3).
+# ---------------------------------------------------------------------------------------------------
+BF_TOL = 1.6e-2
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize('M,N,K', [(4096, 512, 304), (5003, 960, 304), (300, 256, 64), (4100, 304, 512), (4097, 640, 1000), (33, 320, 304)])
+@pytest.mark.parametrize('act', [None, 'relu'])
+def test_linear_bf16_plain(ops, M, N, K, act):
+    a, w, b = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=1 / math.sqrt(K))), rnd(N, seed=3)
+    want = a.float() @ w.float().t() + b
+    if act == 'relu':
+        want = torch.relu(want)
+    got = ops.linear_bf16(dev(a), dev(w), dev(b), act=act)
+    assert got.dtype == torch.bfloat16 and last_kernel().endswith('true>'), last_kernel()
+    check(got.float(), bf(want).float(), tol=BF_TOL, what='bf16 linear %s' % ((M, N, K, act),))
+
+
+def test_to_bf16_pads_and_rounds(ops):
+    x = rnd(37, 300, seed=4)
+    got = ops.to_bf16(dev(x), rows_out=40, cols_out=304).cpu()
+    want = torch.zeros(40, 304, dtype=torch.bfloat16)
+    want[:37, :300] = bf(x)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    v = ops.to_bf16(dev(rnd(300, seed=5)), cols_out=304).cpu()
+    assert v.shape == (304,) and torch.equal(v[:300].view(torch.int16), bf(rnd(300, seed=5)).view(torch.int16)) and (v[300:] == 0).all()
+
+
+@pytest.mark.parametrize('M,S', [(4224, 32), (4200, 128)])
+def test_linear_bf16_encoder_layer_gemms(ops, M, S):
+    """The four GEMMs of an encoder layer as the bf16 path issues them (K = N = 300 padded to 304 with zeros)."""
+    V, E, EP, F, W = 600, 300, 304, 512, 960
+    ids = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(6), dtype=torch.int32)
+    table, pe = rnd(V, E, seed=7), rnd(S, E, seed=8)
+    w_in, b_in = rnd(W, E, seed=9, scale=0.06), rnd(W, seed=10)
+    w_o, b_o = rnd(E, E, seed=11, scale=0.06), rnd(E, seed=12)
+    w1, b1 = rnd(F, E, seed=13, scale=0.06), rnd(F, seed=14)
+    w2, b2 = rnd(E, F, seed=15, scale=0.05), rnd(E, seed=16)
+    g1, be1, g2, be2 = rnd(E, seed=17) + 1.5, rnd(E, seed=18), rnd(E, seed=19) + 1.5, rnd(E, seed=20)
+    pad_v = lambda v: dev(torch.cat([v, torch.zeros(EP - E)]))
+    tb = ops.to_bf16(dev(table), cols_out=EP)
+    # in_proj: gathered bf16 rows, fp32 periodic residual (PE W^T + b)
+    pew = (pe @ w_in.t() + b_in)
+    qkv = ops.linear_bf16(tb, ops.to_bf16(dev(w_in), cols_out=EP), None, a_ids=dev(ids), res=dev(pew), res_kind=1, res_mod=S)
+    x_bf = bf(table)[ids.long()].float()
+    want_qkv = x_bf @ bf(w_in).float().t() + pew[torch.arange(M) % S]
+    check(qkv.float(), bf(want_qkv).float(), tol=BF_TOL, what='bf16 in_proj')
+    # out_proj: residual = bf16 table rows + fp32 pe, LayerNorm over the 300 real columns, N padded to 304
+    attn = bf(rnd(M, E, seed=21))
+    attn_p = torch.zeros(M, EP, dtype=torch.bfloat16)
+    attn_p[:, :E] = attn
+    x1 = ops.linear_bf16(dev(attn_p), ops.to_bf16(dev(w_o), rows_out=EP, cols_out=EP), pad_v(b_o), res=tb, res_kind=2,
+                         res_ids=dev(ids), res_pe=dev(torch.cat([pe, torch.zeros(S, EP - E)], dim=1)), res_period=S,
+                         ln=(pad_v(g1), pad_v(be1)), ln_count=E)
+    want_x1 = O.layer_norm(x_bf + pe[torch.arange(M) % S] + attn.float() @ bf(w_o).float().t() + b_o, g1, be1)
+    assert (x1[:, E:] == 0).all()
+    check(x1[:, :E].float(), bf(want_x1).float(), tol=BF_TOL, what='bf16 out_proj + LN')
+    # linear1 (ReLU) and linear2 (bf16 residual + LN)
+    h = ops.linear_bf16(x1, ops.to_bf16(dev(w1), cols_out=EP), dev(b1), act='relu')
+    x1f = x1[:, :E].float().cpu()
+    want_h = torch.relu(x1f @ bf(w1).float().t() + b1)
+    check(h.float(), bf(want_h).float(), tol=BF_TOL, what='bf16 linear1')
+    x2 = ops.linear_bf16(h, ops.to_bf16(dev(w2), rows_out=EP), pad_v(b2), res=x1, res_kind=3, ln=(pad_v(g2), pad_v(be2)), ln_count=E)
+    want_x2 = O.layer_norm(x1f + h.float().cpu() @ bf(w2).float().t() + b2, g2, be2)
+    assert (x2[:, E:] == 0).all()
+    check(x2[:, :E].float(), bf(want_x2).float(), tol=BF_TOL, what='bf16 linear2 + LN')
+    n_seq = M // S
+    pooled = ops.mean_pool_bf16(x2[:n_seq * S], n_seq, S, E)
+    check(pooled, x2[:n_seq * S, :E].float().cpu().view(n_seq, S, E).mean(dim=1), what='bf16 mean pool')
+
+
+@pytest.mark.parametrize('S', [32, 64, 128, 256])
+def test_token_attention_bf16(ops, S):
+    n_seq, h, hd = (23 if S <= 128 else 3), 10, 30
+    E = h * hd
+    qkv = bf(rnd(n_seq * S, 3 * E, seed=S + 7, scale=2.0)).float()
+    pad = torch.zeros(n_seq * S, 3 * h, 32)
+    pad[:, :, :hd] = qkv.view(n_seq * S, 3 * h, hd)
+    d = dev(bf(pad.view(n_seq * S, 3 * h * 32)))
+    W = h * 32
+    scale = 1.0 / math.sqrt(hd)
+    got = ops.token_attention_bf16(d[:, :W], d[:, W:2 * W], d[:, 2 * W:], n_seq, S, h, hd, scale, out_cols=304)
+    assert got.shape == (n_seq * S, 304) and (got[:, E:] == 0).all()
+    check(got[:, :E].float(), bf(attn_ref(qkv, n_seq, S, h, hd, scale)).float(), tol=BF_TOL, what='bf16 attn S=%d' % S)
+    from lime_cikm25_amd._lib import LimeHipError
+    with pytest.raises(LimeHipError):
+        ops.token_attention_bf16(d[:96 * 2, :W], d[:96 * 2, W:2 * W], d[:96 * 2, 2 * W:], 2, 96, h, hd, scale)
