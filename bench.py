@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 (the 5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {
@@ -158,8 +159,9 @@ def main():
             tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.exists(tfile):
                 traffic = json.load(open(tfile)).get(name, {}).get('hbm_bytes_per_launch')
-            roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
-                    'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
+            peak = PEAK_BF16_MFMA_TFLOPS if name.endswith(', true>') else PEAK_F32_MFMA_TFLOPS     # gemm_pp_kernel<..., BF>
+            roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak,
+                    'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': traffic,
                     'launches': cnt, 'avg_launch_us': round(sec / cnt * 1e6, 1), 'flops_per_launch': fl / cnt,
                     'measured': 'HIP events on the launch stream, eager pass of the same %d steps, branches on one stream' % args.steps,
                     'all_gemm_kernels': {k: {'tflops': round(v[0] / v[1] / 1e12, 2), 'avg_launch_us': round(v[1] / v[2] * 1e6, 1),
