@@ -47,10 +47,13 @@ WORKLOADS = {
              'MIND-shape synthetic, batch=256, history=50, title 32 + body 128, K=1+4, bf16 MFMA token encoders with fp32 '
              'accumulate / softmax / LayerNorm (BASELINE.json configs[2])'),
     'cfg2b_bf16': (dict(compute_dtype='bf16'), 32, 5, 'configs[1] shape (batch=32) with the bf16 token encoders of configs[2]'),
+    'cfg5': (dict(batch_size=1024), 1024, 100,
+             'MIND-shape inference, 1024 impressions x K=100 candidates, history=50, title 32 + body 128, scoring only, '
+             'eval-mode (per-candidate) semantics with every history encoded once (BASELINE.json configs[4]), fp32'),
 }
 
 
-def flops_per_impression(cfg, N):
+def flops_per_impression(cfg, N, per_candidate_user_side=False):
     """Algorithmic FLOPs of one impression row (GEMM FLOPs = 2 m n k)."""
     H, T, L = cfg.max_history_num, cfg.max_title_length, cfg.max_abstract_length
 
@@ -61,8 +64,10 @@ def flops_per_impression(cfg, N):
         news = seq(T) + seq(L) + tail
     else:   # MHSA, title only
         news = T * 360000 + T * T * 800 + T * 160800 + T * 400 + 600000 + 480000
-    user = 50000 * (H + N) + 2400 * N * H + 960000 * H + 320800 * N + 320000
-    return (H + N) * news + user
+    user = lambda n: 50000 * (H + n) + 2400 * n * H + 960000 * H + 320800 * n + 320000
+    if per_candidate_user_side:            # eval semantics: every candidate is its own N = 1 row of the user encoder
+        return (H + N) * news + N * user(1)
+    return (H + N) * news + user(N)
 
 
 def main():
@@ -106,6 +111,15 @@ def main():
     model.training = True                        # [B, K] candidates; every child in eval mode
     batch_cpu = synth.make_batch(cfg, B, N, seed=100 + rank)
     batch = [v.cuda() for v in batch_cpu.values()]
+    step = lambda: model(*batch)
+    if args.workload == 'cfg5':                  # Model.score_impressions: eval semantics, histories encoded once (eager)
+        model.training = False
+        c = {k: v.cuda() for k, v in batch_cpu.items()}
+        sargs = [c[k] for k in ('user_category', 'user_subCategory', 'user_title_text', 'user_title_mask', 'user_content_text',
+                                'user_freshness', 'user_user_topic_lifetime', 'user_history_mask', 'news_category',
+                                'news_subCategory', 'news_title_text', 'news_title_mask', 'news_content_text', 'news_freshness',
+                                'news_user_topic_lifetime', 'remaining_lifetime')]
+        step = lambda: model.score_impressions(*sargs)
 
     def barrier():
         torch.cuda.synchronize()
@@ -115,11 +129,11 @@ def main():
 
     # The forward's ~75 launches are replayed from a HIP graph captured on the first call (Model.use_graph).
     for _ in range(args.warmup):
-        logits = model(*batch)
+        logits = step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        logits = model(*batch)
+        logits = step()
     barrier()
     dt = time.perf_counter() - t0
     dt = D.max_over_ranks(dt, device='cuda')                     # the slowest rank's time
@@ -133,7 +147,7 @@ def main():
         ops.PROFILE = prof
         newsEncoders.SERIAL_STREAMS = True
         for _ in range(args.steps):
-            model(*batch)
+            step()
         torch.cuda.synchronize()
         newsEncoders.SERIAL_STREAMS = not args.overlap_streams
         ops.PROFILE = None
@@ -142,7 +156,7 @@ def main():
 
     if rank == 0:
         value = world * B * args.steps / dt
-        fimp = flops_per_impression(cfg, N)
+        fimp = flops_per_impression(cfg, N, per_candidate_user_side=args.workload == 'cfg5')
         # dominant kernel = the gemm_f32_kernel instantiation with the largest total time (out_proj + linear2 of both
         # encoders: 128x320 tiles, residual in the accumulators, LayerNorm epilogue)
         by_kernel = {}
@@ -179,7 +193,7 @@ def main():
             'end_to_end': {'flops_per_impression': fimp, 'achieved_tflops': round(value * fimp / 1e12, 2),
                            'frac_of_f32_mfma_peak': round(value * fimp / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload != 'cfg5':
             from oracle import lime_oracle
             # the GPU box gives one GPU's share of the host: 16 cores (more threads only oversubscribe)
             ncore = min(len(os.sched_getaffinity(0)), 16)

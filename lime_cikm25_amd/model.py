@@ -129,6 +129,50 @@ class Model(nn.Module):
             out.append(buf[base + offs[i]:base + offs[i] + nbytes].view(t.dtype).view(t.shape))
         return out
 
+    @torch.no_grad()
+    def score_impressions(self, user_category, user_subCategory, user_title_text, user_title_mask, user_content_text,
+                          user_freshness, user_user_topic_lifetime, user_history_mask, news_category, news_subCategory,
+                          news_title_text, news_title_mask, news_content_text, news_freshness, news_user_topic_lifetime,
+                          remaining_lifetime, n_src=None, rows_per_pass=16384):
+        """Scoring-only layout of BASELINE config 5: B impressions with K candidates each -> logits [B, K] with the
+        reference's EVAL semantics (util.py:86-111: every (impression, candidate) pair is its own row with N = 1, Q16),
+        but every history is encoded ONCE instead of once per candidate.
+
+        user_* [B, H, ...], news_* [B, K, ...] (news_user_topic_lifetime may be [B] or [B, K]), remaining_lifetime [B, K].
+        ``n_src``: the GraphSAGE closed form averages over the first n_src node slots, and the reference takes n_src =
+        rows of the forward, i.e. its eval batch size (Q7); default: B * K capped at H + config.batch_size, which is what
+        one reference forward over all pairs would use.  The result equals ``forward`` in eval mode on the B * K expanded
+        rows (tested), the history encoder just runs B * H instead of B * K * H times.
+        """
+        B, K = news_category.shape
+        H = user_category.shape[1]
+        ne, ue = self.news_encoder, self.user_encoder
+        if news_user_topic_lifetime.dim() == 1:
+            news_user_topic_lifetime = news_user_topic_lifetime.unsqueeze(1).expand(B, K)
+        if news_freshness.dim() == 1:
+            news_freshness = news_freshness.unsqueeze(1).expand(B, K)
+        cand, hist = ne.encode_many([
+            (news_title_text, news_title_mask, news_content_text, news_category, news_subCategory, news_freshness.contiguous(),
+             news_user_topic_lifetime.contiguous()),
+            (user_title_text, user_title_mask, user_content_text, user_category, user_subCategory, user_freshness,
+             user_user_topic_lifetime)])                                              # [B, K, D], [B, H, D]
+        rows = B * K
+        if n_src is None:
+            n_src = min(rows, H + ue.user_node_embedding.shape[0])
+        out = torch.empty((B, K), dtype=torch.float32, device=cand.device)
+        per = max(1, rows_per_pass // K)                                              # impressions per pass
+        rl = remaining_lifetime.float()
+        for b0 in range(0, B, per):
+            b1 = min(B, b0 + per)
+            n = (b1 - b0) * K
+            rep = lambda t: t[b0:b1].repeat_interleave(K, dim=0)                      # history side: one copy per candidate row
+            _, logits = ue.match(rep(hist), news_category[b0:b1].reshape(n, 1), news_subCategory[b0:b1].reshape(n, 1),
+                                 rep(user_category), rep(user_subCategory), rep(user_history_mask),
+                                 cand[b0:b1].reshape(n, 1, -1), remaining_lifetime=rl[b0:b1].reshape(n, 1),
+                                 weighting=self.remaining_lifetime_weighting, n_src=n_src)
+            out[b0:b1] = logits.view(b1 - b0, K)
+        return out
+
     def _forward_impl(self, user_ID, user_category, user_subCategory, user_title_text, user_title_mask, user_title_entity,
                       user_content_text, user_content_mask, user_content_entity, user_freshness, user_user_topic_lifetime,
                       user_history_mask, user_history_graph, user_history_category_mask, user_history_category_indices,

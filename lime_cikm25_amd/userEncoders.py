@@ -119,12 +119,13 @@ class CROWN(UserEncoder):
         return self.candidate_aware_attn.attention_weights(hist_topic, cand_topic, user_history_mask)
 
     def match(self, history_embedding, category, subCategory, user_category, user_subCategory, user_history_mask,
-              candidate_news_representation, remaining_lifetime=None, weighting=None, agg=None):
+              candidate_news_representation, remaining_lifetime=None, weighting=None, agg=None, n_src=None):
         """Everything after the history has been encoded (userEncoders.py:103-105, :114-169).
 
         Returns (user_representation [B, N, D], logits [B, N] or None).  With ``weighting`` (the model's
         RemainingLifetimeWeighting) the dot-product match and the lifetime weight are fused into the last kernel.
-        ``agg``: precomputed ``attention_weights(...)``.
+        ``agg``: precomputed ``attention_weights(...)``.  ``n_src``: how many node slots the GraphSAGE mean runs over
+        (Q7: the reference uses the number of rows of the forward; default B).
         """
         if self.training and self.dropout_rate > 0:
             raise NotImplementedError('training-mode dropout on user_node_embedding (userEncoders.py:121) is not implemented')
@@ -135,7 +136,8 @@ class CROWN(UserEncoder):
             if agg is None:
                 agg = self.attention_weights(category, subCategory, user_category, user_subCategory, user_history_mask)
             history_embedding = self.candidate_aware_attn.refine(history_embedding, agg)
-        g = self.graph_sage.forward_closed_form(history_embedding, self.user_node_embedding, n_src=B)       # :121,:151-157
+        g = self.graph_sage.forward_closed_form(history_embedding, self.user_node_embedding,
+                                                n_src=B if n_src is None else n_src)                          # :121,:151-157
         kp = ops.linear(g.view(B * H, D), self.K.weight, None)                                               # :161
         qp = ops.linear(cand.view(B * N, D), self.Q.weight, self.Q.bias)                                     # :162
         w = weighting

@@ -215,6 +215,43 @@ def test_bf16_path_against_oracle(full_size):
     assert abs(aucs[0] - aucs[1]) <= 0.02
 
 
+def test_score_impressions_equals_eval_forward_on_expanded_rows():
+    """BASELINE config 5 layout: B impressions x K candidates scored with every history encoded once.  The result must be
+    the reference's eval-mode function of the B * K (impression, candidate) rows (util.py:86-111): equal to this model's
+    eval forward on the expanded rows, and within tolerance of the oracle's eval forward."""
+    cfg = make_config(max_history_num=10, max_title_length=16, max_abstract_length=32, batch_size=64, vocabulary_size=5000)
+    model, sd = gpu_model(cfg, seed=41)
+    B, K = 5, 6
+    batch = synth.make_batch(cfg, B, K, seed=42)
+    c = {k: v.cuda() for k, v in batch.items()}
+    model.eval()
+    got = model.score_impressions(c['user_category'], c['user_subCategory'], c['user_title_text'], c['user_title_mask'],
+                                  c['user_content_text'], c['user_freshness'], c['user_user_topic_lifetime'], c['user_history_mask'],
+                                  c['news_category'], c['news_subCategory'], c['news_title_text'], c['news_title_mask'],
+                                  c['news_content_text'], c['news_freshness'], c['news_user_topic_lifetime'], c['remaining_lifetime'])
+    assert got.shape == (B, K)
+    # the reference's layout: one row per (impression, candidate), history repeated, candidate tensors without the N axis
+    exp = type(batch)()
+    for k, v in batch.items():
+        if k.startswith('news_') or k == 'remaining_lifetime':
+            exp[k] = v.reshape((B * K,) + tuple(v.shape[2:]))
+        else:
+            exp[k] = v.repeat_interleave(K, dim=0)
+    model.use_graph = False
+    ref_rows = run(model, exp, True)
+    # (not bitwise: the two layouts cross the M >= 4096 threshold between the two GEMM kernels, whose k order differs)
+    assert rel_err(got.cpu().reshape(-1).numpy(), ref_rows.reshape(-1).numpy()) < 2e-5
+    want = O.model_forward(sd, cfg, exp, eval_shape=True).reshape(-1)
+    assert rel_err(got.cpu().reshape(-1).numpy(), want.numpy()) < TOL
+    # chunked passes give the same numbers
+    again = model.score_impressions(c['user_category'], c['user_subCategory'], c['user_title_text'], c['user_title_mask'],
+                                    c['user_content_text'], c['user_freshness'], c['user_user_topic_lifetime'], c['user_history_mask'],
+                                    c['news_category'], c['news_subCategory'], c['news_title_text'], c['news_title_mask'],
+                                    c['news_content_text'], c['news_freshness'], c['news_user_topic_lifetime'], c['remaining_lifetime'],
+                                    rows_per_pass=2 * K)
+    assert torch.equal(again, got)
+
+
 def test_eval_harness_on_gpu(tmp_path):
     """compute_scores (util.py:77-129) with the HIP model on eval-shaped rows: the rank file equals the one built from
     the oracle's scores wherever those are separated beyond the tolerance, and the four metrics agree."""
