@@ -155,8 +155,8 @@ int lime_token_attention_f32(const float* q, const float* k, const float* v, int
 /*
  * lime_token_attention_bf16: the unmasked encoder-layer attention on bf16 storage (config 3): q / k / v bf16 with every
  * head at 32 columns (64-byte head rows), out bf16 packed [.., n_head * head_dim] plus zero columns up to out_cols (the
- * K padding the next GEMM reads).  Operands are widened to fp32 on the way in; scores, softmax and P.V are the fp32 path's.
- * S in {32, 64, 128, 256, 512}.
+ * K padding the next GEMM reads).  S in {32, 64, 128}: Q.K^T and P.V on v_mfma_f32_32x32x16_bf16 (fp32 scores, softmax and
+ * accumulation; P rounded to bf16); S in {256, 512}: operands widened to fp32, fp32 MFMA core.
  */
 int lime_token_attention_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ld_qkv, uint16_t* out,
                               int64_t ldo, int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim, float scale,

@@ -459,6 +459,10 @@ extern "C" int lime_token_attention_f32(const float* q, const float* k, const fl
     return launch<16>(p, s);
 }
 
+int lime_token_attention_bf16_mfma(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ld_qkv, uint16_t* out, int64_t ldo,
+                                   int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim, float scale, int32_t out_pad,
+                                   hipStream_t s);          // token_attn_bf16.hip
+
 extern "C" int lime_token_attention_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ld_qkv, uint16_t* out,
                                          int64_t ldo, int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim, float scale,
                                          int32_t out_cols, void* stream) {
@@ -473,9 +477,13 @@ extern "C" int lime_token_attention_bf16(const uint16_t* q, const uint16_t* k, c
     LIME_REQUIRE(pad >= 0 && pad <= 32 && ldo >= out_cols, LIME_ERR_BAD_ARG,
                  "lime_token_attention_bf16: out_cols must be in [n_head * head_dim, n_head * head_dim + 32] and <= ldo");
     if (n_seq == 0) return LIME_OK;
+    hipStream_t s = (hipStream_t)stream;
+    {   // S <= 128: scores and P.V on the bf16 matrix cores; longer sequences: the fp32-core variant below
+        const int st = lime_token_attention_bf16_mfma(q, k, v, ld_qkv, out, ldo, n_seq, S, n_head, head_dim, scale, pad, s);
+        if (st != 1) return st;
+    }
     AttnP p{(const float*)q, (const float*)k, (const float*)v, (long)ld_qkv, nullptr, (float*)out, (long)ldo, n_seq, S, n_head,
             head_dim, 32, scale, n_seq * n_head, 1, 0, pad};
-    hipStream_t s = (hipStream_t)stream;
     switch (S / 32) {
         case 1: return launch_bf16<1>(p, s);
         case 2: return launch_bf16<2>(p, s);
