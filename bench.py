@@ -173,7 +173,8 @@ def main():
             tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.exists(tfile):
                 traffic = json.load(open(tfile)).get(name, {}).get('hbm_bytes_per_launch')
-            peak = PEAK_BF16_MFMA_TFLOPS if name.endswith(', true>') else PEAK_F32_MFMA_TFLOPS     # gemm_pp_kernel<..., BF>
+            is_bf16 = name.startswith('gemm_pp_kernel<') and name.split(', ')[4].startswith('true')   # gemm_pp_kernel<NTL, LN, RELU, RES, BF, PING>
+            peak = PEAK_BF16_MFMA_TFLOPS if is_bf16 else PEAK_F32_MFMA_TFLOPS
             roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak,
                     'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': traffic,
                     'launches': cnt, 'avg_launch_us': round(sec / cnt * 1e6, 1), 'flops_per_launch': fl / cnt,

@@ -133,6 +133,24 @@ __global__ __launch_bounds__(256) void k_rand16(float* out, const float* rnd, in
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// V6: k_rand16 again, but with the register budget of two waves per SIMD: hipcc then selects the VGPR form of the MFMA
+// (accumulators in arch VGPRs instead of AccVGPRs).  Same instruction stream otherwise.
+__global__ __launch_bounds__(256, 2) void k_rand16_vgpr(float* out, const float* rnd, int iters) {
+    f32x4 acc[8];
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    float a[8], b[8];
+    for (int u = 0; u < 8; ++u) { a[u] = rnd[(threadIdx.x * 16 + u) & 4095]; b[u] = rnd[(threadIdx.x * 16 + 8 + u) & 4095]; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[(u + i) & 7], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) for (int r = 0; r < 4; ++r) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 template <typename F>
 double time_it(F launch, int reps) {
     hipEvent_t e0, e1;
@@ -175,6 +193,12 @@ int main() {
             const int blocks = 1024, it2 = 1000;
             double t = time_it([&] { hipLaunchKernelGGL(k_rand16, dim3(blocks), dim3(256), 0, 0, out, rnd, it2); }, 200);
             printf("f32 16x16x4 random sustained: %.2f TF\n", (double)blocks * 4 * it2 * 64 * 2048 / t / 1e12);
+            for (int blk : {256, 512}) {
+                t = time_it([&] { hipLaunchKernelGGL(k_rand16_vgpr, dim3(blk), dim3(256), 0, 0, out, rnd, it2); }, 100);
+                printf("f32 16x16x4 random, VGPR-form accumulators, %d waves/SIMD: %.2f TF\n", blk / 256, (double)blk * 4 * it2 * 64 * 2048 / t / 1e12);
+                t = time_it([&] { hipLaunchKernelGGL(k_rand16, dim3(blk), dim3(256), 0, 0, out, rnd, it2); }, 100);
+                printf("f32 16x16x4 random, AGPR accumulators,      %d waves/SIMD: %.2f TF\n", blk / 256, (double)blk * 4 * it2 * 64 * 2048 / t / 1e12);
+            }
         }
     }
     for (int blocks : {256}) {
