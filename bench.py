@@ -99,7 +99,8 @@ def main():
         D.init(backend=backend, device_id=torch.device('cuda', local_rank) if backend == 'nccl' else None)
 
     from lime_cikm25_amd import Model, make_config, newsEncoders, ops, synth
-    newsEncoders.SERIAL_STREAMS = not args.overlap_streams
+    if args.overlap_streams:
+        newsEncoders.OVERLAP_BRANCHES = frozenset((0, 1, 2))
     overrides, B, N, desc = WORKLOADS[args.workload]
     cfg = make_config(**overrides)
     model = Model(cfg)
@@ -140,8 +141,9 @@ def main():
     assert torch.isfinite(logits).all()
     # Per-kernel durations: the same K steps again, launched eagerly with a HIP event pair recorded on the launch
     # stream around every lime_linear_f32 launch (events cannot be recorded inside a graph replay).  Every branch of the
-    # forward runs on ONE stream here, as in the timed region by default, so each kernel owns the device and these
-    # durations are the quantity rocprofv3 --kernel-trace reports for the same command (profiles/).
+    # forward runs on ONE stream here (in the timed region only the two small head branches are forked, the token-encoder
+    # GEMMs are alone on the device there as well), so these durations are the quantity rocprofv3 --kernel-trace reports
+    # for the same command (profiles/).
     prof = []
     if rank == 0:
         ops.PROFILE = prof
@@ -149,7 +151,7 @@ def main():
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
-        newsEncoders.SERIAL_STREAMS = not args.overlap_streams
+        newsEncoders.SERIAL_STREAMS = False
         ops.PROFILE = None
     if dist is not None:
         dist.barrier()
@@ -189,7 +191,8 @@ def main():
             'config': {'workload': desc, 'batch_per_gpu': B, 'history': cfg.max_history_num, 'candidates': N,
                        'title_len': cfg.max_title_length, 'body_len': cfg.max_abstract_length,
                        'parallelism': 'rows sharded over %d GPU(s), no data-path collective' % world,
-                       'streams': 'title / body / freshness branches overlapped' if args.overlap_streams else 'one stream'},
+                       'streams': 'title / body / freshness / attention-weight branches forked' if args.overlap_streams else
+                       'token encoders on one stream; freshness and attention-weight branches forked beside the head'},
             'roofline': roof,
             'end_to_end': {'flops_per_impression': fimp, 'achieved_tflops': round(value * fimp / 1e12, 2),
                            'frac_of_f32_mfma_peak': round(value * fimp / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4)},

@@ -35,17 +35,19 @@ def _no_train_dropout(module, p):
 _SIDE = {}
 
 
-# Independent branches of the forward (freshness encoder, candidate-aware attention weights, title chain vs body chain)
-# CAN be forked onto side streams (LIME_OVERLAP_STREAMS=1).  Off by default: the big GEMMs hold two workgroups of 256
-# VGPRs x 4 waves and 61 KB LDS on every CU, so nothing else becomes resident beside them and the forked forward
-# measured no faster than the single-stream one (4.61 vs 4.58 ms) while making per-kernel timings ambiguous.
-SERIAL_STREAMS = not bool(int(os.environ.get('LIME_OVERLAP_STREAMS', '0')))
+# Independent branches of the forward CAN be forked onto side streams (fork / join with wait_stream, which is also how
+# the fork is recorded into the HIP graph): branch 0 = freshness encoder, 2 = candidate-aware attention weights (small,
+# latency-bound kernels that otherwise sit on the critical path in front of the token encoders), 1 = title chain beside the
+# body chain.  OVERLAP_BRANCHES is the set that is forked (LIME_OVERLAP_STREAMS = 0: none, 2: the two small branches --
+# the default, 4.557 vs 4.593 ms --, 1: all three).  The title / body fork is off by default: the big GEMMs hold two
+# workgroups of 256 VGPRs x 4 waves and 61 KB LDS on every CU, so nothing else becomes resident beside them and that fork
+# measured slower (4.651 ms).
+OVERLAP_BRANCHES = {'0': frozenset(), '1': frozenset((0, 1, 2)), '2': frozenset((0, 2))}[os.environ.get('LIME_OVERLAP_STREAMS', '2')]
+SERIAL_STREAMS = False          # bench.py's instrumented pass forces everything onto one stream
 
 
 def _side_stream(device, which=0):
-    """Side streams (per device) for branches that are independent of each other (fork / join with wait_stream,
-    which is also how the fork is recorded into the HIP graph)."""
-    if SERIAL_STREAMS:
+    if SERIAL_STREAMS or which not in OVERLAP_BRANCHES:
         return torch.cuda.current_stream(device)
     key = (device.type, device.index, which)
     if key not in _SIDE:
