@@ -199,16 +199,21 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
             w_voff[j] = (n < p.N) ? (unsigned)n * (unsigned)ldw4 + (unsigned)lseg * 16u : OOB;
         }
     };
-    auto issue = [&](int stage, int c) {               // DMA of chunk c (elements c BKE .. c BKE + BKE - 1) into `stage`
-        const int k0 = c * BKE;
-#if defined(LIME_PP_ABLATE) && LIME_PP_ABLATE == 2       // tools/pp_ablate.py: no operand traffic (results are garbage)
-        return;
-#endif
-        const bool kin = k0 + lseg * EPS < p.K;        // K % EPS == 0: a segment is valid or not as a whole
+    // DMA of chunk c (elements c BKE .. c BKE + BKE - 1) into `stage`, in two parts: every wave issues its two A
+    // instructions in front of the chunk's MFMAs, and its weight instructions in the MIDDLE of them -- wave w behind its
+    // MFMA group w (see compute).  Issued all at once, the workgroup's 28 instructions queue up in the CU's one address
+    // path and every wave sits ~3k cycles in "DMA issue" (a quarter of its time by s_memtime stamps); staggered, a wave
+    // meets an idle path.  The weight panel is L2 resident, so the latest batch still lands before the chunk's barrier.
+    auto issue_a = [&](int stage, int c) {
+        const bool kin = c * BKE + lseg * EPS < p.K;   // K % EPS == 0: a segment is valid or not as a whole
         float* const sb = lds + stage * STAGE;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             dma16(rs_a, sb + (wave * 2 + j) * 256, kin ? a_voff[j] : OOB, c * 64);
+    };
+    auto issue_w = [&](int stage, int c) {
+        const bool kin = c * BKE + lseg * EPS < p.K;
+        float* const sb = lds + stage * STAGE;
 #pragma unroll
         for (int j = 0; j < NWI; ++j)
             dma16(rs_w, sb + A_ST + (wave * NWI + j) * 256, kin ? w_voff[j] : OOB, c * 64);
@@ -219,42 +224,51 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
     // summation label, so a lane reads ONE b128 = k 4 kg .. 4 kg + 3 of its row (logical segment kg) per operand tile and
     // chunk, and the four MFMAs q = 0..3 of a tile pair element q of both fragments: together they cover the chunk's 16 k.
     constexpr int NT16 = 2 * NTL;                                  // 16-column tiles per wave
-    constexpr int GRP = NT16 / 4;                                  // weight fragments are read a quarter slab at a time
     const int pseg = (kg ^ swz4((fi >> 2) & 3)) * 4;
     const int a_off = (32 * wave + fi) * BK + pseg, w_off = A_ST + fi * BK + pseg;
     f32x4 acc[2][NT16];
 
-    auto compute = [&](int stage) {
-#if defined(LIME_PP_ABLATE) && LIME_PP_ABLATE == 1       // tools/pp_ablate.py: no fragment reads, no MFMAs
-        return;
-#endif
+    // MFMAs of the chunk in `stage`; nstage >= 0: this wave's weight DMAs of chunk nc go out behind its MFMA group `wave`.
+    // The weight fragments of group g + 1 are read BEFORE the MFMAs of group g are issued (the sched_barriers that pin
+    // the DMA issue would otherwise also keep hipcc from hoisting those reads, and every group would start with an
+    // exposed LDS round trip).
+    constexpr int GT = 4;                                          // tiles per group
+    constexpr int NG = NT16 / GT;                                  // groups: 5 (320 columns) or 4 (256)
+    auto compute = [&](int stage, int nstage, int nc) {
         const float* sb = lds + stage * STAGE;
-        f32x4 af[2];
+        f32x4 af[2], wf[2][GT];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) af[tt] = *reinterpret_cast<const f32x4*>(sb + a_off + tt * 16 * BK);
 #pragma unroll
-        for (int gb = 0; gb < 4; ++gb) {
-            f32x4 wf[GRP];
+        for (int t = 0; t < GT; ++t) wf[0][t] = *reinterpret_cast<const f32x4*>(sb + w_off + t * 16 * BK);
 #pragma unroll
-            for (int t = 0; t < GRP; ++t) wf[t] = *reinterpret_cast<const f32x4*>(sb + w_off + (gb * GRP + t) * 16 * BK);
+        for (int gb = 0; gb < NG; ++gb) {
+            if (gb + 1 < NG) {
+#pragma unroll
+                for (int t = 0; t < GT; ++t)
+                    wf[(gb + 1) & 1][t] = *reinterpret_cast<const f32x4*>(sb + w_off + ((gb + 1) * GT + t) * 16 * BK);
+            }
             if constexpr (BF) {
                 // one v_mfma_f32_16x16x32_bf16 per tile: the b128 IS the lane's fragment (8 bf16 = k 8 kg .. 8 kg + 7)
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                    for (int t = 0; t < GRP; ++t)
-                        acc[tt][gb * GRP + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, wf[t]), __builtin_bit_cast(bf16x8, af[tt]), acc[tt][gb * GRP + t], 0, 0, 0);
+                    for (int t = 0; t < GT; ++t)
+                        acc[tt][gb * GT + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, wf[gb & 1][t]), __builtin_bit_cast(bf16x8, af[tt]), acc[tt][gb * GT + t], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                        for (int t = 0; t < GRP; ++t)
-                            acc[tt][gb * GRP + t] =
-                                __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][q], af[tt][q], acc[tt][gb * GRP + t], 0, 0, 0);
+                        for (int t = 0; t < GT; ++t)
+                            acc[tt][gb * GT + t] =
+                                __builtin_amdgcn_mfma_f32_16x16x4f32(wf[gb & 1][t][q], af[tt][q], acc[tt][gb * GT + t], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);         // pins the DMA issue between the MFMA groups
+            if (nstage >= 0 && gb == wave) issue_w(nstage, nc);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -397,7 +411,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
     int rid_cur[2] = {rid_next[0], rid_next[1]};
     loader_set_tile(tile);
     prefetch_ids(tile_at(ti + nw_x));
-    issue(0, 0);
+    issue_a(0, 0);
+    issue_w(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
     int stage = 0, par = 0;
@@ -411,9 +426,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
         acc_init(tile, par, rid_cur);
         PSTAMP(0)                                     // 0: accumulator init (residual loads issued)
         for (int c = 0; c + 1 < nchunk; ++c) {
-            issue(stage ^ 1, c + 1);
+            issue_a(stage ^ 1, c + 1);
             PSTAMP(1)                                 // 1: DMA issue
-            compute(stage);
+            compute(stage, stage ^ 1, c + 1);
             __builtin_amdgcn_sched_barrier(0);        // MFMAs touch no memory: hipcc otherwise sinks them below the wait + barrier
             PSTAMP(2)                                 // 2: fragment reads + MFMA issue
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -428,10 +443,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
             rid_cur[1] = rid_next[1];
             loader_set_tile(tbase + ti + nw_x);
             prefetch_ids(tile_at(ti + 2 * nw_x));
-            issue(stage ^ 1, 0);
+            issue_a(stage ^ 1, 0);
         }
         PSTAMP(5)                                     // 5: loader switch
-        compute(stage);
+        compute(stage, more ? (stage ^ 1) : -1, 0);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP(2)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
