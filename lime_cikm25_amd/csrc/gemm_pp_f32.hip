@@ -205,6 +205,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
     // path and every wave sits ~3k cycles in "DMA issue" (a quarter of its time by s_memtime stamps); staggered, a wave
     // meets an idle path.  The weight panel is L2 resident, so the latest batch still lands before the chunk's barrier.
     auto issue_a = [&](int stage, int c) {
+#if defined(LIME_PP_ABLATE) && LIME_PP_ABLATE == 2       // tools/pp_ablate.py: no operand traffic (results are garbage)
+        return;
+#endif
         const bool kin = c * BKE + lseg * EPS < p.K;   // K % EPS == 0: a segment is valid or not as a whole
         float* const sb = lds + stage * STAGE;
 #pragma unroll
@@ -212,6 +215,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
             dma16(rs_a, sb + (wave * 2 + j) * 256, kin ? a_voff[j] : OOB, c * 64);
     };
     auto issue_w = [&](int stage, int c) {
+#if defined(LIME_PP_ABLATE) && LIME_PP_ABLATE == 2
+        return;
+#endif
         const bool kin = c * BKE + lseg * EPS < p.K;
         float* const sb = lds + stage * STAGE;
 #pragma unroll
@@ -235,6 +241,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
     constexpr int GT = 4;                                          // tiles per group
     constexpr int NG = NT16 / GT;                                  // groups: 5 (320 columns) or 4 (256)
     auto compute = [&](int stage, int nstage, int nc) {
+#if defined(LIME_PP_ABLATE) && LIME_PP_ABLATE == 1       // tools/pp_ablate.py: no fragment reads, no MFMAs (DMA issued up front)
+        if (nstage >= 0) issue_w(nstage, nc);
+        return;
+#endif
         const float* sb = lds + stage * STAGE;
         f32x4 af[2], wf[2][GT];
 #pragma unroll
