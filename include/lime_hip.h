@@ -281,6 +281,21 @@ typedef struct {
 } lime_copy_desc;
 int lime_multi_copy(const lime_copy_desc* descs, int32_t n, void* stream);
 
+/*
+ * lime_gather_rows_multi: for up to LIME_MAX_GATHERS tables at once, out_f[r, 0:row_bytes_f) = table_f[idx[r], 0:row_bytes_f)
+ * (byte rows; strides in bytes).  The device-side batch assembly of dataset.py:105-141 / :192-227: one launch gathers the
+ * eight per-news arrays (category, subCategory, title / abstract text, mask, entity: corpus.py:360-367) of every history
+ * slot and candidate of a batch by news index, another the per-behaviour rows by behaviour index.  idx int32 [n_rows];
+ * `descs` is a HOST array (copied into the kernel arguments).  Indices are not range checked (as nn.Embedding's device path).
+ */
+#define LIME_MAX_GATHERS 16
+typedef struct {
+    const void* table;  int64_t table_stride;   /* bytes between table rows */
+    void* out;          int64_t out_stride;     /* bytes between output rows */
+    int32_t row_bytes;  int32_t reserved;
+} lime_gather_desc;
+int lime_gather_rows_multi(const int32_t* idx, int64_t n_rows, const lime_gather_desc* descs, int32_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

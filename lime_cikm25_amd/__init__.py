@@ -7,3 +7,4 @@ Importing the package needs neither a GPU nor the shared library; calling a forw
 """
 from .config import make_config  # noqa: F401
 from .model import Model  # noqa: F401
+from .device_data import DeviceBehaviors, DeviceCorpus  # noqa: F401

@@ -53,6 +53,15 @@ class CopyDesc(ctypes.Structure):
 
 MAX_COPIES = 32
 
+
+class GatherDesc(ctypes.Structure):
+    """lime_gather_desc of include/lime_hip.h."""
+    _fields_ = [('table', c_void_p), ('table_stride', c_int64), ('out', c_void_p), ('out_stride', c_int64),
+                ('row_bytes', c_int32), ('reserved', c_int32)]
+
+
+MAX_GATHERS = 16
+
 # name -> (restype, argtypes); every symbol include/lime_hip.h declares
 SIGNATURES = {
     'lime_abi_version': (c_int32, []),
@@ -85,6 +94,7 @@ SIGNATURES = {
     'lime_row_scale_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     'lime_gather_rows_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p]),
     'lime_multi_copy': (c_int32, [ctypes.POINTER(CopyDesc), c_int32, c_void_p]),
+    'lime_gather_rows_multi': (c_int32, [c_void_p, c_int64, ctypes.POINTER(GatherDesc), c_int32, c_void_p]),
     'lime_linear_bf16': (c_int32, [ctypes.POINTER(LinearBf16Args), c_void_p]),
     'lime_token_attention_bf16': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                             c_int32, c_float, c_int32, c_void_p]),

@@ -760,6 +760,43 @@ extern "C" int lime_mean_pool_bf16(const uint16_t* x, int64_t ldx, float* out, i
 }
 
 // ---------------------------------------------------------------------------------------------------
+// multi-table row gather (device-side batch assembly): blockIdx.y = table, blockIdx.x = output row
+// ---------------------------------------------------------------------------------------------------
+struct GatherTable {
+    lime_gather_desc d[LIME_MAX_GATHERS];
+};
+
+__global__ __launch_bounds__(64) void gather_rows_multi_kernel(const int* __restrict__ idx, const GatherTable t) {
+    const lime_gather_desc d = t.d[blockIdx.y];
+    const long r = blockIdx.x;
+    const char* src = (const char*)d.table + (long)idx[r] * d.table_stride;
+    char* dst = (char*)d.out + r * d.out_stride;
+    const int n = d.row_bytes;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 3) == 0) {
+        const int nw = n >> 2;
+        for (int i = threadIdx.x; i < nw; i += 64) reinterpret_cast<unsigned*>(dst)[i] = reinterpret_cast<const unsigned*>(src)[i];
+        for (int i = (nw << 2) + threadIdx.x; i < n; i += 64) dst[i] = src[i];
+    } else {
+        for (int i = threadIdx.x; i < n; i += 64) dst[i] = src[i];
+    }
+}
+
+extern "C" int lime_gather_rows_multi(const int32_t* idx, int64_t n_rows, const lime_gather_desc* descs, int32_t n, void* stream) {
+    LIME_REQUIRE(n >= 0 && n <= LIME_MAX_GATHERS, LIME_ERR_BAD_ARG, "lime_gather_rows_multi: n = %d outside [0, %d]", n, LIME_MAX_GATHERS);
+    LIME_REQUIRE(n_rows >= 0 && n_rows <= 0x7FFFFFFF, LIME_ERR_BAD_ARG, "lime_gather_rows_multi: bad row count");
+    if (n == 0 || n_rows == 0) return LIME_OK;
+    LIME_REQUIRE(idx && descs, LIME_ERR_BAD_ARG, "lime_gather_rows_multi: NULL pointer");
+    GatherTable t;
+    for (int i = 0; i < n; ++i) {
+        LIME_REQUIRE(descs[i].table && descs[i].out && descs[i].row_bytes > 0 && descs[i].table_stride >= descs[i].row_bytes &&
+                     descs[i].out_stride >= descs[i].row_bytes, LIME_ERR_BAD_ARG, "lime_gather_rows_multi: bad descriptor %d", i);
+        t.d[i] = descs[i];
+    }
+    hipLaunchKernelGGL(gather_rows_multi_kernel, dim3((unsigned)n_rows, (unsigned)n), dim3(64), 0, (hipStream_t)stream, idx, t);
+    return lime_check_launch("lime_gather_rows_multi");
+}
+
+// ---------------------------------------------------------------------------------------------------
 // multi-copy: blockIdx.y = buffer, blockIdx.x = 16 KB piece of it
 // ---------------------------------------------------------------------------------------------------
 struct CopyTable {

@@ -493,3 +493,26 @@ def token_attention_bf16(q, k, v, n_seq, S, n_head, head_dim, scale, out_cols=No
     check(lib.lime_token_attention_bf16(_p(q), _p(k), _p(v), _ld(q), _p(out), _ld(out), n_seq, S, n_head, head_dim, scale, out_cols,
                                         _stream()), 'lime_token_attention_bf16')
     return out
+
+
+def gather_rows_multi(idx, pairs):
+    """out[r] = table[idx[r]] for every (table, out) pair in one launch per 16 pairs.  Tables / outputs: any dtype, row-major
+    with contiguous rows ([n, ...] -> rows of prod(shape[1:]) elements); out has idx.numel() rows."""
+    lib = _lib.load()
+    _vec(idx, 'idx', dtype=torch.int32)
+    R = idx.numel()
+    todo = []
+    for table, out in pairs:
+        if table.dtype != out.dtype or not table.is_cuda or not out.is_cuda or table.shape[1:] != out.shape[1:] or out.shape[0] != R:
+            raise ValueError('gather_rows_multi: table %s %s vs out %s %s (rows %d)' % (tuple(table.shape), table.dtype,
+                                                                                        tuple(out.shape), out.dtype, R))
+        if not table.is_contiguous() or not out.is_contiguous():
+            raise ValueError('gather_rows_multi: tables and outputs must be contiguous')
+        todo.append((table, out))
+    for i in range(0, len(todo), _lib.MAX_GATHERS):
+        part = todo[i:i + _lib.MAX_GATHERS]
+        descs = (_lib.GatherDesc * len(part))()
+        for d, (table, out) in zip(descs, part):
+            rb = (table.numel() // max(1, table.shape[0])) * table.element_size()
+            d.table, d.table_stride, d.out, d.out_stride, d.row_bytes = table.data_ptr(), rb, out.data_ptr(), rb, rb
+        check(lib.lime_gather_rows_multi(_p(idx), R, descs, len(part), _stream()), 'lime_gather_rows_multi')

@@ -224,3 +224,70 @@ def synth_word_embedding(config, seed=0):
     """The tensor the reference unpickles at newsEncoders.py:173-174."""
     return synth_tensor('news_encoder.base_news_encoder.word_embedding.weight',
                         (config.vocabulary_size, config.word_embedding_dim), seed)
+
+
+def synth_corpus(config, n_news=200, n_train=40, n_dev=30, seed=0, n_neg_max=9):
+    """A toy corpus object with the attributes the reference's datasets read (corpus.py:355-368 arrays, the behaviour lists of
+    corpus.py:539-552 / 590-600), filled from the counter-based generator.  News 0 is the <PAD> news (corpus.py:476-477).
+    Histories have 0 .. H clicked news; the per-behaviour freshness / lifetime lists are deliberately shorter or LONGER
+    than H so that dataset.py:125-128's ``[-H:] + [0] * pad`` is exercised on both sides."""
+    from types import SimpleNamespace
+    H, T, L = config.max_history_num, config.max_title_length, config.max_abstract_length
+    V = config.vocabulary_size
+    c = SimpleNamespace()
+    c.config = config
+    c.negative_sample_num = config.negative_sample_num
+    c.max_history_num, c.max_title_length, c.max_abstract_length = H, T, L
+    c.news_category = randint('corpus.cat', seed, n_news, 0, config.category_num).astype(np.int32)
+    c.news_subCategory = randint('corpus.sub', seed, n_news, 0, config.subCategory_num).astype(np.int32)
+
+    def texts(tag, length):
+        ids = randint('corpus.%s' % tag, seed, n_news * length, 1, V).reshape(n_news, length).astype(np.int32)
+        lens = randint('corpus.%s.len' % tag, seed, n_news, 1, length + 1)
+        mask = np.arange(length)[None, :] < lens[:, None]
+        ent = randint('corpus.%s.ent' % tag, seed, n_news * length, 0, 50).reshape(n_news, length).astype(np.int32)
+        return np.where(mask, ids, 0).astype(np.int32), mask, np.where(mask, ent, 0).astype(np.int32)
+    c.news_title_text, c.news_title_mask, c.news_title_entity = texts('title', T)
+    c.news_abstract_text, c.news_abstract_mask, c.news_abstract_entity = texts('abstract', L)
+    for arr in (c.news_title_text, c.news_title_entity, c.news_abstract_text, c.news_abstract_entity):
+        arr[0] = 0
+    c.news_title_mask[0] = False
+    c.news_abstract_mask[0] = False
+    c.news_title_mask[0][0] = True                                         # corpus.py:476-477
+    c.news_abstract_mask[0][0] = True
+    c.news_category[0] = 0
+    c.news_subCategory[0] = 0
+
+    def history(tag, i):
+        n = int(randint('%s.hn' % tag, seed + i, 1, 0, H + 1)[0])
+        idx = np.zeros(H, dtype=np.int32)
+        idx[:n] = randint('%s.h' % tag, seed + i, n, 1, n_news)
+        mask = np.zeros(H, dtype=bool)
+        mask[:n] = True
+        n_list = int(randint('%s.ln' % tag, seed + i, 1, 0, H + 4)[0])      # list length independent of n: shorter and longer than H
+        fr = (_log_uniform('%s.fr' % tag, seed + i, n_list, 60.0, 30 * 86400.0)).astype(np.float64).tolist()
+        lt = (_log_uniform('%s.lt' % tag, seed + i, n_list, 600.0, 14 * 86400.0)).astype(np.float64).tolist()
+        return idx, mask, fr, lt
+    c.train_behaviors = []
+    for i in range(n_train):
+        idx, mask, fr, lt = history('train', i)
+        n_neg = int(randint('train.nn', seed + i, 1, 1, n_neg_max + 1)[0])
+        neg = randint('train.neg', seed + i, n_neg, 1, n_news).astype(np.int64).tolist()
+        neg_lt = _log_uniform('train.neglt', seed + i, n_neg, 600.0, 14 * 86400.0).astype(np.float64).tolist()
+        c.train_behaviors.append([int(randint('train.uid', seed + i, 1, 0, config.user_num)[0]), idx, mask,
+                                  int(randint('train.pos', seed + i, 1, 1, n_news)[0]), neg, i,
+                                  float(_log_uniform('train.cfr', seed + i, 1, 60.0, 30 * 86400.0)[0]),
+                                  float(_log_uniform('train.plt', seed + i, 1, 600.0, 14 * 86400.0)[0]), neg_lt, fr, lt])
+    for split, n in (('dev', n_dev), ('test', max(1, n_dev // 2))):
+        beh = []
+        for i in range(n):
+            idx, mask, fr, lt = history(split, i)
+            beh.append([int(randint('%s.uid' % split, seed + i, 1, 0, config.user_num)[0]), idx, mask,
+                        int(randint('%s.cand' % split, seed + i, 1, 1, n_news)[0]), i,
+                        float(_log_uniform('%s.cfr' % split, seed + i, 1, 60.0, 30 * 86400.0)[0]),
+                        float(_log_uniform('%s.clt' % split, seed + i, 1, 600.0, 14 * 86400.0)[0]), fr, lt])
+        setattr(c, '%s_behaviors' % split, beh)
+    for split in ('train', 'dev', 'test'):                                  # SUE-only tables (dataset.py:21-28): absent for CROWN
+        for name in ('user_history_graph', 'user_history_category_mask', 'user_history_category_indices'):
+            setattr(c, '%s_%s' % (split, name), None)
+    return c

@@ -290,3 +290,52 @@ def model_forward(sd, cfg, inputs, eval_shape=False, taps=None):
         taps['news_representation'] = cand
         taps['logits'] = logits
     return logits
+
+
+# ---------------------------------------------------------------------------------------------------
+# Batch assembly: numpy restatement of the reference's datasets, pinned by
+# tests/golden/dataset_*.npz captured from the imported Train_Dataset / DevTest_Dataset.
+# ---------------------------------------------------------------------------------------------------
+def _pad_history_list(values, H):
+    """dataset.py:125-128 / :202-204: the LAST H entries, then zeros up to H (a longer list is truncated, not padded)."""
+    values = list(values)
+    return values[-H:] + [0] * max(0, H - len(values))
+
+
+def _news_fields(corpus, index):
+    """The eight per-news arrays of corpus.py:360-367 gathered by news index (dataset.py:131-140)."""
+    index = np.asarray(index)
+    return [corpus.news_category[index], corpus.news_subCategory[index], corpus.news_title_text[index],
+            corpus.news_title_mask[index], corpus.news_title_entity[index], corpus.news_abstract_text[index],
+            corpus.news_abstract_mask[index], corpus.news_abstract_entity[index]]
+
+
+def _assemble(corpus, behaviors, rows, cand_index, cand_freshness, cand_lifetime, fr_slot, lt_slot):
+    H = corpus.max_history_num
+    C = corpus.config.category_num
+    B = len(rows)
+    user_id = np.asarray([behaviors[i][0] for i in rows], dtype=np.int64)
+    hist_index = np.stack([np.asarray(behaviors[i][1]) for i in rows])
+    hist_mask = np.stack([np.asarray(behaviors[i][2]) for i in rows])
+    user_fr = np.asarray([_pad_history_list(behaviors[i][fr_slot], H) for i in rows], dtype=np.float32)
+    user_lt = np.asarray([_pad_history_list(behaviors[i][lt_slot], H) for i in rows], dtype=np.float32)
+    out = [user_id] + _news_fields(corpus, hist_index) + [user_fr, user_lt, hist_mask,
+           np.zeros((B, H, H), dtype=np.float32), np.zeros((B, C + 1), dtype=bool), np.zeros((B, H), dtype=np.int64)]    # dataset.py:119-121
+    out += _news_fields(corpus, cand_index) + [np.asarray(cand_freshness, dtype=np.float32), np.asarray(cand_lifetime, dtype=np.float32)]
+    return out
+
+
+def assemble_train(corpus, train_samples, train_freshness, train_user_topic_lifetime, rows):
+    """Train_Dataset.__getitem__ (dataset.py:105-141), default-collated over `rows`.  The three sampled tables are what
+    negative_sampling (dataset.py:42-77) produced on the host.  Returns the 25 arrays in the reference's order."""
+    rows = list(rows)
+    return _assemble(corpus, corpus.train_behaviors, rows, np.asarray(train_samples)[rows], np.asarray(train_freshness)[rows],
+                     np.asarray(train_user_topic_lifetime)[rows], 9, 10)
+
+
+def assemble_devtest(corpus, mode, rows):
+    """DevTest_Dataset.__getitem__ (dataset.py:192-227): one candidate per row, candidate tensors without the N axis."""
+    rows = list(rows)
+    beh = corpus.dev_behaviors if mode == 'dev' else corpus.test_behaviors
+    return _assemble(corpus, beh, rows, np.asarray([beh[i][3] for i in rows]), [beh[i][5] for i in rows],
+                     [beh[i][6] for i in rows], 7, 8)

@@ -69,6 +69,8 @@ def test_bad_arguments_are_rejected_without_a_launch(lib):
     assert lib.lime_multi_copy(None, 3, None) == -1
     assert lib.lime_multi_copy(None, 0, None) == 0
     assert lib.lime_multi_copy(None, 33, None) == -1
+    assert lib.lime_gather_rows_multi(None, 4, None, 2, None) == -1
+    assert lib.lime_gather_rows_multi(None, 0, None, 2, None) == 0
     assert lib.lime_sage_mean_f32(None, None, None, 1, 1, 1, 1, 1, None) == -1
     with pytest.raises(_lib.LimeHipError):
         _lib.check(-1, 'x')
