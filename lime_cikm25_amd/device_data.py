@@ -56,6 +56,7 @@ class DeviceBehaviors:
         self.cand_freshness = t(cand_fr, np.float32)
         self.cand_lifetime = t(cand_lt, np.float32)
         self.num = self.user_id.shape[0]
+        self._plans, self._turn = {}, {}
 
     @classmethod
     def from_train(cls, dev_corpus, corpus, train_samples, train_freshness, train_user_topic_lifetime):
@@ -79,33 +80,49 @@ class DeviceBehaviors:
 
     def assemble(self, rows):
         """The collated batch of behaviour rows `rows` (int32 / int64 tensor or sequence): the reference's 25 tensors in
-        ``__getitem__`` order, on the device.  Train split: candidates [B, 1 + neg, ...]; dev / test: without the N axis."""
+        ``__getitem__`` order, on the device.  Train split: candidates [B, 1 + neg, ...]; dev / test: without the N axis.
+
+        The output tensors come from a ring of two pre-built workspaces per batch size (allocations, views and the two
+        descriptor tables are made once): a returned batch stays valid until the call after the next one.
+        """
+        dev = self.corpus.device
+        rows = torch.as_tensor(rows, device=dev)
+        B = rows.numel()
+        if B not in self._plans:
+            self._plans[B] = [self._plan(B), self._plan(B)]
+        ring = self._plans[B]
+        plan = ring[self._turn.get(B, 0)]
+        self._turn[B] = 1 - self._turn.get(B, 0)
+        plan['rows'].copy_(rows.reshape(-1))                                 # int64 -> int32 on the way if need be
+        ops.gather_rows_multi_run(plan['rows'], plan['level1'])
+        ops.gather_rows_multi_run(plan['idx_all'], plan['level2'])
+        return list(plan['out'])
+
+    def _plan(self, B):
         c = self.corpus
         dev = c.device
-        rows = torch.as_tensor(rows, device=dev).to(torch.int32).contiguous()
-        B, H, N = rows.numel(), self.hist_index.shape[1], self.cand_index.shape[1]
+        H, N = self.hist_index.shape[1], self.cand_index.shape[1]
+        rows = torch.empty(B, dtype=torch.int32, device=dev)
         # level 1: behaviour rows.  The news indices go into ONE vector, candidates first: the order of the level-2 outputs.
         idx_all = torch.empty(B * N + B * H, dtype=torch.int32, device=dev)
         user_id = torch.empty((B, 1), dtype=torch.int64, device=dev)
         hist_mask = torch.empty((B, H), dtype=torch.bool, device=dev)
         ufr, ult = torch.empty((B, H), dtype=torch.float32, device=dev), torch.empty((B, H), dtype=torch.float32, device=dev)
         cfr, clt = torch.empty((B, N), dtype=torch.float32, device=dev), torch.empty((B, N), dtype=torch.float32, device=dev)
-        ops.gather_rows_multi(rows, [(self.cand_index, idx_all[:B * N].view(B, N)), (self.hist_index, idx_all[B * N:].view(B, H)),
-                                     (self.user_id, user_id), (self.hist_mask, hist_mask), (self.user_freshness, ufr),
-                                     (self.user_lifetime, ult), (self.cand_freshness, cfr), (self.cand_lifetime, clt)])
+        level1 = [(self.cand_index, idx_all[:B * N].view(B, N)), (self.hist_index, idx_all[B * N:].view(B, H)),
+                  (self.user_id, user_id), (self.hist_mask, hist_mask), (self.user_freshness, ufr), (self.user_lifetime, ult),
+                  (self.cand_freshness, cfr), (self.cand_lifetime, clt)]
         # level 2: the eight per-news arrays for candidates and history in one launch; every output is one buffer whose
         # first B * N rows are the candidates and the rest the history (adjacent -> the encoder's cat is a view)
-        outs = []
-        for table in c.fields():
-            outs.append(torch.empty((B * N + B * H,) + tuple(table.shape[1:]), dtype=table.dtype, device=dev))
-        ops.gather_rows_multi(idx_all, list(zip(c.fields(), outs)))
+        outs = [torch.empty((B * N + B * H,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev) for t in c.fields()]
         news = [o[:B * N].view((B, N) + tuple(o.shape[1:])) for o in outs]
         user = [o[B * N:].view((B, H) + tuple(o.shape[1:])) for o in outs]
         if self.eval_shape:                                                  # DevTest_Dataset: candidate tensors without the N axis
             news = [t.squeeze(1) for t in news]
             cfr, clt = cfr.squeeze(1), clt.squeeze(1)
-        zeros = self._zeros(B, H)
-        return [user_id.view(B)] + user + [ufr, ult, hist_mask] + zeros + news + [cfr, clt]
+        out = [user_id.view(B)] + user + [ufr, ult, hist_mask] + self._zeros(B, H) + news + [cfr, clt]
+        return {'rows': rows, 'idx_all': idx_all, 'level1': ops.gather_rows_multi_prepare(B, level1),
+                'level2': ops.gather_rows_multi_prepare(B * N + B * H, list(zip(c.fields(), outs))), 'out': out}
 
     def _zeros(self, B, H):
         """dataset.py:119-121: the SUE-only tensors are zeros for every other user encoder."""

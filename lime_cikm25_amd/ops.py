@@ -495,24 +495,39 @@ def token_attention_bf16(q, k, v, n_seq, S, n_head, head_dim, scale, out_cols=No
     return out
 
 
-def gather_rows_multi(idx, pairs):
-    """out[r] = table[idx[r]] for every (table, out) pair in one launch per 16 pairs.  Tables / outputs: any dtype, row-major
-    with contiguous rows ([n, ...] -> rows of prod(shape[1:]) elements); out has idx.numel() rows."""
-    lib = _lib.load()
-    _vec(idx, 'idx', dtype=torch.int32)
-    R = idx.numel()
+def gather_rows_multi_prepare(n_rows, pairs):
+    """Validate (table, out) pairs once and build the descriptor tables: returns an opaque plan for gather_rows_multi_run.
+    Tables / outputs: any dtype, row-major with contiguous rows ([n, ...] -> rows of prod(shape[1:]) elements); every
+    out has n_rows rows.  The plan keeps the tensors alive."""
     todo = []
     for table, out in pairs:
-        if table.dtype != out.dtype or not table.is_cuda or not out.is_cuda or table.shape[1:] != out.shape[1:] or out.shape[0] != R:
+        if table.dtype != out.dtype or not table.is_cuda or not out.is_cuda or table.shape[1:] != out.shape[1:] or out.shape[0] != n_rows:
             raise ValueError('gather_rows_multi: table %s %s vs out %s %s (rows %d)' % (tuple(table.shape), table.dtype,
-                                                                                        tuple(out.shape), out.dtype, R))
+                                                                                        tuple(out.shape), out.dtype, n_rows))
         if not table.is_contiguous() or not out.is_contiguous():
             raise ValueError('gather_rows_multi: tables and outputs must be contiguous')
         todo.append((table, out))
+    tables = []
     for i in range(0, len(todo), _lib.MAX_GATHERS):
         part = todo[i:i + _lib.MAX_GATHERS]
         descs = (_lib.GatherDesc * len(part))()
         for d, (table, out) in zip(descs, part):
             rb = (table.numel() // max(1, table.shape[0])) * table.element_size()
             d.table, d.table_stride, d.out, d.out_stride, d.row_bytes = table.data_ptr(), rb, out.data_ptr(), rb, rb
-        check(lib.lime_gather_rows_multi(_p(idx), R, descs, len(part), _stream()), 'lime_gather_rows_multi')
+        tables.append((descs, len(part)))
+    return {'n_rows': n_rows, 'tables': tables, 'keep': todo}
+
+
+def gather_rows_multi_run(idx, plan):
+    lib = _lib.load()
+    if idx.dtype != torch.int32 or not idx.is_cuda or not idx.is_contiguous() or idx.numel() != plan['n_rows']:
+        raise ValueError('gather_rows_multi: idx must be a contiguous int32 CUDA vector of %d rows' % plan['n_rows'])
+    stream = _stream()
+    for descs, n in plan['tables']:
+        check(lib.lime_gather_rows_multi(idx.data_ptr(), plan['n_rows'], descs, n, stream), 'lime_gather_rows_multi')
+
+
+def gather_rows_multi(idx, pairs):
+    """out[r] = table[idx[r]] for every (table, out) pair, one launch per 16 pairs."""
+    _vec(idx, 'idx', dtype=torch.int32)
+    gather_rows_multi_run(idx, gather_rows_multi_prepare(idx.numel(), pairs))

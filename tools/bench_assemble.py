@@ -1,0 +1,53 @@
+"""Throughput of the device-side batch assembly at the config-2 shape, next to the reference's host path restated in numpy
+(oracle.assemble_train + collate + host->device copy), on a synthetic corpus of MIND-small size.
+
+    python tools/bench_assemble.py
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from lime_cikm25_amd import DeviceBehaviors, DeviceCorpus, make_config, synth  # noqa: E402
+from oracle import lime_oracle as O  # noqa: E402
+
+
+def main():
+    cfg = make_config(vocabulary_size=50000)
+    B, N = 32, 1 + cfg.negative_sample_num
+    corpus = synth.synth_corpus(cfg, n_news=65000, n_train=4096, n_dev=64, seed=1)
+    rng = np.random.default_rng(0)
+    samples = rng.integers(1, 65000, size=(4096, N))
+    fr = rng.uniform(60, 1e6, size=(4096, N))
+    lt = rng.uniform(600, 1e6, size=(4096, N))
+    dc = DeviceCorpus(corpus)
+    beh = DeviceBehaviors.from_train(dc, corpus, samples, fr, lt)
+    rows = torch.arange(B, dtype=torch.int32, device='cuda')
+    for _ in range(5):
+        beh.assemble(rows)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 200
+    row_sets = [rows + i for i in range(100)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        out = beh.assemble(row_sets[i % 100])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    nbytes = sum(t.numel() * t.element_size() for t in out)
+    print('device assembly: %.1f us per %d-impression batch (%.2f MB of batch tensors, %.0f GB/s)' % (dt * 1e6, B, nbytes / 1e6, nbytes / dt / 1e9))
+    t0 = time.perf_counter()
+    m = 20
+    for i in range(m):
+        host = O.assemble_train(corpus, samples, fr, lt, list(range(i, i + B)))
+        dev = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in host]
+    torch.cuda.synchronize()
+    print('host numpy gather + copy (reference path restated): %.1f us per batch' % ((time.perf_counter() - t0) / m * 1e6))
+
+
+if __name__ == '__main__':
+    main()
