@@ -60,6 +60,8 @@ def main():
             ('ffn1_' + name, 2.0 * tok * F * E, lambda: ops.linear(x1, w1, b1, act='relu', out=h)),
             ('ffn2_' + name, 2.0 * tok * F * E, lambda: ops.linear(h, w2, b2, res=x1, ln=ln, out=x2)),
             ('pool_' + name, 0.0, lambda: ops.mean_pool(x2, M, S)),
+            # the stand-alone word gather + positional add (the fused GEMMs do not use it): HBM-bound, 2 x 1200 B per token
+            ('embed_' + name, 0.0, lambda: ops.embed_pe(ids, table, pe, S, out=x2)),
         ]
         for cname, flops, fn in cases:
             if only and cname not in only:
@@ -75,8 +77,12 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / args.iters
             results.append((cname, us, flops / us / 1e6 if flops else 0.0))
+    hbm = {'pool': 1200.0 * (1 + 1 / 128.0), 'embed': 2400.0}          # algorithmic bytes per token (read + write)
+    tokens = {'title': args.news * 32, 'body': args.news * 128}
     for cname, us, tf in results:
-        print('%-12s %9.1f us  %7.2f TFLOP/s' % (cname, us, tf))
+        kind, shape = cname.split('_')
+        extra = '  %6.2f TB/s algorithmic' % (hbm[kind] * tokens[shape] / us / 1e6) if kind in hbm else ''
+        print('%-12s %9.1f us  %7.2f TFLOP/s%s' % (cname, us, tf, extra))
     print('total %.1f us' % sum(r[1] for r in results))
 
 
