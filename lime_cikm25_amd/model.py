@@ -173,6 +173,36 @@ class Model(nn.Module):
             out[b0:b1] = logits.view(b1 - b0, K)
         return out
 
+    @torch.no_grad()
+    def build_news_cache(self, device_corpus, rows_per_pass=8192):
+        """Content cache for ``score_behaviors``: every news of a ``DeviceCorpus`` through the token encoders ONCE."""
+        c = device_corpus
+        return self.news_encoder.build_content_cache(c.news_title_text, c.news_title_mask, c.news_abstract_text, c.news_category,
+                                                     c.news_subCategory, rows_per_pass=rows_per_pass)
+
+    @torch.no_grad()
+    def score_behaviors(self, behaviors, rows, news_cache, n_src=None):
+        """Scores of the (impression, candidate) rows `rows` of a dev / test ``DeviceBehaviors`` -- the function of
+        util.compute_scores' forward (util.py:86-111, eval mode, N = 1 per row) -- from the news cache: no token encoder
+        runs, the history and the candidate of a row are looked up by news index and only their freshness half, the user
+        encoder and the match are computed.  ``n_src`` as in score_impressions (default: the number of rows, capped)."""
+        b = behaviors
+        dev = news_cache.device
+        rows = torch.as_tensor(rows, device=dev).long().reshape(-1)
+        R, H = rows.numel(), b.hist_index.shape[1]
+        ne, ue, c = self.news_encoder, self.user_encoder, b.corpus
+        hist_idx, cand_idx = b.hist_index[rows], b.cand_index[rows]                       # [R, H], [R, 1]
+        hist = ne.encode_cached(news_cache, hist_idx, b.user_freshness[rows], b.user_lifetime[rows]).view(R, H, -1)
+        cand = ne.encode_cached(news_cache, cand_idx, b.cand_freshness[rows], b.cand_lifetime[rows]).view(R, 1, -1)
+        flat_h, flat_c = hist_idx.reshape(-1).long(), cand_idx.reshape(-1).long()
+        remaining = (b.cand_lifetime[rows] - b.cand_freshness[rows])                      # util.py:98-106 (lifetime_type user_topic)
+        if n_src is None:
+            n_src = min(R, H + ue.user_node_embedding.shape[0])
+        _, logits = ue.match(hist, c.news_category[flat_c].view(R, 1), c.news_subCategory[flat_c].view(R, 1),
+                             c.news_category[flat_h].view(R, H), c.news_subCategory[flat_h].view(R, H), b.hist_mask[rows],
+                             cand, remaining_lifetime=remaining.view(R, 1), weighting=self.remaining_lifetime_weighting, n_src=n_src)
+        return logits.view(R)
+
     def _forward_impl(self, user_ID, user_category, user_subCategory, user_title_text, user_title_mask, user_title_entity,
                       user_content_text, user_content_mask, user_content_entity, user_freshness, user_user_topic_lifetime,
                       user_history_mask, user_history_graph, user_history_category_mask, user_history_category_indices,

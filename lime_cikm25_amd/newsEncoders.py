@@ -177,6 +177,42 @@ class LIME(nn.Module):
             return fused
         return ops.linear(fused, self.project.weight, self.project.bias)             # newsEncoders.py:152-153
 
+    # ---- per-news content cache (eval: a news occurs in many impressions, its token encoders need to run once) ----------
+    def build_content_cache(self, title_text, title_mask, content_text, category, subCategory, rows_per_pass=8192):
+        """[n_news, output_dim]: the content half of every news pushed through its half of `project`.
+
+        LIME's representation is project(cat(content(news), freshness(freshness, lifetime))) (newsEncoders.py:146-153) and
+        project is linear, so  rep = content . W[:, :c]^T  +  freshness . W[:, c:]^T + b : the first term depends on the news
+        alone (all the token-encoder work), the second on the occurrence (two bucket lookups and two small GEMMs).  The
+        cache holds the first term per news id; ``encode_cached`` adds the second.  Rebuild it when weights change."""
+        n = title_text.shape[0]
+        cdim = self.base_news_encoder.news_embedding_dim
+        dev = title_text.device
+        ident = isinstance(self.project, nn.Identity)
+        cache = torch.empty((n, cdim if ident else self.project.out_features), dtype=torch.float32, device=dev)
+        for r0 in range(0, n, rows_per_pass):
+            r1 = min(n, r0 + rows_per_pass)
+            content = torch.empty((r1 - r0, cdim), dtype=torch.float32, device=dev)
+            self.base_news_encoder.encode_flat(_i32(title_text[r0:r1]).contiguous(), title_mask[r0:r1].contiguous(),
+                                               _i32(content_text[r0:r1]).contiguous(), _i32(category[r0:r1]).contiguous(),
+                                               _i32(subCategory[r0:r1]).contiguous(), content)
+            if ident:
+                cache[r0:r1] = content
+            else:
+                ops.linear(content, self.project.weight[:, :cdim], None, out=cache[r0:r1])
+        return cache
+
+    def encode_cached(self, cache, news_index, freshness, lifetime):
+        """Representations of the occurrences (news_index[r], freshness[r], lifetime[r]) -> [R, output_dim]."""
+        cdim = self.base_news_encoder.news_embedding_dim
+        R = news_index.numel()
+        idx = _i32(news_index.reshape(-1)).contiguous()
+        fresh = torch.empty((R, cdim), dtype=torch.float32, device=cache.device)
+        self.freshness_encoder.encode_flat(freshness.float().reshape(-1).contiguous(), lifetime.float().reshape(-1).contiguous(), fresh)
+        if isinstance(self.project, nn.Identity):
+            return torch.cat([cache[idx.long()], fresh], dim=1)
+        return ops.linear(fresh, self.project.weight[:, cdim:], self.project.bias, res=cache, res_ids=idx)
+
     def encode_many(self, groups):
         """Encode several [B, n, ...] groups (candidates, history) in ONE pass over the kernels.
 

@@ -68,3 +68,30 @@ def test_assembled_batch_drives_the_model():
         cpu = {n: t.cpu() for n, t in zip(names, batch + [remaining])}
         want = O.model_forward(sd, cfg, cpu, eval_shape=eval_shape)
         assert rel_err(got.numpy().reshape(-1), want.numpy().reshape(-1)) < 1e-3
+
+
+def test_cached_scoring_equals_the_eval_forward():
+    """Model.score_behaviors (per-news content cache, no token encoder at scoring time) == Model.forward in eval mode on the
+    assembled rows == the oracle."""
+    from lime_cikm25_amd import DeviceBehaviors, DeviceCorpus, Model, synth
+    from helpers import rel_err
+    cfg, corpus = dataset_cases.build()
+    model = Model(cfg)
+    model.initialize()
+    synth.fill_state_dict(model, 9)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.cuda().eval()
+    dc = DeviceCorpus(corpus)
+    beh = DeviceBehaviors.from_devtest(dc, corpus, 'dev')
+    cache = model.build_news_cache(dc, rows_per_pass=25)                   # several passes over the 60 news
+    assert cache.shape == (60, cfg.lime_output_dim)
+    rows = list(range(beh.num))
+    got = model.score_behaviors(beh, rows, cache).cpu()
+    batch = beh.assemble(rows)
+    remaining = batch[24] - batch[23]
+    model.use_graph = False
+    ref = model(*batch, remaining).cpu().reshape(-1)
+    assert rel_err(got.numpy(), ref.numpy()) < 2e-5
+    names = list(synth.make_batch(cfg, 2, 2, seed=0).keys())
+    want = O.model_forward(sd, cfg, {n: t.cpu() for n, t in zip(names, batch + [remaining])}, eval_shape=True).reshape(-1)
+    assert rel_err(got.numpy(), want.numpy()) < 1e-3

@@ -48,6 +48,38 @@ def main():
     torch.cuda.synchronize()
     print('host numpy gather + copy (reference path restated): %.1f us per batch' % ((time.perf_counter() - t0) / m * 1e6))
 
+    # eval with the per-news content cache: the token encoders run once per news, scoring looks representations up
+    from lime_cikm25_amd import Model
+    model = Model(cfg)
+    model.initialize()
+    synth.fill_state_dict(model, seed=1)
+    model = model.cuda().eval()
+    n_imp, K = 256, 100                                   # 256 impressions x 100 candidates = 25,600 (impression, candidate) rows
+    dev_beh = []
+    for i in range(n_imp):
+        base = corpus.train_behaviors[i]
+        for k in range(K):
+            dev_beh.append([base[0], base[1], base[2], int(rng.integers(1, 65000)), i * K + k, base[6], base[7], base[9], base[10]])
+    corpus.dev_behaviors = dev_beh
+    beh = DeviceBehaviors.from_devtest(dc, corpus, 'dev')
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cache = model.build_news_cache(dc)
+    torch.cuda.synchronize()
+    t_cache = time.perf_counter() - t0
+    print('content cache: %d news in %.2f s (%.0f news/s)' % (cache.shape[0], t_cache, cache.shape[0] / t_cache))
+    rows = torch.arange(beh.num, device='cuda')
+    chunk = 8192
+    model.score_behaviors(beh, rows[:chunk], cache)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for r0 in range(0, beh.num, chunk):
+        model.score_behaviors(beh, rows[r0:r0 + chunk], cache)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print('cached scoring: %d (impression, candidate) rows in %.3f s = %.0f rows/s (%.0f impressions of %d candidates /s); '
+          'every row re-encoded would need %d news encodes' % (beh.num, dt, beh.num / dt, beh.num / dt / K, K, beh.num * (cfg.max_history_num + 1)))
+
 
 if __name__ == '__main__':
     main()
