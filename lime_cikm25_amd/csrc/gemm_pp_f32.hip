@@ -13,15 +13,17 @@
 //     (10 independent accumulator tiles), so a CU with one workgroup left is not slower per tile.
 //   * operands go global -> LDS without passing registers: no staging VGPRs (the budget goes to a 32 x 320 accumulator
 //     slab per wave), no ds_write, no vmcnt wait in front of a ds_write.  K chunks are 16 deep, two LDS stages; the DMA of
-//     chunk c + 1 is in flight under the MFMAs of chunk c; one barrier per chunk.
+//     chunk c + 1 is in flight under the MFMAs of chunk c (a wave issues its two A instructions in front of them and its
+//     weight instructions in the middle, staggered by wave, so that the workgroup's 28 instructions do not queue up in
+//     the CU's address path all at once); one barrier per chunk.
 //   * an LDS-DMA instruction writes 1 KB linearly (lane l -> base + 16 l), so rows cannot be padded; the image is
-//     [row][16 floats] with the 16-byte segment index XOR-swizzled by (row >> 2) & 3 -- applied to the per-lane SOURCE
-//     address when staging and to the ds_read_b128 address when reading fragments (conflict free: the 16 lanes of a
-//     read phase cover all 16 bank groups).
+//     [row][16 floats] with the 16-byte segment index XOR-swizzled by swz4((row >> 2) & 3) -- applied to the per-lane
+//     SOURCE address when staging and to the ds_read_b128 address when reading fragments (see swz4: the permutation is
+//     chosen for the hardware's non-contiguous 16-lane read groups; measured SQ_LDS_BANK_CONFLICT = 0).
 //   * the MFMA is v_mfma_f32_16x16x4_f32, not 32x32x2: same nominal rate, same LDS traffic per flop here, but half the
-//     accumulator-register traffic per flop -- and the fp32 matrix rate of this chip is POWER limited on real data:
-//     tools/probes/mfma_probe (registers only, random operands, sustained) holds 122 TFLOP/s with 32x32x2 against 154
-//     with 16x16x4 (both 155 on zeros).
+//     accumulator-register traffic per flop.  (A registers-only MFMA loop on random operands is POWER limited with
+//     32x32x2 -- tools/probes/mfma_probe sustains 122 TFLOP/s against 154 with 16x16x4, both 155 on zeros; this kernel is
+//     not: tools/power_probe.py, same time on zeros and random data at 2.39 GHz.)
 //   * a wave owns 32 output rows x all tile columns of the transposed product D^T = W A^T: an output row lives in the
 //     four lanes (i, i + 16, i + 32, i + 48), each holding 4 of every 16 columns as consecutive registers -- residual
 //     loads / result stores are 16-byte accesses, and LayerNorm needs no cross-wave exchange at all (in-lane sums +
