@@ -10,26 +10,28 @@ import json
 import numpy as np
 
 
+def _by_score(y_true, y_score, k=None):
+    """Labels reordered by descending score (numpy's default sort reversed, as the reference does: evaluate.py:8, :22)."""
+    ranked = np.take(y_true, np.argsort(y_score)[::-1][:k])
+    return ranked, np.arange(ranked.shape[0])
+
+
 def dcg_score(y_true, y_score, k=10):
-    """evaluate.py:7-12."""
-    order = np.argsort(y_score)[::-1]
-    y_true = np.take(y_true, order[:k])
-    gains = 2 ** y_true - 1
-    discounts = np.log2(np.arange(len(y_true)) + 2)
-    return np.sum(gains / discounts)
+    """sum_i (2^rel_i - 1) / log2(i + 2) over the k best-scored items (evaluate.py:7-12)."""
+    rel, pos = _by_score(y_true, y_score, k)
+    return np.sum((2 ** rel - 1) / np.log2(pos + 2))
 
 
 def ndcg_score(y_true, y_score, k=10):
-    """evaluate.py:15-18."""
-    return dcg_score(y_true, y_score, k) / dcg_score(y_true, y_true, k)
+    """DCG normalised by the DCG of the ideal order (evaluate.py:15-18)."""
+    ideal = dcg_score(y_true, y_true, k)
+    return dcg_score(y_true, y_score, k) / ideal
 
 
 def mrr_score(y_true, y_score):
-    """evaluate.py:21-25."""
-    order = np.argsort(y_score)[::-1]
-    y_true = np.take(y_true, order)
-    rr_score = y_true / (np.arange(len(y_true)) + 1)
-    return np.sum(rr_score) / np.sum(y_true)
+    """Sum of label / rank over the label mass (evaluate.py:21-25)."""
+    rel, pos = _by_score(y_true, y_score)
+    return np.sum(rel / (pos + 1)) / np.sum(y_true)
 
 
 def roc_auc_score(y_true, y_score):
@@ -51,39 +53,45 @@ def roc_auc_score(y_true, y_score):
 
 
 def parse_line(line):
-    """evaluate.py:27-30."""
-    impid, ranks = line.strip('\n').split()
-    return impid, json.loads(ranks)
+    """'<impression id> [v1,v2,...]' -> (id, list)  (evaluate.py:27-30)."""
+    impid, payload = line.strip('\n').split()
+    return impid, json.loads(payload)
+
+
+def _rank_scores(ranks, n_labels, line_no):
+    """A rank file stores 1-based ranks; the metrics consume 1 / rank (evaluate.py:60-66)."""
+    out = []
+    for r in ranks:
+        v = 1. / r
+        if not 0 <= v <= 1:
+            raise ValueError('Line-{}: score_rslt should be int from 0 to {}'.format(line_no, float(n_labels)))
+        out.append(v)
+    return out
 
 
 def scoring(truth_f, sub_f):
-    """evaluate.py:32-89: (AUC, MRR, nDCG@5, nDCG@10) averaged over the impressions of a truth file and a rank file."""
-    aucs, mrrs, ndcg5s, ndcg10s = [], [], [], []
-    line_index = 1
-    for lt in truth_f:
-        ls = sub_f.readline()
-        impid, labels = parse_line(lt)
-        if labels == []:                       # masked impression
+    """(AUC, MRR, nDCG@5, nDCG@10) averaged over the impressions of a truth file and a rank file read in lock step
+    (evaluate.py:32-89): impressions with an empty label list are skipped, a missing submission line counts as all-ones."""
+    per_impression = []
+    line_no = 1
+    for truth_line in truth_f:
+        sub_line = sub_f.readline()
+        impid, labels = parse_line(truth_line)
+        if not labels:                          # masked impression (the submission line is consumed all the same)
             continue
-        if ls == '':
-            sub_impid, sub_ranks = impid, [1] * len(labels)
+        if sub_line == '':
+            sub_id, ranks = impid, [1] * len(labels)
         else:
             try:
-                sub_impid, sub_ranks = parse_line(ls)
+                sub_id, ranks = parse_line(sub_line)
             except Exception:
-                raise ValueError('line-{}: Invalid Input Format!'.format(line_index))
-        if sub_impid != impid:
-            raise ValueError('line-{}: Inconsistent Impression Id {} and {}'.format(line_index, sub_impid, impid))
+                raise ValueError('line-{}: Invalid Input Format!'.format(line_no))
+        if sub_id != impid:
+            raise ValueError('line-{}: Inconsistent Impression Id {} and {}'.format(line_no, sub_id, impid))
         y_true = np.array(labels, dtype='float32')
-        y_score = []
-        for rank in sub_ranks:
-            score_rslt = 1. / rank
-            if score_rslt < 0 or score_rslt > 1:
-                raise ValueError('Line-{}: score_rslt should be int from 0 to {}'.format(line_index, float(len(labels))))
-            y_score.append(score_rslt)
-        aucs.append(roc_auc_score(y_true, y_score))
-        mrrs.append(mrr_score(y_true, y_score))
-        ndcg5s.append(ndcg_score(y_true, y_score, 5))
-        ndcg10s.append(ndcg_score(y_true, y_score, 10))
-        line_index += 1
-    return np.mean(aucs), np.mean(mrrs), np.mean(ndcg5s), np.mean(ndcg10s)
+        y_score = _rank_scores(ranks, len(labels), line_no)
+        per_impression.append((roc_auc_score(y_true, y_score), mrr_score(y_true, y_score), ndcg_score(y_true, y_score, 5),
+                               ndcg_score(y_true, y_score, 10)))
+        line_no += 1
+    cols = list(zip(*per_impression)) if per_impression else [[], [], [], []]
+    return tuple(np.mean(c) for c in cols)
