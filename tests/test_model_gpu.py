@@ -252,6 +252,26 @@ def test_score_impressions_equals_eval_forward_on_expanded_rows():
     assert torch.equal(again, got)
 
 
+def test_long_body_shape_against_oracle():
+    """BASELINE config 4's sequence shape (Adressa: body length 512, title 32) in the forward: the S = 512 attention path
+    (16 key tiles, K / V tiled inside one workgroup) and the chunked token passes, against the oracle."""
+    from lime_cikm25_amd import newsEncoders
+    cfg = make_config(max_history_num=5, max_abstract_length=512, batch_size=8, vocabulary_size=3000)
+    model, sd = gpu_model(cfg, seed=51)
+    batch = synth.make_batch(cfg, 3, 2, seed=52)
+    want = O.model_forward(sd, cfg, batch)
+    got = run(model, batch, False)
+    assert rel_err(got.numpy(), want.numpy()) < TOL
+    old = newsEncoders.MAX_TOKENS_PER_PASS
+    try:                                                     # force several token passes per encoder (7 news per pass)
+        newsEncoders.MAX_TOKENS_PER_PASS = 7 * 512
+        model._graphs.clear()
+        again = run(model, batch, False)
+    finally:
+        newsEncoders.MAX_TOKENS_PER_PASS = old
+    assert rel_err(again.numpy(), want.numpy()) < TOL
+
+
 def test_eval_harness_on_gpu(tmp_path):
     """compute_scores (util.py:77-129) with the HIP model on eval-shaped rows: the rank file equals the one built from
     the oracle's scores wherever those are separated beyond the tolerance, and the four metrics agree."""
