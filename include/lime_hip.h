@@ -67,7 +67,10 @@ enum { LIME_ACT_NONE = 0, LIME_ACT_RELU = 1, LIME_ACT_TANH = 2, LIME_ACT_SIGMOID
  *        res_ids != NULL : res[res_ids[r] * ldr + n] (+ res_pe[(r % res_period) * ldr_pe + n])
  *   ln_gamma != NULL : v = LayerNorm over the N columns of row r (eps = ln_eps); requires N <= 320 and either no
  *        activation (residual allowed) or ReLU without residual
- *   c[r * ldc + n] = v
+ *   c[r * ldc + n] = v                                   (pool32 == 0)
+ *   pool32 == 1: c[(r / 32) * ldc + n] = mean over the 32 rows of block r / 32 of v -- the token mean pooling of
+ *        newsEncoders.py:317,321 taken in the epilogue (a 32-token title is finished; a longer sequence is the mean of its
+ *        S / 32 block rows).  Needs M % 32 == 0, M >= 4096, the LayerNorm epilogue with a dense residual, 16-byte operands.
  * lda/ldw/ldr/ldc are in elements.
  */
 typedef struct {
@@ -82,7 +85,7 @@ typedef struct {
     int32_t M, N, K;
     int32_t act;
     int32_t res_mod;      /* > 0 (res_ids == NULL): residual row = (r / res_div) % res_mod -- a periodic table */
-    int32_t reserved;     /* must be 0 */
+    int32_t pool32;       /* 1: (LayerNorm epilogue) c is [M / 32, N]: row r = mean of result rows 32 r .. 32 r + 31 */
 } lime_linear_args;
 
 int lime_linear_f32(const lime_linear_args* args, void* stream);
@@ -111,9 +114,11 @@ typedef struct {
     const void* res;      int64_t ldr;   int32_t res_kind; int32_t res_mod;
     const int32_t* res_ids; const float* res_pe; int64_t ldr_pe; int32_t res_period;
     const float* ln_gamma; const float* ln_beta; float ln_eps; int32_t ln_count;
-    uint16_t* c;          int64_t ldc;
+    uint16_t* c;          int64_t ldc;      /* pool32: float* instead, [M / 32, N] (see lime_linear_args.pool32) */
     int32_t M, N, K;
     int32_t act;
+    int32_t pool32;       /* 1: LayerNorm epilogue with a bf16 residual (res_kind 3) only; M % 32 == 0; fp32 block means */
+    int32_t reserved;     /* must be 0 */
 } lime_linear_bf16_args;
 
 int lime_linear_bf16(const lime_linear_bf16_args* args, void* stream);

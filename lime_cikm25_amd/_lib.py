@@ -26,7 +26,7 @@ class LinearArgs(Structure):
         ('c', c_void_p), ('ldc', c_int64),
         ('M', c_int32), ('N', c_int32), ('K', c_int32),
         ('act', c_int32),
-        ('res_mod', c_int32), ('reserved', c_int32),
+        ('res_mod', c_int32), ('pool32', c_int32),
     ]
 
 
@@ -43,6 +43,7 @@ class LinearBf16Args(ctypes.Structure):
         ('c', c_void_p), ('ldc', c_int64),
         ('M', c_int32), ('N', c_int32), ('K', c_int32),
         ('act', c_int32),
+        ('pool32', c_int32), ('reserved', c_int32),
     ]
 
 

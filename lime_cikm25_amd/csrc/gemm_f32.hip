@@ -609,15 +609,17 @@ extern "C" int lime_linear_f32(const lime_linear_args* a, void* stream) {
                  "lime_linear_f32: res_pe needs res_ids, res_period > 0 and ldr_pe >= N");
     LIME_REQUIRE(!a->ln_gamma || a->ln_beta, LIME_ERR_BAD_ARG, "lime_linear_f32: ln_gamma without ln_beta");
     LIME_REQUIRE(a->act >= LIME_ACT_NONE && a->act <= LIME_ACT_SIGMOID, LIME_ERR_BAD_ARG, "lime_linear_f32: bad act %d", a->act);
-    LIME_REQUIRE(a->res_mod >= 0 && a->reserved == 0, LIME_ERR_BAD_ARG, "lime_linear_f32: res_mod < 0 or reserved != 0");
+    LIME_REQUIRE(a->res_mod >= 0 && (a->pool32 == 0 || a->pool32 == 1), LIME_ERR_BAD_ARG, "lime_linear_f32: res_mod < 0 or pool32 not 0 / 1");
     if (a->M == 0) return LIME_OK;
 
     // big M, 16-byte friendly operands: two four-wave workgroups per CU with LDS-DMA staging (gemm_pp_f32.hip)
     static const bool pp_off = getenv("LIME_GEMM_NO_PP") != nullptr;          // A/B switch for tools/, not a product option
-    if (!pp_off) {
+    if (!pp_off || a->pool32) {
         const int st = lime_linear_pp(a, (hipStream_t)stream);
         if (st != LIME_PP_NOT_APPLICABLE) return st;
     }
+    LIME_REQUIRE(!a->pool32, LIME_ERR_UNSUPPORTED,
+                 "lime_linear_f32: pool32 needs the big-M kernel (M >= 4096 and a multiple of 32, LayerNorm + dense residual, 16-byte operands)");
 
     GemmP p;
     p.a = a->a; p.lda = a->lda; p.a_ids = a->a_ids; p.a_pe = a->a_pe; p.lda_pe = a->lda_pe; p.a_period = a->a_period;

@@ -110,12 +110,29 @@ __device__ __forceinline__ void buf_store4(f32x4 v, __amdgpu_buffer_rsrc_t r, un
 // 49 % of the LDS cycles).  The permutation {0, 2, 3, 1} of (r >> 2) & 3 makes all four groups conflict free.
 __device__ __forceinline__ int swz4(int q) { return (0x78 >> (2 * q)) & 3; }
 
+// Sum over the 16 lanes of a DPP row (the lanes that share a k slot, i.e. the 16 tokens of an MFMA tile): butterfly with
+// quad_perm (xor 1, xor 2) and row rotations by 4 and 8; every lane ends up with the total.
+__device__ __forceinline__ float row16_sum(float v) {
+    int x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));        // quad_perm [1,0,3,2]
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));        // quad_perm [2,3,0,1]
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x124, 0xF, 0xF, true));       // row_ror:4
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, true));       // row_ror:8
+    return v;
+}
+
 // NTL: 32-column MFMA tiles per wave (tile width 32 * NTL).  LN: LayerNorm epilogue (one column block spans N).
 // RES: 0 none, 1 dense fp32 residual rows (r, or r % res_mod), 2 gathered rows + fp32 positional table,
 //      3 (BF only) dense bf16 residual rows.
 // BF:  bf16 operands (A rows, gathered table rows, W) and bf16 output, v_mfma_f32_16x16x32_bf16, fp32 accumulation and
 //      epilogue (lime_linear_bf16).  The LDS image is byte-identical: a row's chunk is 64 bytes = 16 floats or 32 bf16.
-template <int NTL, bool LN, bool RELU, int RES, bool BF>
+// POOL: (LayerNorm epilogue) instead of the [M, N] result, row r of C is the mean of result rows 32 r .. 32 r + 31 -- a
+//      wave's 32 output rows -- so the mean pooling over the tokens of a news (newsEncoders.py:317,321) never sees the
+//      activations in HBM: S = 32 sequences are finished here, longer ones by a mean over their S / 32 block rows.
+template <int NTL, bool LN, bool RELU, int RES, bool BF, bool POOL = false>
 __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
     constexpr int ES = BF ? 2 : 4;                 // operand element size
     constexpr int EPS = 16 / ES;                   // elements per 16-byte segment
@@ -388,21 +405,39 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
         }
         const float* const gs = Gs + 4 * kg;
         const float* const es = Es + 4 * kg;
+        if constexpr (POOL) {
+            // block row (row0 + 32 wave) / 32 of C: the column means over this wave's 32 output rows (all valid or all beyond M)
+            const int rl0 = 32 * wave;
+            const __amdgpu_buffer_rsrc_t rs_p = make_rsrc((char*)p.c + ((long)((row0 + rl0) >> 5) * p.ldc + col0) * 4);
+            const bool rows_ok = row0 + rl0 < p.M;
 #pragma unroll
-        for (int t = 0; t < NT16; ++t) {
-            f32x4 ga, be;
-            if constexpr (LN) {
-                ga = *reinterpret_cast<const f32x4*>(gs + 16 * t);
-                be = *reinterpret_cast<const f32x4*>(es + 16 * t);
+            for (int t = 0; t < NT16; ++t) {
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(gs + 16 * t);
+                const f32x4 be = *reinterpret_cast<const f32x4*>(es + 16 * t);
+                f32x4 y = (acc[0][t] - mean[0]) * rstd[0] * ga + be;
+                y += (acc[1][t] - mean[1]) * rstd[1] * ga + be;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = row16_sum(y[j]) * (1.0f / 32.0f);
+                const bool ok = rows_ok && fi == 0 && (col0 + 16 * t + 4 * kg < p.N);
+                buf_store4(y, rs_p, ok ? (unsigned)(16 * t + 4 * kg) * 4u : OOB, 0);
             }
+        } else {
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                f32x4 y = acc[tt][t];
-                if constexpr (LN) y = (y - mean[tt]) * rstd[tt] * ga + be;
-                unsigned o = cof[tt] + (unsigned)t * (16u * ES);
-                if (t >= NT16 - 4) o = (col0 + 16 * t + 4 * kg < p.N) ? o : OOB;
-                if constexpr (BF) buf_store4_bf16(y, rs_c, o, 0);
-                else buf_store4(y, rs_c, o, 0);
+            for (int t = 0; t < NT16; ++t) {
+                f32x4 ga, be;
+                if constexpr (LN) {
+                    ga = *reinterpret_cast<const f32x4*>(gs + 16 * t);
+                    be = *reinterpret_cast<const f32x4*>(es + 16 * t);
+                }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    f32x4 y = acc[tt][t];
+                    if constexpr (LN) y = (y - mean[tt]) * rstd[tt] * ga + be;
+                    unsigned o = cof[tt] + (unsigned)t * (16u * ES);
+                    if (t >= NT16 - 4) o = (col0 + 16 * t + 4 * kg < p.N) ? o : OOB;
+                    if constexpr (BF) buf_store4_bf16(y, rs_c, o, 0);
+                    else buf_store4(y, rs_c, o, 0);
+                }
             }
         }
     };
@@ -490,7 +525,7 @@ int num_cus() {
     return n;
 }
 
-template <int NTL, bool LN, bool RELU, int RES, bool BF = false>
+template <int NTL, bool LN, bool RELU, int RES, bool BF = false, bool POOL = false>
 int launch(const PPParams& p0, hipStream_t stream) {
     PPParams p = p0;
     p.n_row_blocks = (p.M + BM - 1) / BM;
@@ -501,9 +536,9 @@ int launch(const PPParams& p0, hipStream_t stream) {
 #ifdef LIME_STAMPS
     p.stamps = g_pp_stamp_buf;
 #endif
-    hipLaunchKernelGGL((gemm_pp_kernel<NTL, LN, RELU, RES, BF>), dim3((unsigned)nwg), dim3(256), 0, stream, p);
-    lime_set_last_linear_kernel("gemm_pp_kernel<%d, %s, %s, %d, %s>", NTL, LN ? "true" : "false", RELU ? "true" : "false", RES,
-                                BF ? "true" : "false");
+    hipLaunchKernelGGL((gemm_pp_kernel<NTL, LN, RELU, RES, BF, POOL>), dim3((unsigned)nwg), dim3(256), 0, stream, p);
+    lime_set_last_linear_kernel(POOL ? "gemm_pp_kernel<%d, %s, %s, %d, %s, true>" : "gemm_pp_kernel<%d, %s, %s, %d, %s>", NTL,
+                                LN ? "true" : "false", RELU ? "true" : "false", RES, BF ? "true" : "false");
     return lime_check_launch("lime_linear_f32");
 }
 
@@ -535,6 +570,7 @@ int lime_linear_pp(const lime_linear_args* a, hipStream_t s) {
         if (res == 1 && a->res_mod > 0 && (long)a->res_mod * a->ldr * 4 >= lim) return LIME_PP_NOT_APPLICABLE;
     }
     if (ln && (a->N > 320 || relu)) return LIME_PP_NOT_APPLICABLE;
+    if (a->pool32 && !(ln && has_res && !a->res_ids && a->res_div <= 1 && a->M % 32 == 0)) return LIME_PP_NOT_APPLICABLE;
     // column validity is tested in the last two 32-column tiles of a block only: the last block must not be narrower
     auto tail_ok = [&](int bn) { const int last = a->N - (a->N - 1) / bn * bn; return last >= bn - 64; };
 
@@ -549,7 +585,7 @@ int lime_linear_pp(const lime_linear_args* a, hipStream_t s) {
     if (ln) {
         if (!tail_ok(320)) return LIME_PP_NOT_APPLICABLE;
         if (res == 0) return launch<10, true, false, 0>(p, s);
-        if (res == 1) return launch<10, true, false, 1>(p, s);
+        if (res == 1) return a->pool32 ? launch<10, true, false, 1, false, true>(p, s) : launch<10, true, false, 1>(p, s);
         return launch<10, true, false, 2>(p, s);
     }
     if (res == 2) return LIME_PP_NOT_APPLICABLE;
@@ -575,7 +611,11 @@ extern "C" int lime_linear_bf16(const lime_linear_bf16_args* a, void* stream) {
     auto al = [](const void* ptr, long ld, int elem, int bytes) { return ptr == nullptr || ((uintptr_t)ptr % bytes == 0 && (ld * elem) % bytes == 0); };
     LIME_REQUIRE(al(a->a, a->lda, 2, 16) && al(a->w, a->ldw, 2, 16), LIME_ERR_BAD_ARG,
                  "lime_linear_bf16: a / w rows must be 16-byte aligned (lda, ldw multiples of 8)");
-    LIME_REQUIRE(al(a->c, a->ldc, 2, 8), LIME_ERR_BAD_ARG, "lime_linear_bf16: c rows must be 8-byte aligned (ldc multiple of 4)");
+    LIME_REQUIRE(a->reserved == 0 && (a->pool32 == 0 || a->pool32 == 1), LIME_ERR_BAD_ARG, "lime_linear_bf16: pool32 must be 0 / 1, reserved 0");
+    LIME_REQUIRE(a->pool32 ? al(a->c, a->ldc, 4, 16) : al(a->c, a->ldc, 2, 8), LIME_ERR_BAD_ARG,
+                 "lime_linear_bf16: c rows must be 8-byte aligned (ldc multiple of 4); pool32: 16-byte aligned fp32 rows");
+    LIME_REQUIRE(!a->pool32 || (a->ln_gamma && a->res_kind == 3 && a->M % 32 == 0), LIME_ERR_UNSUPPORTED,
+                 "lime_linear_bf16: pool32 needs the LayerNorm epilogue with a bf16 residual and M %% 32 == 0");
     LIME_REQUIRE(a->res_kind >= 0 && a->res_kind <= 3 && (a->res_kind == 0) == (a->res == nullptr), LIME_ERR_BAD_ARG,
                  "lime_linear_bf16: res_kind %d does not match res", a->res_kind);
     LIME_REQUIRE(a->act == LIME_ACT_NONE || (a->act == LIME_ACT_RELU && a->res_kind == 0), LIME_ERR_UNSUPPORTED,
@@ -590,7 +630,7 @@ extern "C" int lime_linear_bf16(const lime_linear_bf16_args* a, void* stream) {
     if (a->res_kind == 3) LIME_REQUIRE(al(a->res, a->ldr, 2, 8) && a->ldr >= a->N, LIME_ERR_BAD_ARG, "lime_linear_bf16: bf16 residual misaligned");
     if (a->M == 0) return LIME_OK;
     const long lim = 0x7FFFFFF0L;
-    LIME_REQUIRE(128L * a->lda * 2 < lim && (long)a->N * a->ldw * 2 < lim && 128L * a->ldc * 2 < lim && 128L * a->ldr * 4 < lim &&
+    LIME_REQUIRE(128L * a->lda * 2 < lim && (long)a->N * a->ldw * 2 < lim && 128L * a->ldc * 4 < lim && 128L * a->ldr * 4 < lim &&
                  (long)a->M * 4 < lim, LIME_ERR_UNSUPPORTED, "lime_linear_bf16: operand too large for 32-bit offsets");
     const bool wide = ((a->N + 319) / 320 * 320 - a->N) < ((a->N + 255) / 256 * 256 - a->N);
     const int bn = (ln || wide) ? 320 : 256;
@@ -610,7 +650,7 @@ extern "C" int lime_linear_bf16(const lime_linear_bf16_args* a, void* stream) {
         switch (a->res_kind) {
             case 0: return launch<10, true, false, 0, true>(p, s);
             case 2: return launch<10, true, false, 2, true>(p, s);
-            case 3: return launch<10, true, false, 3, true>(p, s);
+            case 3: return a->pool32 ? launch<10, true, false, 3, true, true>(p, s) : launch<10, true, false, 3, true>(p, s);
             default: break;
         }
         LIME_REQUIRE(false, LIME_ERR_UNSUPPORTED, "lime_linear_bf16: LayerNorm with an fp32 residual is not built");

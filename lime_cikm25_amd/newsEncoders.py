@@ -334,11 +334,14 @@ class CategoryPredictor(nn.Module):
         self.fc = nn.Linear(title_embedding, category_num)
 
 
-def encode_tokens(ids, table, pe, transformer, nhead):
+def encode_tokens(ids, table, pe, transformer, nhead, pooled_out=None):
     """Word gather + positional table + the post-LN encoder layer(s) of newsEncoders.py:311-320.
 
     ids: [M, S] int32 (every id must be in [0, V): unchecked, as on nn.Embedding's device path);
     returns the layer output [M * S, E].  Five launches per layer, activations stay fp32.
+    With ``pooled_out`` ([M, E]) the token mean pooling of :317 / :321 is taken in the last GEMM's epilogue (pool32: means
+    over 32-token blocks; a longer sequence is finished by a mean over its S / 32 block rows) and the layer output never
+    reaches HBM; returns None then.
     """
     M, S = ids.shape
     E = table.shape[1]
@@ -367,10 +370,20 @@ def encode_tokens(ids, table, pe, transformer, nhead):
         else:
             x1 = ops.linear(attn, sa.out_proj.weight, sa.out_proj.bias, res=x, ln=ln1, ln_eps=layer.norm1.eps)
         h = ops.linear(x1, layer.linear1.weight, layer.linear1.bias, act='relu')
+        last = li == len(transformer.layers) - 1
+        if last and pooled_out is not None and transformer.norm is None and S % 32 == 0 and M * S >= 4096:
+            blocks = ops.linear(h, layer.linear2.weight, layer.linear2.bias, res=x1, ln=(layer.norm2.weight, layer.norm2.bias),
+                                ln_eps=layer.norm2.eps, pool32=True, out=pooled_out if S == 32 else None)
+            if S != 32:
+                ops.mean_pool(blocks, M, S // 32, out=pooled_out)
+            return None
         x = ops.linear(h, layer.linear2.weight, layer.linear2.bias, res=x1, ln=(layer.norm2.weight, layer.norm2.bias),
                        ln_eps=layer.norm2.eps)
     if transformer.norm is not None:
         raise NotImplementedError('a final encoder norm is not used by the reference (newsEncoders.py:245,247)')
+    if pooled_out is not None:
+        ops.mean_pool(x, M, S, out=pooled_out)
+        return None
     return x
 
 
@@ -412,6 +425,13 @@ def encode_tokens_bf16(ids, table_bf16, pe, transformer, nhead, pooled_out):
         else:
             x1 = ops.linear_bf16(attn, w_o, padv(sa.out_proj.bias), res=x, res_kind=3, ln=ln1, ln_eps=layer.norm1.eps, ln_count=E)
         h = ops.linear_bf16(x1, ops.to_bf16(layer.linear1.weight, cols_out=EP), layer.linear1.bias, act='relu')
+        last = li == len(transformer.layers) - 1
+        if last and transformer.norm is None:
+            # token mean pooling in the epilogue: fp32 means over 32-token blocks, [M * S / 32, EP]
+            blocks = ops.linear_bf16(h, ops.to_bf16(layer.linear2.weight, rows_out=EP), padv(layer.linear2.bias), res=x1, res_kind=3,
+                                     ln=(padv(layer.norm2.weight), padv(layer.norm2.bias)), ln_eps=layer.norm2.eps, ln_count=E,
+                                     pool32=True)
+            return ops.mean_pool(blocks[:, :E], M, S // 32, out=pooled_out)
         x = ops.linear_bf16(h, ops.to_bf16(layer.linear2.weight, rows_out=EP), padv(layer.linear2.bias), res=x1, res_kind=3,
                             ln=(padv(layer.norm2.weight), padv(layer.norm2.bias)), ln_eps=layer.norm2.eps, ln_count=E)
     if transformer.norm is not None:
@@ -501,8 +521,8 @@ class CROWN(NewsEncoder):
                         encode_tokens_bf16(ids[m0:m1], table_b, pos.table(), tr, self.head_num,
                                            xin[half * M + m0:half * M + m1, :E])
                         continue
-                    y = encode_tokens(ids[m0:m1], table, pos.table(), tr, self.head_num)                 # :311-320
-                    ops.mean_pool(y, m1 - m0, S, out=xin[half * M + m0:half * M + m1, :E])                # :317,:321
+                    encode_tokens(ids[m0:m1], table, pos.table(), tr, self.head_num,
+                                  pooled_out=xin[half * M + m0:half * M + m1, :E])                                   # :311-321
         main.wait_stream(side)
         # category representation (:340-342) and the raw category / subCategory rows of feature_fusion (:221-225)
         sub_table = self.subCategory_embedding.weight

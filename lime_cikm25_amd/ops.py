@@ -61,7 +61,7 @@ def _mask_u8(mask, name):
 
 
 def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=0, res=None, res_div=1, res_ids=None,
-           res_pe=None, res_period=0, ln=None, ln_eps=1e-5, res_mod=0):
+           res_pe=None, res_period=0, ln=None, ln_eps=1e-5, res_mod=0, pool32=False):
     """C = epilogue(A . W^T + bias) -- see ``lime_linear_f32`` in include/lime_hip.h.
 
     a: [M, K] (or the [V, K] table when a_ids is given, M = len(a_ids)); w: [N, K]; out: [M, N] (may be a view).
@@ -78,12 +78,16 @@ def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=
         M = a_ids.numel()
     else:
         M = a.shape[0]
+    rows_out = M // 32 if pool32 else M
+    if pool32 and M % 32:
+        raise ValueError('pool32 needs M %% 32 == 0 (M = %d)' % M)
     if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        out = torch.empty((rows_out, N), dtype=torch.float32, device=a.device)
     _mat(out, 'out')
-    if tuple(out.shape) != (M, N):
-        raise ValueError('out must be [%d, %d], got %s' % (M, N, tuple(out.shape)))
+    if tuple(out.shape) != (rows_out, N):
+        raise ValueError('out must be [%d, %d], got %s' % (rows_out, N, tuple(out.shape)))
     args = LinearArgs()
+    args.pool32 = 1 if pool32 else 0
     args.a, args.lda = a.data_ptr(), _ld(a)
     args.a_ids = a_ids.data_ptr() if a_ids is not None else None
     if a_pe is not None:
@@ -410,7 +414,7 @@ def to_bf16(src, rows_out=None, cols_out=None, out=None):
 
 
 def linear_bf16(a, w, bias=None, act=None, out=None, a_ids=None, res=None, res_kind=0, res_mod=0, res_ids=None, res_pe=None,
-                res_period=0, ln=None, ln_eps=1e-5, ln_count=None):
+                res_period=0, ln=None, ln_eps=1e-5, ln_count=None, pool32=False):
     """``lime_linear_bf16``: a / w / out (and residual kinds 2, 3) bfloat16, bias / LayerNorm / residual kind 1 fp32."""
     lib = _lib.load()
     _mat(a, 'a', dtype=torch.bfloat16)
@@ -419,12 +423,16 @@ def linear_bf16(a, w, bias=None, act=None, out=None, a_ids=None, res=None, res_k
     if a.shape[1] != K:
         raise ValueError('a has %d columns, w has K=%d' % (a.shape[1], K))
     M = a_ids.numel() if a_ids is not None else a.shape[0]
+    if pool32 and M % 32:
+        raise ValueError('pool32 needs M %% 32 == 0 (M = %d)' % M)
+    rows_out, odt = (M // 32, torch.float32) if pool32 else (M, torch.bfloat16)       # pool32: fp32 means over 32-row blocks
     if out is None:
-        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
-    _mat(out, 'out', dtype=torch.bfloat16)
-    if tuple(out.shape) != (M, N):
-        raise ValueError('out must be [%d, %d], got %s' % (M, N, tuple(out.shape)))
+        out = torch.empty((rows_out, N), dtype=odt, device=a.device)
+    _mat(out, 'out', dtype=odt)
+    if tuple(out.shape) != (rows_out, N):
+        raise ValueError('out must be [%d, %d], got %s' % (rows_out, N, tuple(out.shape)))
     args = _lib.LinearBf16Args()
+    args.pool32 = 1 if pool32 else 0
     args.a, args.lda = a.data_ptr(), _ld(a)
     args.a_ids = _vec(a_ids, 'a_ids', dtype=torch.int32).data_ptr() if a_ids is not None else None
     args.w, args.ldw = w.data_ptr(), _ld(w)

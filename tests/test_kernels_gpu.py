@@ -223,6 +223,26 @@ def test_linear_pp_is_deterministic(ops):
         assert torch.equal(ops.linear(a, w, b, res=r, ln=(g, be)), first)
 
 
+@pytest.mark.parametrize('M,K', [(4096, 512), (9024, 300), (70400, 512)])
+def test_linear_pool32_epilogue(ops, M, K):
+    """pool32: the LayerNorm output averaged over 32-row blocks in the epilogue == mean_pool of the full result."""
+    N = 300
+    a, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3), rnd(M, N, seed=4)
+    g, be = rnd(N, seed=5) + 1.5, rnd(N, seed=6)
+    full = ops.linear(dev(a), dev(w), dev(b), res=dev(r), ln=(dev(g), dev(be)))
+    big = torch.full((M // 32, N + 52), 7.0, device='cuda')
+    got = ops.linear(dev(a), dev(w), dev(b), res=dev(r), ln=(dev(g), dev(be)), pool32=True, out=big[:, :N])
+    assert last_kernel().startswith('gemm_pp_kernel<10, true, false, 1, false, true'), last_kernel()
+    check(got, full.cpu().view(M // 32, 32, N).mean(dim=1), what='pool32')
+    assert (big[:, N:] == 7).all()
+    check(got, O.layer_norm(r + a @ w.t() + b, g, be).view(M // 32, 32, N).mean(dim=1), what='pool32 vs oracle')
+    from lime_cikm25_amd._lib import LimeHipError
+    with pytest.raises(LimeHipError):                      # needs the big-M kernel
+        ops.linear(dev(a[:64]), dev(w), dev(b), res=dev(r[:64]), ln=(dev(g), dev(be)), pool32=True)
+    with pytest.raises(ValueError):
+        ops.linear(dev(a[:M - 4]), dev(w), dev(b), res=dev(r[:M - 4]), ln=(dev(g), dev(be)), pool32=True)      # M % 32 != 0
+
+
 def test_linear_rejects_bad_shapes(ops):
     from lime_cikm25_amd._lib import LimeHipError
     a, w = dev(rnd(8, 16)), dev(rnd(4, 16))
@@ -550,6 +570,11 @@ def test_linear_bf16_encoder_layer_gemms(ops, M, S):
     want_x2 = O.layer_norm(x1f + h.float().cpu() @ bf(w2).float().t() + b2, g2, be2)
     assert (x2[:, E:] == 0).all()
     check(x2[:, :E].float(), bf(want_x2).float(), tol=BF_TOL, what='bf16 linear2 + LN')
+    mb = M // 32 * 32                                            # pool32: fp32 means over 32-row blocks straight from the epilogue
+    blocks = ops.linear_bf16(h[:mb], ops.to_bf16(dev(w2), rows_out=EP), pad_v(b2), res=x1[:mb], res_kind=3, ln=(pad_v(g2), pad_v(be2)),
+                             ln_count=E, pool32=True)
+    assert blocks.dtype == torch.float32 and blocks.shape == (mb // 32, EP) and (blocks[:, E:] == 0).all()
+    check(blocks[:, :E], want_x2[:mb].view(mb // 32, 32, E).mean(dim=1), tol=BF_TOL, what='bf16 linear2 + LN + pool32')
     n_seq = M // S
     pooled = ops.mean_pool_bf16(x2[:n_seq * S], n_seq, S, E)
     check(pooled, x2[:n_seq * S, :E].float().cpu().view(n_seq, S, E).mean(dim=1), what='bf16 mean pool')
