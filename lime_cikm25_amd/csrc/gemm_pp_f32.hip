@@ -537,8 +537,8 @@ int launch(const PPParams& p0, hipStream_t stream) {
     p.stamps = g_pp_stamp_buf;
 #endif
     hipLaunchKernelGGL((gemm_pp_kernel<NTL, LN, RELU, RES, BF, POOL>), dim3((unsigned)nwg), dim3(256), 0, stream, p);
-    lime_set_last_linear_kernel(POOL ? "gemm_pp_kernel<%d, %s, %s, %d, %s, true>" : "gemm_pp_kernel<%d, %s, %s, %d, %s>", NTL,
-                                LN ? "true" : "false", RELU ? "true" : "false", RES, BF ? "true" : "false");
+    lime_set_last_linear_kernel("gemm_pp_kernel<%d, %s, %s, %d, %s, %s>", NTL, LN ? "true" : "false", RELU ? "true" : "false", RES,
+                                BF ? "true" : "false", POOL ? "true" : "false");          // as rocprofv3 prints the instantiation
     return lime_check_launch("lime_linear_f32");
 }
 
