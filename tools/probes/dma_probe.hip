@@ -3,13 +3,14 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-template <int MODE>   // 0: DMA only; 1: + s_waitcnt lgkmcnt(0) after each batch; 2: + s_waitcnt vmcnt(0) after each batch
+// PIECE: 0 = a DMA instruction covers 16 rows x 64 B (the GEMM's staging pattern), 1 = 8 rows x 128 B (whole cache lines)
+template <int MODE, int PIECE = 0>   // 0: DMA only; 1: + s_waitcnt lgkmcnt(0) after each batch; 2: + s_waitcnt vmcnt(0) after each batch
 __global__ __launch_bounds__(256, 2) void k(const float* src, float* out, int iters, long rows) {
     __shared__ __attribute__((aligned(16))) float lds[14336];            // 56 KB: two workgroups per CU
     __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 0x7FFFFFF0, 0x00020000);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned row = (blockIdx.x * 977u + wave * 131u + (lane >> 2)) % (unsigned)rows;
-    unsigned voff = row * 1200u + (lane & 3) * 16u;
+    unsigned row = (blockIdx.x * 977u + wave * 131u + (PIECE ? (lane >> 3) : (lane >> 2))) % (unsigned)rows;
+    unsigned voff = row * 1200u + (PIECE ? (lane & 7) : (lane & 3)) * 16u;
     const unsigned wrap = (unsigned)(rows * 1200 - 7 * 19200 - 20000);
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -27,13 +28,13 @@ __global__ __launch_bounds__(256, 2) void k(const float* src, float* out, int it
     __syncthreads();
     out[blockIdx.x * 256 + threadIdx.x] = lds[threadIdx.x];
 }
-template <int MODE>
+template <int MODE, int PIECE = 0>
 float run(const float* src, float* out, long rows) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL(k<MODE>, dim3(512), dim3(256), 0, 0, src, out, 2000, rows);
+    hipLaunchKernelGGL((k<MODE, PIECE>), dim3(512), dim3(256), 0, 0, src, out, 2000, rows);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL(k<MODE>, dim3(512), dim3(256), 0, 0, src, out, 2000, rows);
+    hipLaunchKernelGGL((k<MODE, PIECE>), dim3(512), dim3(256), 0, 0, src, out, 2000, rows);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     return ms;
@@ -49,6 +50,8 @@ int main() {
         printf("  DMA only            : %.3f ms  %.2f TB/s  (%.0f cycles per 7-DMA batch at 2.4 GHz)\n", t0, bytes / t0 / 1e9, t0 * 1e-3 * 2.4e9 / 2000);
         printf("  + lgkmcnt(0) / batch: %.3f ms  %.2f TB/s  (%.0f cycles)\n", t1, bytes / t1 / 1e9, t1 * 1e-3 * 2.4e9 / 2000);
         printf("  + vmcnt(0) / batch  : %.3f ms  %.2f TB/s  (%.0f cycles)\n", t2, bytes / t2 / 1e9, t2 * 1e-3 * 2.4e9 / 2000);
+        float t3 = run<0, 1>(src, out, r);
+        printf("  DMA only, 8 rows x 128 B per instruction: %.3f ms  %.2f TB/s  (%.0f cycles)\n", t3, bytes / t3 / 1e9, t3 * 1e-3 * 2.4e9 / 2000);
     }
     return 0;
 }
