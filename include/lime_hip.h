@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LIME_ABI_VERSION 1
+#define LIME_ABI_VERSION 2
 
 typedef enum {
     LIME_OK = 0,
