@@ -10,6 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_vo
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblime_hip.so')
 
+ABI_VERSION = 2          # LIME_ABI_VERSION of include/lime_hip.h this binding was written against
 LIME_ACT = {None: 0, 'none': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3}
 
 
@@ -124,8 +125,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     got = lib.lime_abi_version()
-    if got != 1:
-        raise LimeHipError('liblime_hip.so has ABI version %d, this binding expects 1' % got)
+    if got != ABI_VERSION:
+        raise LimeHipError('liblime_hip.so has ABI version %d, this binding expects %d' % (got, ABI_VERSION))
     _lib = lib
     return lib
 

@@ -33,7 +33,9 @@ def test_header_and_binding_agree(lib):
 
 
 def test_abi_version(lib):
-    assert lib.lime_abi_version() == 1
+    header = open(os.path.join(ROOT, 'include', 'lime_hip.h')).read()
+    declared = int(re.search(r'#define\s+LIME_ABI_VERSION\s+(\d+)', header).group(1))
+    assert lib.lime_abi_version() == _lib.ABI_VERSION == declared
 
 
 def _c_layout(tmp_path):
