@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LIME_ABI_VERSION 2
+#define LIME_ABI_VERSION 3
 
 typedef enum {
     LIME_OK = 0,
@@ -86,6 +86,7 @@ typedef struct {
     int32_t act;
     int32_t res_mod;      /* > 0 (res_ids == NULL): residual row = (r / res_div) % res_mod -- a periodic table */
     int32_t pool32;       /* 1: (LayerNorm epilogue) c is [M / 32, N]: row r = mean of result rows 32 r .. 32 r + 31 */
+    float* ln_rstd;       /* optional [M]: 1 / sqrt(var + eps) of every row's LayerNorm, kept for lime_layernorm_bwd_f32 */
 } lime_linear_args;
 
 int lime_linear_f32(const lime_linear_args* args, void* stream);
@@ -300,6 +301,71 @@ typedef struct {
     int32_t row_bytes;  int32_t reserved;
 } lime_gather_desc;
 int lime_gather_rows_multi(const int32_t* idx, int64_t n_rows, const lime_gather_desc* descs, int32_t n, void* stream);
+
+/* =====================================================================================================
+ * Training step: the backward of the token encoder layers and the optimizer of
+ * trainer.py:33,71-73,131-148.  Gradients of matrix products reuse lime_linear_f32 (dX = dY . W with the transposed
+ * weight as its W operand); the entry points below are the pieces lime_linear_f32 cannot express.  Dense reductions
+ * over the rows go through caller-provided workspaces and are fixed-order; lime_embed_bwd_f32 alone uses float atomics
+ * (a word row receives contributions from many tokens), so the word-table gradient is reproducible only up to the
+ * order of its fp32 additions.
+ * ===================================================================================================== */
+
+/* dW[n, k] (+)= sum_m dy[m, n] * x[m, k]: the weight gradient of y = x W^T (nn.Linear backward; loss.backward() at
+ * trainer.py:145).  dy [M, N], x [M, K], dw [N, K]; exact-fp32 MFMA, M split over workgroups, partial tiles in
+ * `workspace` (lime_linear_wgrad_workspace(M, N, K) floats), summed in split order.  accumulate != 0: dw += ... */
+int64_t lime_linear_wgrad_workspace(int32_t M, int32_t N, int32_t K);
+int lime_linear_wgrad_f32(const float* dy, int64_t ldy, const float* x, int64_t ldx, float* dw, int64_t lddw, int32_t M,
+                          int32_t N, int32_t K, int32_t accumulate, float* workspace, int64_t workspace_floats, void* stream);
+
+/* out[n] (+)= sum_m x[m, n]: the bias gradient.  workspace: lime_colsum_workspace(M, N) floats. */
+int64_t lime_colsum_workspace(int32_t M, int32_t N);
+int lime_colsum_f32(const float* x, int64_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate, float* workspace,
+                    int64_t workspace_floats, void* stream);
+
+/* Backward of y = LayerNorm(z) (norm1 / norm2 of the encoder layers, newsEncoders.py:244-247) from what the forward keeps:
+ * y itself and rstd (lime_linear_args.ln_rstd); xhat is recovered as (y - beta) / gamma (gamma must be non-zero).
+ *   dY(r, :) = dy[(r / dy_div), :] * dy_scale      (dy_div = S, dy_scale = 1 / S: the mean pooling of :317,:321 folded in)
+ *   dz[r, :] = rstd[r] * (g - mean(g) - xhat * mean(g * xhat)),  g = dY * gamma
+ *   dgamma (+)= sum_r dY * xhat;  dbeta (+)= sum_r dY;  dzsum (+)= sum_r dz (the bias gradient of the linear layer whose
+ *   output fed the residual sum); each of the three may be NULL.  E <= 512.
+ * workspace: lime_layernorm_bwd_workspace(M, E) floats. */
+int64_t lime_layernorm_bwd_workspace(int32_t M, int32_t E);
+int lime_layernorm_bwd_f32(const float* dy, int64_t lddy, int32_t dy_div, float dy_scale, const float* y, int64_t ldy,
+                           const float* gamma, const float* beta, const float* rstd, float* dz, int64_t lddz, int32_t M,
+                           int32_t E, float* dgamma, float* dbeta, float* dzsum, int32_t accumulate, float* workspace,
+                           int64_t workspace_floats, void* stream);
+
+/* dh[r, c] = 0 where h[r, c] <= 0 (ReLU backward on the saved activation of linear1), in place */
+int lime_relu_bwd_f32(float* dh, int64_t lddh, const float* h, int64_t ldh, int64_t rows, int32_t cols, void* stream);
+
+/* Backward of lime_token_attention_f32 without a key mask (the encoder layers): given q / k / v as the forward read them
+ * and dout [tokens, n_head * head_dim] (packed), writes dq / dk / dv in the layout of q / k / v (row stride ld_dqkv, head
+ * h at column h * head_stride; columns head_dim .. head_stride - 1 come out as zeros).  The probabilities are recomputed.
+ * S <= 128, head_dim <= head_stride <= 32. */
+int lime_token_attention_bwd_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* dout, int64_t ldo,
+                                 float* dq, float* dk, float* dv, int64_t ld_dqkv, int32_t n_seq, int32_t S, int32_t n_head,
+                                 int32_t head_dim, int32_t head_stride, float scale, void* stream);
+
+/* dtable[ids[r], :] += dx[r, :] (nn.Embedding backward, newsEncoders.py:311-312).  dtable must be initialised by the
+ * caller (zeros, or a gradient to add to).  Rows with ids[r] == hot_id (the padding word, pass -1 for none) are summed
+ * per wave before they touch memory.  dim <= 512. */
+int lime_embed_bwd_f32(const int32_t* ids, const float* dx, int64_t lddx, float* dtable, int64_t ld_table, int64_t rows,
+                       int32_t dim, int32_t hot_id, void* stream);
+
+/* out2[0] = ||g||_2 over the flat gradient buffer, out2[1] = min(1, max_norm / (out2[0] + 1e-6))  -- the coefficient of
+ * torch.nn.utils.clip_grad_norm_ (trainer.py:146-147); max_norm <= 0: out2[1] = 1.  workspace >= 1024 floats. */
+int lime_grad_clip_coef_f32(const float* g, int64_t n, float max_norm, float* out2, float* workspace, int64_t workspace_floats,
+                            void* stream);
+
+/* One torch.optim.Adam step (trainer.py:33,148; amsgrad off) over flat buffers, the gradient scaled by *grad_scale (device
+ * scalar, e.g. out2 + 1 above; NULL = 1): step is the 1-based step count used for the bias corrections. */
+int lime_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int32_t step, const float* grad_scale, void* stream);
+
+/* loss[0] = mean_b(-log_softmax(logits[b, :])[0]) (trainer.py:71-73); dlogits (optional) = its gradient [B, K] */
+int lime_nll_softmax_f32(const float* logits, int64_t ld, int32_t B, int32_t K, float* loss, float* dlogits, int64_t ldd,
+                         void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_vo
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblime_hip.so')
 
-ABI_VERSION = 2          # LIME_ABI_VERSION of include/lime_hip.h this binding was written against
+ABI_VERSION = 3          # LIME_ABI_VERSION of include/lime_hip.h this binding was written against
 LIME_ACT = {None: 0, 'none': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3}
 
 
@@ -28,6 +28,7 @@ class LinearArgs(Structure):
         ('M', c_int32), ('N', c_int32), ('K', c_int32),
         ('act', c_int32),
         ('res_mod', c_int32), ('pool32', c_int32),
+        ('ln_rstd', c_void_p),
     ]
 
 
@@ -102,6 +103,24 @@ SIGNATURES = {
                                             c_int32, c_float, c_int32, c_void_p]),
     'lime_to_bf16': (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64, c_int64, c_int32, c_void_p]),
     'lime_mean_pool_bf16': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
+    # training step
+    'lime_linear_wgrad_workspace': (c_int64, [c_int32, c_int32, c_int32]),
+    'lime_linear_wgrad_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
+                                        c_void_p, c_int64, c_void_p]),
+    'lime_colsum_workspace': (c_int64, [c_int32, c_int32]),
+    'lime_colsum_f32': (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
+    'lime_layernorm_bwd_workspace': (c_int64, [c_int32, c_int32]),
+    'lime_layernorm_bwd_f32': (c_int32, [c_void_p, c_int64, c_int32, c_float, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+                                         c_int64, c_void_p]),
+    'lime_relu_bwd_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p]),
+    'lime_token_attention_bwd_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                               c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    'lime_embed_bwd_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p]),
+    'lime_grad_clip_coef_f32': (c_int32, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
+    'lime_adam_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
+                                c_int32, c_void_p, c_void_p]),
+    'lime_nll_softmax_f32': (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,791 @@
+// Backward kernels of the training step (reference trainer.py:131-148 drives
+// loss.backward() through the encoder layers of newsEncoders.py:244-247,311-321).
+//
+//   wgrad_kernel           dW[n, k] = sum_m dY[m, n] X[m, k]      split over M, exact-fp32 MFMA, partials + fixed-order reduce
+//   colsum_kernel          db[n] = sum_m dY[m, n]
+//   layernorm_bwd_kernel   dZ of y = LayerNorm(z) from (dY, y, rstd) + the column sums for d gamma / d beta / bias
+//   relu_bwd_kernel        dH *= (h > 0)
+//   token_attn_bwd_kernel  dQ / dK / dV of softmax(scale Q K^T) V per (sequence, head), probabilities recomputed
+//   embed_bwd_kernel       dTable[ids[r]] += dX[r]                (the one place with float atomics: word rows repeat)
+//   sumsq / clip / adam    clip_grad_norm_ + Adam over flat buffers, nll_softmax: the loss of trainer.py:71-73
+//
+// All dense reductions are fixed-order (partials in a caller workspace, then one summing pass).
+#include "common.h"
+
+namespace {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    // v_mfma_f32_16x16x4_f32: lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]; c[r] = C[4 (l >> 4) + r][l & 15]
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float block_sum_4(float v, float* red) {        // 256 threads, fixed order
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// reduce_partials: out[r, c] (+)= sum_s ws[s * split_stride + r * ldw + c].  A workgroup owns 64 consecutive outputs; its
+// four waves take the splits s = wave, wave + 4, ... and the four sums are added in a fixed order.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ ws, long split_stride, int splits,
+                                                               long ldw, float* __restrict__ out, long ldo, int rows, int cols,
+                                                               int accumulate) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + lane;
+    const bool ok = e < (long)rows * cols;
+    const int r = ok ? (int)(e / cols) : 0, c = ok ? (int)(e - (long)r * cols) : 0;
+    float s = 0.f;
+    if (ok) {
+        const float* p = ws + (long)r * ldw + c;
+        for (int i = g; i < splits; i += 4) s += p[(long)i * split_stride];
+    }
+    red[g][lane] = s;
+    __syncthreads();
+    if (g == 0 && ok) {
+        const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        float* o = out + (long)r * ldo + c;
+        *o = accumulate ? *o + t : t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad: workgroup = one 128 x TK tile of dW over one slice of the M rows.  Four waves, each a 64 x TK/2 quadrant
+// (4 x NKT accumulator tiles of 16 x 16).  32-row chunks of dY and X go global -> registers -> LDS (two stages).
+// ---------------------------------------------------------------------------------------------------
+constexpr int WG_TN = 128;
+constexpr int WG_MC = 32;
+
+template <int NKT>       // 16-column accumulator tiles per wave along K: TK = 32 * NKT
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dy, long ldy, const float* __restrict__ x, long ldx,
+                                                     float* __restrict__ ws, int M, int N, int K, int n_tiles, int k_tiles,
+                                                     int rows_per_split) {
+    constexpr int TK = 32 * NKT;
+    constexpr int LDA = WG_TN + 16;          // pitch % 32 == 16: the two row groups of a half-wave hit disjoint banks
+    constexpr int LDB = TK + 16;
+    constexpr int A4 = WG_MC * WG_TN / 4 / 256;            // float4 per thread per chunk (dY tile): 4
+    constexpr int B4 = (WG_MC * TK / 4 + 255) / 256;       // (X tile): 4 or 5
+    __shared__ float As[2][WG_MC * LDA];
+    __shared__ float Bs[2][WG_MC * LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, kg = lane >> 4;
+    const int ntile = n_tiles * k_tiles;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / ntile, tile = logical - split * ntile;
+    const int n0 = (tile / k_tiles) * WG_TN, k0 = (tile % k_tiles) * TK;
+    const long m_begin = (long)split * rows_per_split;
+    const long m_end = min((long)M, m_begin + rows_per_split);
+    const int wn = (wave >> 1) * 64, wk = (wave & 1) * (TK / 2);
+
+    f32x4 acc[4][NKT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4v ra[A4], rb[B4];
+    const bool vec_ok = ((ldy | ldx) & 3) == 0 && ((((uintptr_t)dy) | ((uintptr_t)x)) & 15) == 0;
+    auto load_chunk = [&](long m0) {
+#pragma unroll
+        for (int j = 0; j < A4; ++j) {
+            const int f = tid + 256 * j, r = f / (WG_TN / 4), c = (f % (WG_TN / 4)) * 4;
+            const long m = m0 + r;
+            f32x4v v = {0.f, 0.f, 0.f, 0.f};
+            if (m < m_end) {
+                const float* p = dy + m * ldy + n0 + c;
+                if (vec_ok && n0 + c + 3 < N) v = *reinterpret_cast<const f32x4v*>(p);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (n0 + c + e < N) v[e] = p[e];
+                }
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < B4; ++j) {
+            const int f = tid + 256 * j, r = f / (TK / 4), c = (f % (TK / 4)) * 4;
+            const long m = m0 + r;
+            f32x4v v = {0.f, 0.f, 0.f, 0.f};
+            if (f < WG_MC * TK / 4 && m < m_end) {
+                const float* p = x + m * ldx + k0 + c;
+                if (vec_ok && k0 + c + 3 < K) v = *reinterpret_cast<const f32x4v*>(p);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (k0 + c + e < K) v[e] = p[e];
+                }
+            }
+            rb[j] = v;
+        }
+    };
+    auto store_chunk = [&](int stage) {
+#pragma unroll
+        for (int j = 0; j < A4; ++j) {
+            const int f = tid + 256 * j, r = f / (WG_TN / 4), c = (f % (WG_TN / 4)) * 4;
+            *reinterpret_cast<f32x4v*>(&As[stage][r * LDA + c]) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < B4; ++j) {
+            const int f = tid + 256 * j, r = f / (TK / 4), c = (f % (TK / 4)) * 4;
+            if (f < WG_MC * TK / 4) *reinterpret_cast<f32x4v*>(&Bs[stage][r * LDB + c]) = rb[j];
+        }
+    };
+
+    if (m_begin < m_end) {
+        load_chunk(m_begin);
+        store_chunk(0);
+        __syncthreads();
+        int stage = 0;
+        for (long m0 = m_begin; m0 < m_end; m0 += WG_MC) {
+            const bool more = m0 + WG_MC < m_end;
+            if (more) load_chunk(m0 + WG_MC);
+            const float* as = &As[stage][kg * LDA + wn + fi];
+            const float* bs = &Bs[stage][kg * LDB + wk + fi];
+#pragma unroll
+            for (int s = 0; s < WG_MC / 4; ++s) {
+                float a[4], b[NKT];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = as[4 * s * LDA + 16 * i];
+#pragma unroll
+                for (int j = 0; j < NKT; ++j) b[j] = bs[4 * s * LDB + 16 * j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NKT; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+            }
+            if (more) store_chunk(stage ^ 1);
+            __syncthreads();
+            stage ^= 1;
+        }
+    }
+    // partial tile -> ws[split][n][k] over the padded [n_tiles * 128, k_tiles * TK] grid
+    const long ldw = (long)k_tiles * TK;
+    float* o = ws + (long)split * ((long)n_tiles * WG_TN) * ldw;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NKT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                o[(long)(n0 + wn + 16 * i + 4 * kg + r) * ldw + k0 + wk + 16 * j + fi] = acc[i][j][r];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// colsum: partial[blk][c] = sum of x[r, c] over the block's rows
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ldx, int M, int N, int rows_per_block,
+                                                      float* __restrict__ ws) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min((long)M, r0 + rows_per_block);
+    float s = 0.f;
+    if (c < N)
+        for (long r = r0 + g; r < r1; r += 4) s += x[r * ldx + c];
+    red[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && c < N) ws[(long)blockIdx.y * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm backward.  y = gamma * xhat + beta with xhat = (z - mean) * rstd; given dY, y and rstd:
+//   g = dY * gamma;  dZ = rstd * (g - mean(g) - xhat * mean(g * xhat)),   xhat = (y - beta) / gamma
+// dY row of output row r is dy[(r / dy_div)] * dy_scale (the mean-pool backward of newsEncoders.py:317,321 broadcasts one
+// pooled-gradient row over the S tokens with 1 / S).  One wave per row, CPL columns per lane; partial column sums
+// (d gamma, d beta, sum dZ) per workgroup in ws[blk][3][E].
+// ---------------------------------------------------------------------------------------------------
+template <int CPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, long lddy, int dy_div, float dy_scale,
+                                                             const float* __restrict__ y, long ldy, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ rstd,
+                                                             float* __restrict__ dz, long lddz, int M, int E, int rows_per_block,
+                                                             float* __restrict__ ws) {
+    __shared__ float red[4][3][64 * CPL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float ga[CPL], be[CPL], inv_ga[CPL], sg[CPL], sb[CPL], sz[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        const int c = lane + 64 * j;
+        ga[j] = c < E ? gamma[c] : 0.f;
+        be[j] = c < E ? beta[c] : 0.f;
+        inv_ga[j] = c < E ? 1.0f / ga[j] : 0.f;
+        sg[j] = sb[j] = sz[j] = 0.f;
+    }
+    const float inv_e = 1.0f / (float)E;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min((long)M, r0 + rows_per_block);
+    for (long r = r0 + wave; r < r1; r += 4) {
+        const float* pdy = dy + (r / dy_div) * lddy;
+        const float* py = y + r * ldy;
+        float d[CPL], xh[CPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int c = lane + 64 * j;
+            d[j] = c < E ? pdy[c] * dy_scale : 0.f;
+            xh[j] = c < E ? (py[c] - be[j]) * inv_ga[j] : 0.f;
+            const float g = d[j] * ga[j];
+            s1 += g;
+            s2 += g * xh[j];
+        }
+        s1 = wave_sum(s1) * inv_e;
+        s2 = wave_sum(s2) * inv_e;
+        const float rs = rstd[r];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int c = lane + 64 * j;
+            const float v = rs * (d[j] * ga[j] - s1 - xh[j] * s2);
+            if (c < E) dz[r * lddz + c] = v;
+            sg[j] += d[j] * xh[j];
+            sb[j] += d[j];
+            sz[j] += c < E ? v : 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        red[wave][0][lane + 64 * j] = sg[j];
+        red[wave][1][lane + 64 * j] = sb[j];
+        red[wave][2][lane + 64 * j] = sz[j];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 3 * E; e += 256) {
+        const int k = e / E, c = e - k * E;
+        ws[((long)blockIdx.x * 3 + k) * E + c] = red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c];
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ dh, long lddh, const float* __restrict__ h, long ldh,
+                                                        long rows, int cols) {
+    const long total = rows * cols;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / cols;
+        const int c = (int)(e - r * cols);
+        if (!(h[r * ldh + c] > 0.f)) dh[r * lddh + c] = 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// token attention backward (unmasked encoder-layer attention, newsEncoders.py:316,320).
+// A problem = one (sequence, head); a wave owns 32 query rows (and, for dK / dV, the 32 key rows of the same numbers);
+// a problem takes SP / 32 waves, a workgroup 128 / SP problems.  Everything goes through v_mfma_f32_16x16x4_f32:
+//   S = scale Q K^T -> P = softmax(S) (registers) -> LDS;   dP = dO V^T (registers);  delta = rowsum(P dP)
+//   dV = P^T dO;   dS = scale P (dP - delta) -> LDS over P;   dQ = dS K;   dK = dS^T Q
+// ---------------------------------------------------------------------------------------------------
+constexpr int AB_LD = 34;        // Q / K / V / dO rows: 32 columns + 2 (row-indexed fragment reads are conflict-free)
+
+template <int SP>
+__global__ __launch_bounds__(256) void token_attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ v, long ld, const float* __restrict__ dout,
+                                                              long ldo, float* __restrict__ dq, float* __restrict__ dk,
+                                                              float* __restrict__ dv, long ldd, int n_seq, int S, int n_head,
+                                                              int head_dim, int head_stride, float scale) {
+    constexpr int NT = SP / 16;                 // 16-column score tiles per row
+    constexpr int WPP = SP / 32;                // waves per problem
+    constexpr int PPW = 4 / WPP;                // problems per workgroup
+    constexpr int LDP = SP + 2;
+    constexpr int PROB_FLOATS = 4 * SP * AB_LD + SP * LDP;
+    extern __shared__ float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, kg = lane >> 4;
+    const int pw = wave / WPP;                  // problem slot of this wave
+    const int wr = wave % WPP;                  // which 32-row block of the problem
+    const long prob = (long)blockIdx.x * PPW + pw;
+    const long n_prob = (long)n_seq * n_head;
+    const bool live = prob < n_prob;
+    const int seq = live ? (int)(prob / n_head) : 0, head = live ? (int)(prob % n_head) : 0;
+    float* Qs = smem + pw * PROB_FLOATS;
+    float* Ks = Qs + SP * AB_LD;
+    float* Vs = Ks + SP * AB_LD;
+    float* Os = Vs + SP * AB_LD;                // dO
+    float* Ps = Os + SP * AB_LD;                // P, then dS
+    const int R0 = 32 * wr;
+
+    // ---- stage Q, K, V, dO (zero beyond S rows / head_dim columns) ----------------------------------------------
+    {
+        const int lt = tid - pw * (64 * WPP);                           // thread index inside the problem
+        const long row_base = (long)seq * S;
+        for (int e = lt; e < SP * 32; e += 64 * WPP) {
+            const int r = e >> 5, c = e & 31;
+            const bool ok = live && r < S && c < head_dim;
+            const long g = (row_base + r) * ld + (long)head * head_stride + c;
+            Qs[r * AB_LD + c] = ok ? q[g] : 0.f;
+            Ks[r * AB_LD + c] = ok ? k[g] : 0.f;
+            Vs[r * AB_LD + c] = ok ? v[g] : 0.f;
+            Os[r * AB_LD + c] = ok ? dout[(row_base + r) * ldo + (long)head * head_dim + c] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    // ---- S tiles and dP tiles of this wave's 32 query rows ------------------------------------------------------
+    f32x4 p[2][NT], dp[2][NT];
+    {
+        float qa[2][8], oa[2][8];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                qa[rt][s] = Qs[(R0 + 16 * rt + fi) * AB_LD + 4 * s + kg];
+                oa[rt][s] = Os[(R0 + 16 * rt + fi) * AB_LD + 4 * s + kg];
+            }
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const float kb = Ks[(16 * ct + fi) * AB_LD + 4 * s + kg];
+                const float vb = Vs[(16 * ct + fi) * AB_LD + 4 * s + kg];
+                s0 = mfma16(qa[0][s], kb, s0);
+                s1 = mfma16(qa[1][s], kb, s1);
+                d0 = mfma16(oa[0][s], vb, d0);
+                d1 = mfma16(oa[1][s], vb, d1);
+            }
+            p[0][ct] = s0; p[1][ct] = s1; dp[0][ct] = d0; dp[1][ct] = d1;
+        }
+    }
+    // softmax over the row (columns: tiles ct x the 16 lanes with the same kg), then delta and dS
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                const bool col_ok = 16 * ct + fi < S;
+                const float sv = col_ok ? p[rt][ct][r] * scale : -INFINITY;
+                p[rt][ct][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
+            mx = fmaxf(mx, __shfl_xor(mx, 4)); mx = fmaxf(mx, __shfl_xor(mx, 8));
+            float sum = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                const float e = expf(p[rt][ct][r] - mx);
+                p[rt][ct][r] = e;
+                sum += e;
+            }
+            sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
+            const float inv = 1.0f / sum;
+            float dl = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                p[rt][ct][r] *= inv;
+                dl += p[rt][ct][r] * dp[rt][ct][r];
+            }
+            dl += __shfl_xor(dl, 1); dl += __shfl_xor(dl, 2); dl += __shfl_xor(dl, 4); dl += __shfl_xor(dl, 8);
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) dp[rt][ct][r] = scale * p[rt][ct][r] * (dp[rt][ct][r] - dl);      // dS
+        }
+    // P -> LDS
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ps[(R0 + 16 * rt + 4 * kg + r) * LDP + 16 * ct + fi] = p[rt][ct][r];
+    __syncthreads();
+
+    const long out_row0 = (long)seq * S + R0;
+    auto store_tile = [&](float* dst, int jt, int dt, const f32x4& a) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * jt + 4 * kg + r, col = 16 * dt + fi;
+            if (live && R0 + row < S && col < head_stride)
+                dst[(out_row0 + row) * ldd + (long)head * head_stride + col] = a[r];
+        }
+    };
+    // ---- dV[j, d] = sum_i P[i, j] dO[i, d] for the wave's key rows j ---------------------------------------------
+    {
+        f32x4 a[2][2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) a[jt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < SP / 4; ++s) {
+            const int i = 4 * s + kg;
+            const float a0 = Ps[i * LDP + R0 + fi], a1 = Ps[i * LDP + R0 + 16 + fi];
+            const float b0 = Os[i * AB_LD + fi], b1 = Os[i * AB_LD + 16 + fi];
+            a[0][0] = mfma16(a0, b0, a[0][0]); a[0][1] = mfma16(a0, b1, a[0][1]);
+            a[1][0] = mfma16(a1, b0, a[1][0]); a[1][1] = mfma16(a1, b1, a[1][1]);
+        }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) store_tile(dv, jt, dt, a[jt][dt]);
+    }
+    __syncthreads();
+    // dS over P
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ps[(R0 + 16 * rt + 4 * kg + r) * LDP + 16 * ct + fi] = dp[rt][ct][r];
+    __syncthreads();
+    // ---- dQ[i, d] = sum_j dS[i, j] K[j, d];  dK[j, d] = sum_i dS[i, j] Q[i, d] -----------------------------------
+    {
+        f32x4 aq[2][2], ak[2][2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) aq[jt][dt] = ak[jt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < SP / 4; ++s) {
+            const int j = 4 * s + kg;
+            const float q0 = Ps[(R0 + fi) * LDP + j], q1 = Ps[(R0 + 16 + fi) * LDP + j];     // dS[i, j]: rows of this wave
+            const float kb0 = Ks[j * AB_LD + fi], kb1 = Ks[j * AB_LD + 16 + fi];
+            aq[0][0] = mfma16(q0, kb0, aq[0][0]); aq[0][1] = mfma16(q0, kb1, aq[0][1]);
+            aq[1][0] = mfma16(q1, kb0, aq[1][0]); aq[1][1] = mfma16(q1, kb1, aq[1][1]);
+            const float t0 = Ps[j * LDP + R0 + fi], t1 = Ps[j * LDP + R0 + 16 + fi];         // dS[i = j-index here, key row]
+            const float qb0 = Qs[j * AB_LD + fi], qb1 = Qs[j * AB_LD + 16 + fi];
+            ak[0][0] = mfma16(t0, qb0, ak[0][0]); ak[0][1] = mfma16(t0, qb1, ak[0][1]);
+            ak[1][0] = mfma16(t1, qb0, ak[1][0]); ak[1][1] = mfma16(t1, qb1, ak[1][1]);
+        }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                store_tile(dq, jt, dt, aq[jt][dt]);
+                store_tile(dk, jt, dt, ak[jt][dt]);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// word-table gradient: dTable[ids[r], :] += dX[r, :].  A workgroup walks 512 consecutive rows, one wave per row; rows
+// whose id is `hot_id` (the padding word, a large share of all tokens) are summed in registers and added once per wave.
+// ---------------------------------------------------------------------------------------------------
+template <int CPL>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ ids, const float* __restrict__ dx, long lddx,
+                                                         float* __restrict__ dtable, long ldt, long rows, int dim, int hot_id,
+                                                         int rows_per_block) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float hot[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) hot[j] = 0.f;
+    bool any_hot = false;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(rows, r0 + rows_per_block);
+    for (long r = r0 + wave; r < r1; r += 4) {
+        const int id = ids[r];
+        const float* p = dx + r * lddx;
+        if (id == hot_id) {
+            any_hot = true;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const int c = lane + 64 * j;
+                if (c < dim) hot[j] += p[c];
+            }
+        } else {
+            float* t = dtable + (long)id * ldt;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const int c = lane + 64 * j;
+                if (c < dim) unsafeAtomicAdd(t + c, p[c]);
+            }
+        }
+    }
+    if (any_hot) {
+        float* t = dtable + (long)hot_id * ldt;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int c = lane + 64 * j;
+            if (c < dim) unsafeAtomicAdd(t + c, hot[j]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// optimizer: sum of squares -> clip coefficient -> Adam   (trainer.py:33, 146-148)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) s += g[e] * g[e];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// out[0] = total norm, out[1] = min(1, max_norm / (norm + 1e-6)) (torch.nn.utils.clip_grad_norm_); max_norm <= 0: 1
+__global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict__ partial, int n, float max_norm,
+                                                         float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) s += partial[e];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+        out[0] = norm;
+        out[1] = max_norm > 0.f ? fminf(1.0f, max_norm / (norm + 1e-6f)) : 1.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n, float lr, float beta1, float beta2, float eps,
+                                                    float weight_decay, float bias1, float bias2_sqrt,
+                                                    const float* __restrict__ grad_scale) {
+    const float gs = grad_scale ? *grad_scale : 1.0f;
+    const float step = lr / bias1;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        float gr = g[e] * gs;
+        const float pe = p[e];
+        if (weight_decay != 0.f) gr += weight_decay * pe;
+        const float me = beta1 * m[e] + (1.0f - beta1) * gr;
+        const float ve = beta2 * v[e] + (1.0f - beta2) * gr * gr;
+        m[e] = me;
+        v[e] = ve;
+        p[e] = pe - step * (me / (sqrtf(ve) / bias2_sqrt + eps));
+    }
+}
+
+// loss = mean_b (-log_softmax(logits[b])[0]);  dlogits = (softmax - onehot_0) / B      (trainer.py:71-73)
+__global__ __launch_bounds__(256) void nll_softmax_kernel(const float* __restrict__ logits, long ld, int B, int K,
+                                                           float* __restrict__ loss, float* __restrict__ dlogits, long ldd) {
+    __shared__ float red[4];
+    float part = 0.f;
+    const float inv_b = 1.0f / (float)B;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float* x = logits + (long)b * ld;
+        float mx = x[0];
+        for (int j = 1; j < K; ++j) mx = fmaxf(mx, x[j]);
+        float s = 0.f;
+        for (int j = 0; j < K; ++j) s += expf(x[j] - mx);
+        const float lse = mx + logf(s);
+        part += lse - x[0];
+        if (dlogits)
+            for (int j = 0; j < K; ++j) dlogits[(long)b * ldd + j] = (expf(x[j] - lse) - (j == 0 ? 1.0f : 0.f)) * inv_b;
+    }
+    const float tot = block_sum_4(part, red);
+    if (threadIdx.x == 0) *loss = tot * inv_b;
+}
+
+}  // namespace
+
+// ===================================================================================================
+// C ABI
+// ===================================================================================================
+namespace {
+
+struct WgradPlan { int nkt, tk, n_tiles, k_tiles, splits, rows_per_split; long np, kp; };
+
+WgradPlan wgrad_plan(int M, int N, int K) {
+    WgradPlan w;
+    const long k128 = ((long)K + 127) / 128 * 128, k160 = ((long)K + 159) / 160 * 160;
+    w.nkt = k160 < k128 ? 5 : 4;
+    w.tk = 32 * w.nkt;
+    w.n_tiles = (N + WG_TN - 1) / WG_TN;
+    w.k_tiles = (K + w.tk - 1) / w.tk;
+    w.np = (long)w.n_tiles * WG_TN;
+    w.kp = (long)w.k_tiles * w.tk;
+    const int ntile = w.n_tiles * w.k_tiles;
+    int splits = (512 + ntile - 1) / ntile;                       // about two workgroups per CU
+    const int max_splits = (M + 255) / 256;                       // at least 8 chunks of 32 rows per workgroup
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int rps = (M + splits - 1) / splits;
+    rps = (rps + WG_MC - 1) / WG_MC * WG_MC;
+    w.rows_per_split = rps;
+    w.splits = (M + rps - 1) / rps;
+    if (w.splits < 1) w.splits = 1;
+    return w;
+}
+
+int launch_reduce(const float* ws, long split_stride, int splits, long ldw, float* out, long ldo, int rows, int cols,
+                  int accumulate, hipStream_t s) {
+    const long total = (long)rows * cols;
+    const int grid = (int)((total + 63) / 64);
+    reduce_partials_kernel<<<grid, 256, 0, s>>>(ws, split_stride, splits, ldw, out, ldo, rows, cols, accumulate);
+    return lime_check_launch("reduce_partials");
+}
+
+int colsum_blocks(int M) {
+    int b = (M + 255) / 256;
+    return b < 1 ? 1 : (b > 256 ? 256 : b);
+}
+
+int ln_rows_per_block(int M) { return M >= 65536 ? 256 : 64; }
+
+}  // namespace
+
+extern "C" int64_t lime_linear_wgrad_workspace(int32_t M, int32_t N, int32_t K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const WgradPlan w = wgrad_plan(M, N, K);
+    return (int64_t)w.splits * w.np * w.kp;
+}
+
+extern "C" int lime_linear_wgrad_f32(const float* dy, int64_t ldy, const float* x, int64_t ldx, float* dw, int64_t lddw,
+                                     int32_t M, int32_t N, int32_t K, int32_t accumulate, float* workspace,
+                                     int64_t workspace_floats, void* stream) {
+    LIME_REQUIRE(dy && x && dw && workspace, LIME_ERR_BAD_ARG, "lime_linear_wgrad_f32: null pointer");
+    LIME_REQUIRE(M > 0 && N > 0 && K > 0, LIME_ERR_BAD_ARG, "lime_linear_wgrad_f32: non-positive dimension");
+    LIME_REQUIRE(ldy >= N && ldx >= K && lddw >= K, LIME_ERR_BAD_ARG, "lime_linear_wgrad_f32: leading dimension smaller than the row");
+    const WgradPlan w = wgrad_plan(M, N, K);
+    LIME_REQUIRE(workspace_floats >= (int64_t)w.splits * w.np * w.kp, LIME_ERR_BAD_ARG,
+                 "lime_linear_wgrad_f32: workspace holds %ld floats, lime_linear_wgrad_workspace() asks for %ld",
+                 (long)workspace_floats, (long)((int64_t)w.splits * w.np * w.kp));
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = w.n_tiles * w.k_tiles * w.splits;
+    if (w.nkt == 5)
+        wgrad_kernel<5><<<grid, 256, 0, s>>>(dy, ldy, x, ldx, workspace, M, N, K, w.n_tiles, w.k_tiles, w.rows_per_split);
+    else
+        wgrad_kernel<4><<<grid, 256, 0, s>>>(dy, ldy, x, ldx, workspace, M, N, K, w.n_tiles, w.k_tiles, w.rows_per_split);
+    const int st = lime_check_launch("wgrad_kernel");
+    if (st != LIME_OK) return st;
+    return launch_reduce(workspace, w.np * w.kp, w.splits, w.kp, dw, lddw, N, K, accumulate, s);
+}
+
+extern "C" int64_t lime_colsum_workspace(int32_t M, int32_t N) {
+    return M > 0 && N > 0 ? (int64_t)colsum_blocks(M) * N : 0;
+}
+
+extern "C" int lime_colsum_f32(const float* x, int64_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate,
+                               float* workspace, int64_t workspace_floats, void* stream) {
+    LIME_REQUIRE(x && out && workspace, LIME_ERR_BAD_ARG, "lime_colsum_f32: null pointer");
+    LIME_REQUIRE(M > 0 && N > 0 && ldx >= N, LIME_ERR_BAD_ARG, "lime_colsum_f32: bad dimensions");
+    const int nblk = colsum_blocks(M);
+    LIME_REQUIRE(workspace_floats >= (int64_t)nblk * N, LIME_ERR_BAD_ARG, "lime_colsum_f32: workspace too small (%ld < %ld)",
+                 (long)workspace_floats, (long)nblk * N);
+    hipStream_t s = (hipStream_t)stream;
+    const int rpb = (M + nblk - 1) / nblk;
+    colsum_kernel<<<dim3((N + 63) / 64, nblk), 256, 0, s>>>(x, ldx, M, N, rpb, workspace);
+    const int st = lime_check_launch("colsum_kernel");
+    if (st != LIME_OK) return st;
+    return launch_reduce(workspace, N, nblk, N, out, N, 1, N, accumulate, s);
+}
+
+extern "C" int64_t lime_layernorm_bwd_workspace(int32_t M, int32_t E) {
+    if (M <= 0 || E <= 0) return 0;
+    const int rpb = ln_rows_per_block(M);
+    return (int64_t)((M + rpb - 1) / rpb) * 3 * E;
+}
+
+extern "C" int lime_layernorm_bwd_f32(const float* dy, int64_t lddy, int32_t dy_div, float dy_scale, const float* y, int64_t ldy,
+                                      const float* gamma, const float* beta, const float* rstd, float* dz, int64_t lddz,
+                                      int32_t M, int32_t E, float* dgamma, float* dbeta, float* dzsum, int32_t accumulate,
+                                      float* workspace, int64_t workspace_floats, void* stream) {
+    LIME_REQUIRE(dy && y && gamma && beta && rstd && dz && workspace, LIME_ERR_BAD_ARG, "lime_layernorm_bwd_f32: null pointer");
+    LIME_REQUIRE(M > 0 && E > 0 && dy_div >= 1, LIME_ERR_BAD_ARG, "lime_layernorm_bwd_f32: bad dimensions");
+    LIME_REQUIRE(E <= 512, LIME_ERR_UNSUPPORTED, "lime_layernorm_bwd_f32: E = %d > 512", E);
+    LIME_REQUIRE(lddy >= E && ldy >= E && lddz >= E, LIME_ERR_BAD_ARG, "lime_layernorm_bwd_f32: leading dimension smaller than E");
+    const int rpb = ln_rows_per_block(M);
+    const int nblk = (M + rpb - 1) / rpb;
+    LIME_REQUIRE(workspace_floats >= (int64_t)nblk * 3 * E, LIME_ERR_BAD_ARG, "lime_layernorm_bwd_f32: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int cpl = (E + 63) / 64;
+#define LN_BWD(C) layernorm_bwd_kernel<C><<<nblk, 256, 0, s>>>(dy, lddy, dy_div, dy_scale, y, ldy, gamma, beta, rstd, dz, lddz, M, E, rpb, workspace)
+    if (cpl <= 2) LN_BWD(2); else if (cpl <= 5) LN_BWD(5); else LN_BWD(8);
+#undef LN_BWD
+    int st = lime_check_launch("layernorm_bwd_kernel");
+    if (st != LIME_OK) return st;
+    float* outs[3] = {dgamma, dbeta, dzsum};
+    for (int k = 0; k < 3; ++k) {
+        if (!outs[k]) continue;
+        st = launch_reduce(workspace + (long)k * E, 3L * E, nblk, E, outs[k], E, 1, E, accumulate, s);
+        if (st != LIME_OK) return st;
+    }
+    return LIME_OK;
+}
+
+extern "C" int lime_relu_bwd_f32(float* dh, int64_t lddh, const float* h, int64_t ldh, int64_t rows, int32_t cols, void* stream) {
+    LIME_REQUIRE(dh && h, LIME_ERR_BAD_ARG, "lime_relu_bwd_f32: null pointer");
+    LIME_REQUIRE(rows >= 0 && cols > 0 && lddh >= cols && ldh >= cols, LIME_ERR_BAD_ARG, "lime_relu_bwd_f32: bad dimensions");
+    if (rows == 0) return LIME_OK;
+    const long total = rows * cols;
+    const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    relu_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(dh, lddh, h, ldh, rows, cols);
+    return lime_check_launch("relu_bwd_kernel");
+}
+
+namespace {
+template <int SP>
+int launch_attn_bwd(const float* q, const float* k, const float* v, long ld, const float* dout, long ldo, float* dq, float* dk,
+                    float* dv, long ldd, int n_seq, int S, int n_head, int head_dim, int head_stride, float scale,
+                    hipStream_t s) {
+    constexpr int PPW = 4 / (SP / 32);
+    constexpr int BYTES = PPW * (4 * SP * AB_LD + SP * (SP + 2)) * 4;
+    static bool configured = false;
+    if (!configured) {
+        const hipError_t e = hipFuncSetAttribute((const void*)token_attn_bwd_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+        LIME_REQUIRE(e == hipSuccess, LIME_ERR_LAUNCH, "lime_token_attention_bwd_f32: cannot reserve %d bytes of LDS: %s", BYTES,
+                     hipGetErrorString(e));
+        configured = true;
+    }
+    const long n_prob = (long)n_seq * n_head;
+    const int grid = (int)((n_prob + PPW - 1) / PPW);
+    token_attn_bwd_kernel<SP><<<grid, 256, BYTES, s>>>(q, k, v, ld, dout, ldo, dq, dk, dv, ldd, n_seq, S, n_head, head_dim,
+                                                      head_stride, scale);
+    return lime_check_launch("token_attn_bwd_kernel");
+}
+}  // namespace
+
+extern "C" int lime_token_attention_bwd_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* dout,
+                                            int64_t ldo, float* dq, float* dk, float* dv, int64_t ld_dqkv, int32_t n_seq,
+                                            int32_t S, int32_t n_head, int32_t head_dim, int32_t head_stride, float scale,
+                                            void* stream) {
+    LIME_REQUIRE(q && k && v && dout && dq && dk && dv, LIME_ERR_BAD_ARG, "lime_token_attention_bwd_f32: null pointer");
+    LIME_REQUIRE(n_seq >= 0 && S > 0 && n_head > 0 && head_dim > 0, LIME_ERR_BAD_ARG, "lime_token_attention_bwd_f32: bad dimensions");
+    LIME_REQUIRE(S <= 128 && head_dim <= 32 && head_stride >= head_dim && head_stride <= 32, LIME_ERR_UNSUPPORTED,
+                 "lime_token_attention_bwd_f32: needs S <= 128 and head_dim <= head_stride <= 32 (S=%d head_dim=%d head_stride=%d)",
+                 S, head_dim, head_stride);
+    LIME_REQUIRE(ld_qkv >= (int64_t)n_head * head_stride && ld_dqkv >= (int64_t)n_head * head_stride && ldo >= (int64_t)n_head * head_dim,
+                 LIME_ERR_BAD_ARG, "lime_token_attention_bwd_f32: leading dimension smaller than the row");
+    if (n_seq == 0) return LIME_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (S <= 32) return launch_attn_bwd<32>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, s);
+    if (S <= 64) return launch_attn_bwd<64>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, s);
+    return launch_attn_bwd<128>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, s);
+}
+
+extern "C" int lime_embed_bwd_f32(const int32_t* ids, const float* dx, int64_t lddx, float* dtable, int64_t ld_table, int64_t rows,
+                                  int32_t dim, int32_t hot_id, void* stream) {
+    LIME_REQUIRE(ids && dx && dtable, LIME_ERR_BAD_ARG, "lime_embed_bwd_f32: null pointer");
+    LIME_REQUIRE(rows >= 0 && dim > 0 && lddx >= dim && ld_table >= dim, LIME_ERR_BAD_ARG, "lime_embed_bwd_f32: bad dimensions");
+    LIME_REQUIRE(dim <= 512, LIME_ERR_UNSUPPORTED, "lime_embed_bwd_f32: dim = %d > 512", dim);
+    if (rows == 0) return LIME_OK;
+    const int rpb = 512;
+    const int grid = (int)((rows + rpb - 1) / rpb);
+    hipStream_t s = (hipStream_t)stream;
+    if (dim <= 320) embed_bwd_kernel<5><<<grid, 256, 0, s>>>(ids, dx, lddx, dtable, ld_table, rows, dim, hot_id, rpb);
+    else embed_bwd_kernel<8><<<grid, 256, 0, s>>>(ids, dx, lddx, dtable, ld_table, rows, dim, hot_id, rpb);
+    return lime_check_launch("embed_bwd_kernel");
+}
+
+extern "C" int lime_grad_clip_coef_f32(const float* g, int64_t n, float max_norm, float* out2, float* workspace,
+                                       int64_t workspace_floats, void* stream) {
+    LIME_REQUIRE(g && out2 && workspace, LIME_ERR_BAD_ARG, "lime_grad_clip_coef_f32: null pointer");
+    LIME_REQUIRE(n > 0 && workspace_floats >= 1024, LIME_ERR_BAD_ARG, "lime_grad_clip_coef_f32: n <= 0 or workspace < 1024 floats");
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+    sumsq_kernel<<<grid, 256, 0, s>>>(g, n, workspace);
+    int st = lime_check_launch("sumsq_kernel");
+    if (st != LIME_OK) return st;
+    clip_coef_kernel<<<1, 256, 0, s>>>(workspace, grid, max_norm, out2);
+    return lime_check_launch("clip_coef_kernel");
+}
+
+extern "C" int lime_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int32_t step, const float* grad_scale, void* stream) {
+    LIME_REQUIRE(p && g && m && v, LIME_ERR_BAD_ARG, "lime_adam_f32: null pointer");
+    LIME_REQUIRE(n >= 0 && step >= 1, LIME_ERR_BAD_ARG, "lime_adam_f32: n < 0 or step < 1");
+    if (n == 0) return LIME_OK;
+    const double b1 = 1.0 - pow((double)beta1, (double)step), b2 = sqrt(1.0 - pow((double)beta2, (double)step));
+    const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    adam_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, (float)b1, (float)b2, grad_scale);
+    return lime_check_launch("adam_kernel");
+}
+
+extern "C" int lime_nll_softmax_f32(const float* logits, int64_t ld, int32_t B, int32_t K, float* loss, float* dlogits, int64_t ldd,
+                                    void* stream) {
+    LIME_REQUIRE(logits && loss, LIME_ERR_BAD_ARG, "lime_nll_softmax_f32: null pointer");
+    LIME_REQUIRE(B > 0 && K > 0 && ld >= K && (!dlogits || ldd >= K), LIME_ERR_BAD_ARG, "lime_nll_softmax_f32: bad dimensions");
+    nll_softmax_kernel<<<1, 256, 0, (hipStream_t)stream>>>(logits, ld, B, K, loss, dlogits, ldd);
+    return lime_check_launch("nll_softmax_kernel");
+}

@@ -55,7 +55,7 @@ struct GemmP {
     const float* a; long lda; const int* a_ids; const float* a_pe; long lda_pe; int a_period;
     const float* w; long ldw; const float* bias;
     const float* res; long ldr; int res_div; int res_mod; const int* res_ids; const float* res_pe; long ldr_pe; int res_period;
-    const float* ln_g; const float* ln_b; float ln_eps;
+    const float* ln_g; const float* ln_b; float ln_eps; float* ln_rstd;
     float* c; long ldc; int M, N, K; int act;
     int n_row_blocks, n_col_blocks;
 #ifdef LIME_STAMPS
@@ -436,6 +436,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && TM * TN <= 4) ? 2 : 
 #pragma unroll
                     for (int w = 0; w < WN; ++w) tot += red_sq[w * BM + wrow0 + i * 32 + fi];
                     rstd[i] = 1.0f / sqrtf(tot * inv_n + p.ln_eps);
+                    if (p.ln_rstd != nullptr && wn == 0 && fh == 0 && (wrow0 + i * 32 + fi) < rows_left)
+                        p.ln_rstd[row0 + wrow0 + i * 32 + fi] = rstd[i];
                 }
             }
             // result: 4 consecutive columns per register group -> one 16-byte store
@@ -610,6 +612,7 @@ extern "C" int lime_linear_f32(const lime_linear_args* a, void* stream) {
     LIME_REQUIRE(!a->ln_gamma || a->ln_beta, LIME_ERR_BAD_ARG, "lime_linear_f32: ln_gamma without ln_beta");
     LIME_REQUIRE(a->act >= LIME_ACT_NONE && a->act <= LIME_ACT_SIGMOID, LIME_ERR_BAD_ARG, "lime_linear_f32: bad act %d", a->act);
     LIME_REQUIRE(a->res_mod >= 0 && (a->pool32 == 0 || a->pool32 == 1), LIME_ERR_BAD_ARG, "lime_linear_f32: res_mod < 0 or pool32 not 0 / 1");
+    LIME_REQUIRE(!a->ln_rstd || (a->ln_gamma && !a->pool32), LIME_ERR_BAD_ARG, "lime_linear_f32: ln_rstd needs the LayerNorm epilogue without pool32");
     if (a->M == 0) return LIME_OK;
 
     // big M, 16-byte friendly operands: two four-wave workgroups per CU with LDS-DMA staging (gemm_pp_f32.hip)
@@ -627,7 +630,7 @@ extern "C" int lime_linear_f32(const lime_linear_args* a, void* stream) {
     p.res = a->res; p.ldr = a->ldr; p.res_div = a->res_div > 0 ? a->res_div : 1; p.res_ids = a->res_ids;
     p.res_mod = (a->res && !a->res_ids && a->res_mod > 0) ? a->res_mod : 0;
     p.res_pe = a->res_pe; p.ldr_pe = a->ldr_pe; p.res_period = a->res_period;
-    p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps;
+    p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps; p.ln_rstd = a->ln_rstd;
     p.c = a->c; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act;
     p.n_row_blocks = p.n_col_blocks = 0;
     // acc + bias + res (the documented order with no activation) == (res + acc) + bias up to fp32 rounding

@@ -9,7 +9,7 @@ struct PPParams {
     const float* a; long lda; const int* a_ids;
     const float* w; long ldw; const float* bias;
     const float* res; long ldr; int res_mod; const int* res_ids; const float* res_pe; long ldr_pe; int res_period;
-    const float* ln_g; const float* ln_b; float ln_eps;
+    const float* ln_g; const float* ln_b; float ln_eps; float* ln_rstd;
     float* c; long ldc; int M, N, K;
     int ln_count;        // LayerNorm divides by this many columns (N unless the caller zero-padded N)
     int n_row_blocks, n_col_blocks;

@@ -395,6 +395,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
                 s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
                 mean[tt] = s1 * inv_n;
                 rstd[tt] = rsqrtf(fmaxf(s2 * inv_n - mean[tt] * mean[tt], 0.f) + p.ln_eps);
+                const int r = row0 + 32 * wave + 16 * tt + fi;
+                if (p.ln_rstd != nullptr && kg == 0 && r < p.M) p.ln_rstd[r] = rstd[tt];
             }
         }
         unsigned cof[2];
@@ -579,7 +581,7 @@ int lime_linear_pp(const lime_linear_args* a, hipStream_t s) {
     p.w = a->w; p.ldw = a->ldw; p.bias = a->bias;
     p.res = a->res; p.ldr = a->ldr; p.res_mod = a->res_mod; p.res_ids = a->res_ids;
     p.res_pe = a->res_pe; p.ldr_pe = a->ldr_pe; p.res_period = a->res_period > 0 ? a->res_period : 1;
-    p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps;
+    p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps; p.ln_rstd = a->ln_rstd;
     p.c = a->c; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K; p.ln_count = a->N;
     p.n_row_blocks = p.n_col_blocks = 0;
     if (ln) {
@@ -642,7 +644,7 @@ extern "C" int lime_linear_bf16(const lime_linear_bf16_args* a, void* stream) {
     p.w = (const float*)a->w; p.ldw = a->ldw; p.bias = a->bias;
     p.res = (const float*)a->res; p.ldr = a->ldr; p.res_mod = a->res_mod; p.res_ids = a->res_ids;
     p.res_pe = a->res_pe; p.ldr_pe = a->ldr_pe; p.res_period = a->res_period > 0 ? a->res_period : 1;
-    p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps;
+    p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps; p.ln_rstd = nullptr;
     p.c = (float*)a->c; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K; p.ln_count = ln ? a->ln_count : a->N;
     p.n_row_blocks = p.n_col_blocks = 0;
     hipStream_t s = (hipStream_t)stream;

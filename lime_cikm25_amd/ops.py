@@ -61,11 +61,11 @@ def _mask_u8(mask, name):
 
 
 def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=0, res=None, res_div=1, res_ids=None,
-           res_pe=None, res_period=0, ln=None, ln_eps=1e-5, res_mod=0, pool32=False):
+           res_pe=None, res_period=0, ln=None, ln_eps=1e-5, res_mod=0, pool32=False, ln_rstd=None):
     """C = epilogue(A . W^T + bias) -- see ``lime_linear_f32`` in include/lime_hip.h.
 
     a: [M, K] (or the [V, K] table when a_ids is given, M = len(a_ids)); w: [N, K]; out: [M, N] (may be a view).
-    ln: (gamma, beta) for the fused LayerNorm (N <= 320).
+    ln: (gamma, beta) for the fused LayerNorm (N <= 320); ln_rstd: optional [M] output of the rows' 1 / sqrt(var + eps).
     """
     lib = _lib.load()
     _mat(a, 'a')
@@ -120,6 +120,8 @@ def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=
         args.ln_gamma = _vec(ln[0], 'ln gamma', N).data_ptr()
         args.ln_beta = _vec(ln[1], 'ln beta', N).data_ptr()
         args.ln_eps = ln_eps
+        if ln_rstd is not None:
+            args.ln_rstd = _vec(ln_rstd, 'ln_rstd', M).data_ptr()
     args.c, args.ldc = out.data_ptr(), _ld(out)
     args.M, args.N, args.K = M, N, K
     args.act = LIME_ACT[act]
@@ -539,3 +541,163 @@ def gather_rows_multi(idx, pairs):
     """out[r] = table[idx[r]] for every (table, out) pair, one launch per 16 pairs."""
     _vec(idx, 'idx', dtype=torch.int32)
     gather_rows_multi_run(idx, gather_rows_multi_prepare(idx.numel(), pairs))
+
+
+# ---- training step (include/lime_hip.h, "Training step") ------------------------------------------------------------------
+_WS = {}
+
+
+def _workspace(device, floats):
+    """A per-device scratch buffer for the fixed-order reductions (grown on demand; launches on one stream are ordered, so
+    consecutive kernels can share it)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < floats:
+        ws = torch.empty(max(int(floats), 1 << 20), dtype=torch.float32, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def linear_wgrad(dy, x, out=None, accumulate=False):
+    """dW [N, K] (+)= dy^T x  (dy [M, N], x [M, K])."""
+    lib = _lib.load()
+    _mat(dy, 'dy')
+    _mat(x, 'x')
+    M, N = dy.shape
+    K = x.shape[1]
+    if x.shape[0] != M:
+        raise ValueError('dy has %d rows, x has %d' % (M, x.shape[0]))
+    if out is None:
+        if accumulate:
+            raise ValueError('accumulate needs out')
+        out = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    _mat(out, 'out')
+    if tuple(out.shape) != (N, K):
+        raise ValueError('out must be [%d, %d]' % (N, K))
+    if M == 0:
+        return out if accumulate else out.zero_()
+    need = lib.lime_linear_wgrad_workspace(M, N, K)
+    ws = _workspace(dy.device, need)
+    check(lib.lime_linear_wgrad_f32(_p(dy), _ld(dy), _p(x), _ld(x), _p(out), _ld(out), M, N, K, 1 if accumulate else 0, _p(ws),
+                                    ws.numel(), _stream()), 'lime_linear_wgrad_f32')
+    return out
+
+
+def colsum(x, out=None, accumulate=False):
+    """out [N] (+)= column sums of x [M, N]."""
+    lib = _lib.load()
+    _mat(x, 'x')
+    M, N = x.shape
+    if out is None:
+        if accumulate:
+            raise ValueError('accumulate needs out')
+        out = torch.empty(N, dtype=torch.float32, device=x.device)
+    _vec(out, 'out', N)
+    if M == 0:
+        return out if accumulate else out.zero_()
+    ws = _workspace(x.device, lib.lime_colsum_workspace(M, N))
+    check(lib.lime_colsum_f32(_p(x), _ld(x), M, N, _p(out), 1 if accumulate else 0, _p(ws), ws.numel(), _stream()), 'lime_colsum_f32')
+    return out
+
+
+def layernorm_bwd(dy, y, gamma, beta, rstd, dy_div=1, dy_scale=1.0, want_dzsum=True):
+    """Backward of y = LayerNorm(z): returns (dz [M, E], dgamma, dbeta, dzsum or None).  dy: [ceil(M / dy_div), E]."""
+    lib = _lib.load()
+    _mat(dy, 'dy')
+    _mat(y, 'y')
+    M, E = y.shape
+    if dy.shape[1] != E or dy.shape[0] * dy_div < M:
+        raise ValueError('dy must be [>= %d, %d]' % ((M + dy_div - 1) // dy_div, E))
+    _vec(gamma, 'gamma', E)
+    _vec(beta, 'beta', E)
+    _vec(rstd, 'rstd', M)
+    dev = y.device
+    dz = torch.empty((M, E), dtype=torch.float32, device=dev)
+    dgamma = torch.empty(E, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(E, dtype=torch.float32, device=dev)
+    dzsum = torch.empty(E, dtype=torch.float32, device=dev) if want_dzsum else None
+    ws = _workspace(dev, lib.lime_layernorm_bwd_workspace(M, E))
+    check(lib.lime_layernorm_bwd_f32(_p(dy), _ld(dy), dy_div, dy_scale, _p(y), _ld(y), _p(gamma), _p(beta), _p(rstd), _p(dz), _ld(dz),
+                                     M, E, _p(dgamma), _p(dbeta), _p(dzsum), 0, _p(ws), ws.numel(), _stream()),
+          'lime_layernorm_bwd_f32')
+    return dz, dgamma, dbeta, dzsum
+
+
+def relu_bwd_(dh, h):
+    """dh[h <= 0] = 0, in place."""
+    lib = _lib.load()
+    _mat(dh, 'dh')
+    _mat(h, 'h')
+    if dh.shape != h.shape:
+        raise ValueError('dh and h differ in shape')
+    check(lib.lime_relu_bwd_f32(_p(dh), _ld(dh), _p(h), _ld(h), dh.shape[0], dh.shape[1], _stream()), 'lime_relu_bwd_f32')
+    return dh
+
+
+def token_attention_bwd(q, k, v, dout, n_seq, S, n_head, head_dim, scale, head_stride=None, dqkv=None):
+    """Backward of the unmasked ``token_attention``: q / k / v column views of one packed qkv buffer [tokens, 3 * n_head *
+    head_stride]; returns dqkv in the same layout."""
+    lib = _lib.load()
+    hs = head_dim if head_stride is None else head_stride
+    W = n_head * hs
+    for t, name in ((q, 'q'), (k, 'k'), (v, 'v')):
+        _mat(t, name)
+        if t.shape[0] != n_seq * S or t.shape[1] != W:
+            raise ValueError('%s must be [n_seq * S, n_head * head_stride]' % name)
+    if not (_ld(q) == _ld(k) == _ld(v)):
+        raise ValueError('q, k, v must share one leading dimension')
+    _mat(dout, 'dout')
+    if tuple(dout.shape) != (n_seq * S, n_head * head_dim):
+        raise ValueError('dout must be [n_seq * S, n_head * head_dim]')
+    if dqkv is None:
+        dqkv = torch.empty((n_seq * S, 3 * W), dtype=torch.float32, device=q.device)
+    _mat(dqkv, 'dqkv')
+    dq, dk, dv = dqkv[:, :W], dqkv[:, W:2 * W], dqkv[:, 2 * W:]
+    check(lib.lime_token_attention_bwd_f32(_p(q), _p(k), _p(v), _ld(q), _p(dout), _ld(dout), _p(dq), _p(dk), _p(dv), _ld(dqkv),
+                                           n_seq, S, n_head, head_dim, hs, scale, _stream()), 'lime_token_attention_bwd_f32')
+    return dqkv
+
+
+def embed_bwd(ids, dx, dtable, hot_id=0):
+    """dtable[ids[r]] += dx[r]  (float atomics)."""
+    lib = _lib.load()
+    _vec(ids, 'ids', dtype=torch.int32)
+    _mat(dx, 'dx')
+    _mat(dtable, 'dtable')
+    if dx.shape[0] != ids.numel() or dx.shape[1] != dtable.shape[1]:
+        raise ValueError('dx must be [len(ids), dim]')
+    check(lib.lime_embed_bwd_f32(_p(ids), _p(dx), _ld(dx), _p(dtable), _ld(dtable), ids.numel(), dx.shape[1], hot_id, _stream()),
+          'lime_embed_bwd_f32')
+    return dtable
+
+
+def grad_clip_coef(g, max_norm):
+    """[norm, min(1, max_norm / (norm + 1e-6))] of the flat gradient buffer, as a 2-element device tensor."""
+    lib = _lib.load()
+    _vec(g, 'g')
+    out = torch.empty(2, dtype=torch.float32, device=g.device)
+    ws = _workspace(g.device, 1024)
+    check(lib.lime_grad_clip_coef_f32(_p(g), g.numel(), float(max_norm), _p(out), _p(ws), ws.numel(), _stream()), 'lime_grad_clip_coef_f32')
+    return out
+
+
+def adam_step_(p, g, m, v, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=None):
+    lib = _lib.load()
+    n = p.numel()
+    for t, name in ((p, 'p'), (g, 'g'), (m, 'm'), (v, 'v')):
+        _vec(t, name, n)
+    check(lib.lime_adam_f32(_p(p), _p(g), _p(m), _p(v), n, lr, betas[0], betas[1], eps, weight_decay, step, _p(grad_scale), _stream()),
+          'lime_adam_f32')
+    return p
+
+
+def nll_softmax(logits, want_grad=True):
+    """(loss [1], dlogits [B, K] or None) of trainer.py:71-73."""
+    lib = _lib.load()
+    _mat(logits, 'logits')
+    B, K = logits.shape
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    d = torch.empty((B, K), dtype=torch.float32, device=logits.device) if want_grad else None
+    check(lib.lime_nll_softmax_f32(_p(logits), _ld(logits), B, K, _p(loss), _p(d), _ld(d) if d is not None else K, _stream()),
+          'lime_nll_softmax_f32')
+    return loss, d

@@ -1,0 +1,162 @@
+"""Backward / optimizer kernels of the training step (include/lime_hip.h, "Training step") on the MI355X, each against
+torch's own fp32 / fp64 CPU autograd of the same op on seeded inputs.  Tolerance: 1e-3 relative (the north star's), with the
+tighter bound exact-fp32 kernels are expected to reach asserted alongside."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TIGHT = 5e-5
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'these tests need the GPU'
+    from lime_cikm25_amd import ops as _ops
+    from lime_cikm25_amd import _lib
+    _lib.load()
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def close(got, want, tol=TIGHT, what=''):
+    got = got.detach().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert torch.isfinite(got).all(), what
+    e = rel_err(got.numpy(), want.detach().numpy())
+    assert e <= tol, '%s: rel err %.3e > %.1e' % (what, e, tol)
+    return e
+
+
+@pytest.mark.parametrize('M,N,K', [(1000, 900, 300), (5000, 300, 512), (333, 50, 100), (70, 400, 1800), (4099, 512, 300),
+                                   (20000, 960, 300)])
+def test_wgrad(ops, M, N, K):
+    dy, x = rnd(M, N, seed=1), rnd(M, K, seed=2)
+    want = (dy.double().t() @ x.double()).float()
+    got = ops.linear_wgrad(dy.cuda(), x.cuda())
+    close(got, want, what='wgrad %s' % ((M, N, K),))
+    # accumulate into an existing gradient, strided operands
+    wide_dy, wide_x = rnd(M, N + 8, seed=3).cuda(), rnd(M, K + 4, seed=4).cuda()
+    base = rnd(N, K, seed=5)
+    out = base.clone().cuda()
+    ops.linear_wgrad(wide_dy[:, 4:N + 4], wide_x[:, :K], out=out, accumulate=True)
+    want = base + (wide_dy[:, 4:N + 4].cpu().double().t() @ wide_x[:, :K].cpu().double()).float()
+    close(out, want, what='wgrad accumulate')
+
+
+@pytest.mark.parametrize('M,N', [(1, 7), (1000, 300), (70000, 960)])
+def test_colsum(ops, M, N):
+    x = rnd(M, N, seed=6)
+    close(ops.colsum(x.cuda()), x.double().sum(0).float(), what='colsum')
+
+
+@pytest.mark.parametrize('M,E,div', [(96, 300, 1), (5000, 300, 1), (4096 * 2, 300, 32), (70016, 300, 128), (300, 400, 1), (64, 50, 16)])
+def test_layernorm_bwd_and_rstd(ops, M, E, div):
+    K = 64
+    a, w, b = rnd(M, K, seed=1), rnd(E, K, seed=2, scale=0.3), rnd(E, seed=3)
+    res = rnd(M, E, seed=4)
+    gamma, beta = rnd(E, seed=5) * 0.5 + 1.0, rnd(E, seed=6)
+    dy = rnd((M + div - 1) // div, E, seed=7)
+    z = (a @ w.t() + b + res).double().requires_grad_()
+    gd, bd = gamma.double().requires_grad_(), beta.double().requires_grad_()
+    y = F.layer_norm(z, (E,), gd, bd, 1e-5)
+    dy_full = dy.double().repeat_interleave(div, dim=0)[:M] / div
+    y.backward(dy_full)
+    rstd_want = (1.0 / torch.sqrt(z.detach().var(dim=1, unbiased=False) + 1e-5)).float()
+
+    if E <= 320:          # the fused LayerNorm epilogue of lime_linear_f32 hands out rstd
+        rstd = torch.empty(M, dtype=torch.float32, device='cuda')
+        yg = ops.linear(a.cuda(), w.cuda(), b.cuda(), res=res.cuda(), ln=(gamma.cuda(), beta.cuda()), ln_rstd=rstd)
+        close(yg, y.detach().float(), what='fused LN forward')
+        close(rstd, rstd_want, what='ln_rstd')
+    else:
+        yg, rstd = y.detach().float().cuda(), rstd_want.cuda()
+    dz, dg, db, dzs = ops.layernorm_bwd(dy.cuda(), yg, gamma.cuda(), beta.cuda(), rstd, dy_div=div, dy_scale=1.0 / div)
+    close(dz, z.grad.float(), tol=2e-4, what='dz')
+    close(dg, gd.grad.float(), tol=2e-4, what='dgamma')
+    close(db, bd.grad.float(), tol=2e-4, what='dbeta')
+    close(dzs, z.grad.sum(0).float(), tol=2e-4, what='dzsum')
+
+
+def test_relu_bwd(ops):
+    h = torch.relu(rnd(777, 512, seed=1))
+    dh = rnd(777, 512, seed=2)
+    got = ops.relu_bwd_(dh.clone().cuda(), h.cuda())
+    assert torch.equal(got.cpu(), dh * (h > 0))
+
+
+@pytest.mark.parametrize('n_seq,S,nh,hd,hs', [(3, 16, 10, 30, 32), (5, 32, 10, 30, 32), (2, 50, 4, 20, 20), (3, 64, 10, 30, 32),
+                                              (2, 128, 10, 30, 32), (1, 100, 2, 32, 32), (37, 32, 10, 30, 32)])
+def test_token_attention_bwd(ops, n_seq, S, nh, hd, hs):
+    tok = n_seq * S
+    scale = 1.0 / math.sqrt(hd)
+    W = nh * hs
+    qkv = torch.zeros(tok, 3 * W)
+    vals = rnd(tok, 3, nh, hd, seed=1)
+    qkv.view(tok, 3, nh, hs)[..., :hd] = vals
+    dout = rnd(tok, nh * hd, seed=2)
+    x = vals.double().requires_grad_()
+    q, k, v = (x[:, i].reshape(n_seq, S, nh, hd).permute(0, 2, 1, 3) for i in range(3))
+    p = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(tok, nh * hd)
+    o.backward(dout.double())
+    want = torch.zeros(tok, 3, nh, hs)
+    want[..., :hd] = x.grad.float()
+    g = qkv.cuda()
+    # the forward kernel on the same operands, for completeness of the pair
+    out = ops.token_attention(g[:, :W], g[:, W:2 * W], g[:, 2 * W:], n_seq, S, nh, hd, scale, head_stride=hs)
+    close(out, o.detach().float(), what='attention forward')
+    dqkv = ops.token_attention_bwd(g[:, :W], g[:, W:2 * W], g[:, 2 * W:], dout.cuda(), n_seq, S, nh, hd, scale, head_stride=hs)
+    close(dqkv, want.view(tok, 3 * W), tol=2e-4, what='dqkv')
+    if hs > hd:
+        assert (dqkv.view(tok, 3, nh, hs)[..., hd:] == 0).all(), 'pad columns must be exact zeros'
+
+
+def test_embed_bwd(ops):
+    V, D, rows = 500, 300, 20000
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(1, V, (rows,), generator=g, dtype=torch.int32)
+    ids[torch.rand(rows, generator=g) < 0.4] = 0                  # the padding word dominates
+    dx = rnd(rows, D, seed=4)
+    want = torch.zeros(V, D, dtype=torch.float64).index_add_(0, ids.long(), dx.double()).float()
+    got = ops.embed_bwd(ids.cuda(), dx.cuda(), torch.zeros(V, D, device='cuda'), hot_id=0)
+    close(got, want, tol=2e-4, what='embedding gradient')
+    got = ops.embed_bwd(ids.cuda(), dx.cuda(), torch.zeros(V, D, device='cuda'), hot_id=-1)
+    close(got, want, tol=2e-4, what='embedding gradient, no hot row')
+
+
+def test_nll_softmax(ops):
+    logits = rnd(37, 5, seed=1, scale=4.0)
+    x = logits.double().requires_grad_()
+    loss = (-torch.log_softmax(x, dim=1).select(dim=1, index=0)).mean()
+    loss.backward()
+    got_loss, got_d = ops.nll_softmax(logits.cuda())
+    close(got_loss, loss.detach().float().reshape(1), what='loss')
+    close(got_d, x.grad.float(), what='dlogits')
+
+
+def test_clip_and_adam_follow_torch(ops):
+    n = 100003
+    p0, grads = rnd(n, seed=1), [rnd(n, seed=10 + i, scale=0.05 * (i + 1)) for i in range(4)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3, weight_decay=0.0)
+    p = p0.clone().cuda()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step, g in enumerate(grads, 1):
+        ref.grad = g.clone()
+        norm = torch.nn.utils.clip_grad_norm_([ref], 4.0)
+        opt.step()
+        gg = g.cuda()
+        coef = ops.grad_clip_coef(gg, 4.0)
+        close(coef[:1], norm.reshape(1), what='grad norm')
+        ops.adam_step_(p, gg, m, v, step, 1e-3, grad_scale=coef[1:])
+        close(p, ref.detach(), tol=1e-5, what='parameters after step %d' % step)
