@@ -112,7 +112,7 @@ def main():
     model.training = True                        # [B, K] candidates; every child in eval mode
     batch_cpu = synth.make_batch(cfg, B, N, seed=100 + rank)
     batch = [v.cuda() for v in batch_cpu.values()]
-    step = lambda: model(*batch)
+    step = torch.no_grad()(lambda: model(*batch))      # scoring: no autograd graph (grad mode on would take the training path)
     if args.workload == 'cfg5':                  # Model.score_impressions: eval semantics, histories encoded once (eager)
         model.training = False
         c = {k: v.cuda() for k, v in batch_cpu.items()}

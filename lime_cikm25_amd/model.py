@@ -2,7 +2,7 @@
 import torch
 import torch.nn as nn
 
-from . import newsEncoders, ops, userEncoders
+from . import newsEncoders, ops, training, userEncoders
 from .util import RemainingLifetimeWeighting
 
 # positions (in the 26-tensor signature, model.py:151-154) of the inputs the scoring path reads; the others
@@ -19,9 +19,10 @@ class Model(nn.Module):
     ``news_embedding_dim``), ``initialize()`` and 26-tensor ``forward`` as the reference's Model
     (model.py:12-187); ``state_dict()`` has the reference's key set.  ``forward`` returns logits [B, N].
 
-    Scoring only: the forward pass runs entirely in hand-written HIP kernels and does not record an
-    autograd graph (the training step is SURVEY.md section 8f row 2).  Candidates and history are encoded in one pass
-    over the news-encoder kernels (the reference encodes them in two calls, model.py:171 and userEncoders.py:110).
+    Scoring (eval mode, or any call under ``torch.no_grad()``): the forward pass runs entirely in hand-written HIP
+    kernels and records no autograd graph.  In training mode with grad enabled (``model.train(); model(...)``, what
+    trainer.py:131 does) ``forward`` takes the differentiable path of ``lime_cikm25_amd.training``.  Candidates and history
+    are encoded in one pass over the news-encoder kernels (the reference encodes them in two calls, model.py:171 and userEncoders.py:110).
 
     The ~75 kernel launches of a forward are captured once per input signature into a HIP graph and replayed
     (``use_graph``, on by default): the forward is launch-bound from Python otherwise (2.5 ms of gaps on 6 ms of
@@ -75,6 +76,12 @@ class Model(nn.Module):
                 user_history_mask, user_history_graph, user_history_category_mask, user_history_category_indices, news_category,
                 news_subCategory, news_title_text, news_title_mask, news_title_entity, news_content_text, news_content_mask,
                 news_content_entity, news_freshness, news_user_topic_lifetime, remaining_lifetime)
+        if self.training and torch.is_grad_enabled():
+            # trainer.py:131-145: model.train(); logits = model(...); loss.backward() -- the differentiable path
+            return training.forward_train(self, user_category, user_subCategory, user_title_text, user_content_text,
+                                          user_freshness, user_user_topic_lifetime, user_history_mask, news_category,
+                                          news_subCategory, news_title_text, news_content_text, news_freshness,
+                                          news_user_topic_lifetime, remaining_lifetime)
         if (self.use_graph and ops.PROFILE is None and user_category.is_cuda
                 and not torch.cuda.is_current_stream_capturing()):
             return self._forward_graphed(args)

@@ -1,0 +1,389 @@
+"""The training step of LIME-CROWN-CROWN: a differentiable ``Model.forward`` for
+``loss.backward()`` (reference trainer.py:131-148), and the native step that replaces trainer.py:143-148 --
+``zero_grad / backward / clip_grad_norm_ / Adam.step`` -- plus the gradient all-reduce of a data-parallel run.
+
+Where the arithmetic runs
+  * token encoders (word gather + positional table + post-LN encoder layer + mean pool, 97 % of a step's FLOPs):
+    hand-written HIP forward AND backward behind one autograd node (``_TokenEncoder``): the forward of the scoring path
+    with the LayerNorm rstd kept, backward = LayerNorm / attention / ReLU backward kernels, the MFMA weight-gradient GEMM,
+    input gradients on lime_linear_f32 with transposed weights, word-table scatter-add.
+  * every nn.Linear of the tail and the user encoder: ``_Linear`` (HIP GEMMs forward and backward).
+  * the small element-wise / softmax glue between them (intent attention, cosine similarity, candidate-aware weights,
+    gated LayerNorm, GraphSAGE mean, history-vs-candidate softmax, lifetime weight): torch ops on the device with torch's
+    autograd.  The fused scoring kernels of that glue have no hand-written backward yet.
+
+Dropout: the reference trains with dropout_rate 0.2 inside the encoder layers; the HIP encoder has no dropout masks, so a
+model whose token encoders are in training mode with dropout_rate > 0 raises NotImplementedError.  Dropout in the torch
+glue (feature_fusion, user_node_embedding, the hard-coded p = 0.2 of the candidate-aware attention) is honoured.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# autograd nodes over the HIP kernels
+# ---------------------------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    """y = act(x W^T + b) on lime_linear_f32; backward: dX on lime_linear_f32 (W^T as the weight operand), dW on the
+    weight-gradient GEMM, db as a column sum."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        x = x if x.stride(-1) == 1 else x.contiguous()
+        y = ops.linear(x, w, b, act=act)
+        ctx.act = act
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, y if act is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.act == 'relu':
+            dy = ops.relu_bwd_(dy.clone(), y)
+        elif ctx.act == 'tanh':
+            dy = dy * (1.0 - y * y)
+        elif ctx.act == 'sigmoid':
+            dy = dy * y * (1.0 - y)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.linear(dy, w.t().contiguous(), None)
+        if ctx.needs_input_grad[1]:
+            dw = ops.linear_wgrad(dy, x)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(dy)
+        return dx, dw, db, None
+
+
+def linear(x, lin, act=None):
+    """nn.Linear ``lin`` applied to the last axis of x (any leading shape)."""
+    shape = x.shape[:-1]
+    y = _Linear.apply(x.reshape(-1, x.shape[-1]), lin.weight, lin.bias, act)
+    return y.view(*shape, -1)
+
+
+def _unpad_heads(t, groups, hd, hs):
+    """[groups * hs, ...] -> [groups * hd, ...]: drop the padding rows ``ops.pad_heads`` inserted."""
+    if hs == hd:
+        return t
+    rest = t.shape[1:]
+    return t.view(groups, hs, *rest)[:, :hd].reshape(groups * hd, *rest)
+
+
+class _TokenEncoder(torch.autograd.Function):
+    """pooled [M, E] = mean_S(EncoderLayer(E[ids] + PE))  (newsEncoders.py:311-321 for one of title / body)."""
+
+    @staticmethod
+    def forward(ctx, ids, nhead, eps1, eps2, table, pe, in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b):
+        M, S = ids.shape
+        E = table.shape[1]
+        hd = E // nhead
+        hs = 32 if hd <= 32 else hd
+        if hs > 32 or S > 128:
+            raise NotImplementedError('the attention backward kernel covers head_dim <= 32 and S <= 128 (got %d, %d)' % (hd, S))
+        W = nhead * hs
+        flat = ids.reshape(-1).contiguous()
+        tok = M * S
+        dev = table.device
+        w_in = ops.pad_heads(in_w, 3 * nhead, hd, hs) if hs != hd else in_w
+        b_in = ops.pad_heads(in_b, 3 * nhead, hd, hs) if hs != hd else in_b
+        pew = ops.linear(pe[:S], w_in, b_in)
+        qkv = ops.linear(table, w_in, None, a_ids=flat, res=pew, res_mod=S)
+        ao = ops.token_attention(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, 1.0 / math.sqrt(hd), head_stride=hs)
+        rstd1 = torch.empty(tok, dtype=torch.float32, device=dev)
+        x1 = ops.linear(ao, out_w, out_b, res=table, res_ids=flat, res_pe=pe, res_period=S, ln=(n1_w, n1_b), ln_eps=eps1,
+                        ln_rstd=rstd1)
+        h = ops.linear(x1, l1_w, l1_b, act='relu')
+        rstd2 = torch.empty(tok, dtype=torch.float32, device=dev)
+        y = ops.linear(h, l2_w, l2_b, res=x1, ln=(n2_w, n2_b), ln_eps=eps2, ln_rstd=rstd2)
+        pooled = ops.mean_pool(y, M, S)
+        ctx.dims = (M, S, E, nhead, hd, hs)
+        ctx.save_for_backward(flat, table, pe, w_in, out_w, l1_w, l2_w, n1_w, n1_b, n2_w, n2_b, qkv, ao, x1, rstd1, h, y, rstd2)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        (flat, table, pe, w_in, out_w, l1_w, l2_w, n1_w, n1_b, n2_w, n2_b, qkv, ao, x1, rstd1, h, y, rstd2) = ctx.saved_tensors
+        M, S, E, nhead, hd, hs = ctx.dims
+        W = nhead * hs
+        dpooled = dpooled.contiguous()
+        # norm2 <- mean pool: every token of a sequence receives dpooled / S
+        dz2, dn2_w, dn2_b, dl2_b = ops.layernorm_bwd(dpooled, y, n2_w, n2_b, rstd2, dy_div=S, dy_scale=1.0 / S)
+        del y
+        dl2_w = ops.linear_wgrad(dz2, h)
+        dh = ops.linear(dz2, l2_w.t().contiguous(), None)
+        ops.relu_bwd_(dh, h)
+        del h
+        dl1_w = ops.linear_wgrad(dh, x1)
+        dl1_b = ops.colsum(dh)
+        dx1 = ops.linear(dh, l1_w.t().contiguous(), None, res=dz2)             # through linear1 + the residual branch
+        del dh, dz2
+        dz1, dn1_w, dn1_b, dout_b = ops.layernorm_bwd(dx1, x1, n1_w, n1_b, rstd1)
+        del dx1, x1
+        dout_w = ops.linear_wgrad(dz1, ao)
+        dao = ops.linear(dz1, out_w.t().contiguous(), None)
+        del ao
+        dqkv = ops.token_attention_bwd(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], dao, M, S, nhead, hd, 1.0 / math.sqrt(hd),
+                                       head_stride=hs)
+        del dao, qkv
+        x0 = ops.embed_pe(flat, table, pe, S)                                   # the layer input, re-gathered
+        din_w = _unpad_heads(ops.linear_wgrad(dqkv, x0), 3 * nhead, hd, hs)
+        din_b = _unpad_heads(ops.colsum(dqkv), 3 * nhead, hd, hs)
+        del x0
+        dx0 = ops.linear(dqkv, w_in.t().contiguous(), None, res=dz1)            # through in_proj + the residual branch
+        dtable = None
+        if ctx.needs_input_grad[4]:
+            dtable = torch.zeros_like(table)
+            ops.embed_bwd(flat, dx0, dtable, hot_id=0)
+        return (None, None, None, None, dtable, None, din_w, din_b, dout_w, dout_b, dl1_w, dl1_b, dl2_w, dl2_b, dn1_w, dn1_b,
+                dn2_w, dn2_b)
+
+
+def encode_tokens(ids, table, pos_encoder, transformer, nhead):
+    if len(transformer.layers) != 1 or transformer.norm is not None:
+        raise NotImplementedError('the training path covers num_layers = 1 without a final norm (config.py default)')
+    layer = transformer.layers[0]
+    if layer.training and (layer.dropout.p > 0 or layer.self_attn.dropout > 0 or pos_encoder.dropout.p > 0):
+        raise NotImplementedError('training-mode dropout inside the encoder layers is not implemented on the HIP path: '
+                                  'train with dropout_rate = 0 or keep the token encoders in eval mode')
+    sa = layer.self_attn
+    return _TokenEncoder.apply(ids.contiguous(), nhead, layer.norm1.eps, layer.norm2.eps, table, pos_encoder.table(),
+                               sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, layer.linear1.weight,
+                               layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, layer.norm1.weight, layer.norm1.bias,
+                               layer.norm2.weight, layer.norm2.bias)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the differentiable forward
+# ---------------------------------------------------------------------------------------------------------------------
+def _additive_attention(att, feature):
+    """layers.Attention.forward without a mask (layers.py:285-300): feature [M, k, D] -> [M, D]."""
+    a = linear(feature, att.affine1, act='tanh')
+    score = (a * att.affine2.weight.view(1, 1, -1)).sum(dim=-1)
+    alpha = torch.softmax(score, dim=1)
+    return (alpha.unsqueeze(-1) * feature).sum(dim=1)
+
+
+def crown_content(enc, title_text, content_text, category, subCategory):
+    """newsEncoders.CROWN.forward (newsEncoders.py:302-373) on M flat news -> [M, 900]."""
+    if enc.training and enc.dropout_rate > 0:
+        raise NotImplementedError('training-mode dropout on the word embeddings (newsEncoders.py:311-312) is not implemented '
+                                  'on the HIP path: train with dropout_rate = 0 or keep the news encoder in eval mode')
+    table = enc.word_embedding.weight
+    title_p = encode_tokens(title_text, table, enc.title_pos_encoder, enc.title_transformer, enc.head_num)      # :311-317
+    body_p = encode_tokens(content_text, table, enc.body_pos_encoder, enc.body_transformer, enc.head_num)       # :312-321
+    cat_e = enc.category_embedding.weight[category.long()]
+    sub_e = enc.subCategory_embedding.weight[subCategory.long()]
+    cat_rep = linear(torch.cat([cat_e, sub_e], dim=1), enc.category_affine)                                     # :340-342
+    w_int = torch.cat([lin.weight for lin in enc.intent_layers], dim=0)
+    b_int = torch.cat([lin.bias for lin in enc.intent_layers], dim=0)
+    k, D = enc.intent_num, enc.intent_embedding_dim
+
+    def intents(pooled):                                                                                        # :284-295
+        x = torch.cat([pooled, cat_rep], dim=1)
+        return _Linear.apply(x, w_int, b_int, 'relu').view(-1, k, D)
+
+    title_i = _additive_attention(enc.title_intent_attention, intents(title_p))                                 # :355
+    body_i = _additive_attention(enc.body_intent_attention, intents(body_p))                                    # :356
+    sim = (F.cosine_similarity(title_i, body_i, dim=1) + 1) / 2.0                                               # :297-300
+    return torch.cat([title_i, sim.unsqueeze(1) * body_i, enc.dropout(cat_e.clone()), enc.dropout(sub_e.clone())], dim=1)   # :221-225
+
+
+def lime_news(ne, title_text, content_text, category, subCategory, freshness, lifetime):
+    """LIME.forward, fusion 'concat' (newsEncoders.py:140-153) on M flat news -> [M, 400]."""
+    from .newsEncoders import CROWN
+    base = ne.base_news_encoder
+    if not isinstance(base, CROWN):
+        raise NotImplementedError('the training path covers the CROWN content encoder (LIME-CROWN-CROWN)')
+    content = crown_content(base, title_text, content_text, category, subCategory)
+    fe = ne.freshness_encoder
+    fb = ops.bucketize(freshness).long()
+    lb = ops.bucketize(lifetime).long()
+    fresh = linear(torch.cat([fe.freshness_embedding.weight[fb], fe.lifetime_embedding.weight[lb]], dim=1), fe.dense, act='tanh')
+    fused = torch.cat([content, fresh], dim=1)
+    return fused if isinstance(ne.project, nn.Identity) else linear(fused, ne.project)
+
+
+def _topic(ne, category, subCategory):
+    """userEncoders.py:103-105 / :115-117."""
+    x = torch.cat([ne.category_embedding.weight[category.long()], ne.subCategory_embedding.weight[subCategory.long()]], dim=-1)
+    return linear(x, ne.category_affine)
+
+
+def candidate_aware(att, hist, hist_topic, cand_topic, mask):
+    """CandidateAware_ClickedNewsAttention.forward (layers.py:52-93); the value_proj branch is dead there."""
+    B, H, D = hist.shape
+    N = cand_topic.shape[1]
+    nh, hd = att.num_heads, att.head_dim
+    Q = linear(cand_topic, att.query_proj).view(B, N, nh, hd).transpose(1, 2)
+    K = linear(hist_topic, att.key_proj).view(B, H, nh, hd).transpose(1, 2)
+    s = torch.matmul(Q, K.transpose(-2, -1)) / att.scale
+    if mask is not None:
+        s = s.masked_fill(mask.view(B, 1, 1, H) == 0, -1e9)
+    a = att.dropout(torch.softmax(s, dim=-1))
+    qw = torch.softmax(torch.norm(Q.transpose(1, 2).reshape(B, N, -1), dim=-1), dim=1)
+    agg = torch.softmax((a.sum(dim=1) * qw.unsqueeze(-1)).sum(dim=1), dim=-1)
+    wc = agg.unsqueeze(-1) * hist
+    if not att.use_residual_connection:
+        return wc
+    gate = linear(wc, att.gate_proj, act='sigmoid')
+    ln = att.layernorm
+    return F.layer_norm(gate * wc + (1 - gate) * hist, (D,), ln.weight, ln.bias, ln.eps)
+
+
+def user_match(ue, hist, cand, category, subCategory, user_category, user_subCategory, user_history_mask, n_src=None):
+    """userEncoders.CROWN.forward after the history is encoded (userEncoders.py:103-105, :114-169) -> user [B, N, D]."""
+    B, H, D = hist.shape
+    N = cand.shape[1]
+    ne = ue.news_encoder
+    if ue.use_candidate_aware_attn:
+        hist = candidate_aware(ue.candidate_aware_attn, hist, _topic(ne, user_category, user_subCategory),
+                               _topic(ne, category, subCategory), user_history_mask)
+    nodes = ue.dropout_(ue.user_node_embedding.unsqueeze(0).expand(B, -1, -1))                                    # :121
+    n_src = B if n_src is None else n_src
+    if n_src > H + nodes.shape[1]:
+        raise IndexError('rows per forward (%d) exceed the node slots H + config.batch_size (SURVEY Q7)' % n_src)
+    X = torch.cat([hist, nodes], dim=1)
+    conv = ue.graph_sage.convs[0]
+    g = linear(X[:, :n_src].mean(dim=1), conv.lin_l).unsqueeze(1) + linear(hist, conv.lin_r)                      # :151-157
+    kp = linear(g, ue.K)                                                                                         # :161
+    qp = linear(cand, ue.Q)                                                                                      # :162
+    a = torch.matmul(qp, kp.transpose(1, 2)) / ue.attention_scalar                                               # [B, N, H]
+    return torch.matmul(torch.softmax(a, dim=-1), g)                                                             # :164-168
+
+
+def lifetime_weight(w, remaining):
+    """RemainingLifetimeWeighting (util.py:23-49): the factor on the dot product, a constant of the parameters."""
+    if not w.use_remaining_lifetime_weighting:
+        return None
+    if w.use_expired_penalty:
+        s = torch.sigmoid(w.alpha * remaining)
+        return torch.where(remaining >= 0, s, w.beta * s)
+    return torch.sigmoid(w.alpha * remaining.abs())
+
+
+def forward_train(model, user_category, user_subCategory, user_title_text, user_content_text, user_freshness,
+                  user_user_topic_lifetime, user_history_mask, news_category, news_subCategory, news_title_text,
+                  news_content_text, news_freshness, news_user_topic_lifetime, remaining_lifetime):
+    """Model.forward with [B, N] candidates (model.py:171-187), recording the autograd graph."""
+    ne, ue = model.news_encoder, model.user_encoder
+    B, N = news_category.shape
+    H = user_category.shape[1]
+    i32 = lambda t: t if t.dtype == torch.int32 else t.to(torch.int32)
+    flat2 = lambda c, u: torch.cat([c.reshape(B * N, -1), u.reshape(B * H, -1)], dim=0)
+    flat1 = lambda c, u: torch.cat([c.reshape(-1), u.reshape(-1)], dim=0)
+    if news_freshness.dim() == 1:
+        news_freshness = news_freshness.unsqueeze(1).expand(B, N)
+    if news_user_topic_lifetime.dim() == 1:
+        news_user_topic_lifetime = news_user_topic_lifetime.unsqueeze(1).expand(B, N)
+    rep = lime_news(ne, i32(flat2(news_title_text, user_title_text)), i32(flat2(news_content_text, user_content_text)),
+                    i32(flat1(news_category, user_category)), i32(flat1(news_subCategory, user_subCategory)),
+                    flat1(news_freshness.float(), user_freshness.float()).contiguous(),
+                    flat1(news_user_topic_lifetime.float(), user_user_topic_lifetime.float()).contiguous())
+    cand = rep[:B * N].view(B, N, -1)
+    hist = rep[B * N:].view(B, H, -1)
+    user = user_match(ue, hist, cand, news_category, news_subCategory, user_category, user_subCategory, user_history_mask)
+    logits = (user * cand).sum(dim=-1)                                                                            # util.py:37
+    w = lifetime_weight(model.remaining_lifetime_weighting, remaining_lifetime.float())
+    return logits if w is None else logits * w
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the native step: flat parameter / gradient / Adam-state buffers, one clip + one Adam launch, one all-reduce
+# ---------------------------------------------------------------------------------------------------------------------
+def negative_log_softmax(logits):
+    """trainer.py:71-73 on the HIP loss kernel (forward and gradient in one launch)."""
+    return _NllSoftmax.apply(logits)
+
+
+class _NllSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits):
+        loss, d = ops.nll_softmax(logits.contiguous())
+        ctx.save_for_backward(d)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (d,) = ctx.saved_tensors
+        return d * dloss
+
+
+# parameters the reference constructs and never uses on this path: autograd leaves their .grad at None, Adam and
+# clip_grad_norm_ skip them, and so does the flat bucket
+_DEAD = ('base_news_encoder.affine.', '.ISAB.', 'category_predictor.', 'user_encoder.affine.', 'candidate_aware_attn.value_proj.')
+
+
+class TrainStep:
+    """trainer.py:33 + :143-148 for one process (one GPU): Adam(lr, weight_decay) over the parameters that receive
+    gradients, ``clip_grad_norm_(gradient_clip_norm)``, and -- under torch.distributed -- ONE all-reduce (RCCL over xGMI on
+    ROCm) of the flat gradient bucket before the clip, averaging over ranks as DistributedDataParallel does.
+
+    Parameters are re-pointed into one flat fp32 buffer (``p.data`` becomes a view, values preserved) and their ``.grad``
+    into a second one, so zeroing, the norm, the all-reduce and the Adam update are one launch each.
+    """
+
+    def __init__(self, model, lr=1e-4, weight_decay=0.0, gradient_clip_norm=4.0, betas=(0.9, 0.999), eps=1e-8,
+                 process_group=None):
+        self.model = model
+        self.lr, self.weight_decay, self.clip, self.betas, self.eps = lr, weight_decay, gradient_clip_norm, betas, eps
+        self.group = process_group
+        named, seen = [], set()
+        for name, p in model.named_parameters():
+            if not p.requires_grad or id(p) in seen or any(d in name for d in _DEAD):
+                continue
+            seen.add(id(p))
+            named.append((name, p))
+        self.names = [n for n, _ in named]
+        total = sum(p.numel() for _, p in named)
+        dev = named[0][1].device
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for _, p in named:
+                n = p.numel()
+                self.flat[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat[off:off + n].view(p.shape)
+                p.grad = self.grad[off:off + n].view(p.shape)
+                off += n
+        self.step_count = 0
+        self.last_norm = None
+
+    def world_size(self):
+        import torch.distributed as dist
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def backward_and_update(self, loss):
+        """loss.backward() into the flat bucket, all-reduce, clip, Adam.  Returns the (device) gradient norm."""
+        self.grad.zero_()
+        loss.backward()
+        ws = self.world_size()
+        if ws > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.grad, group=self.group)
+            self.grad.mul_(1.0 / ws)
+        return self.update()
+
+    def update(self):
+        self.step_count += 1
+        coef = ops.grad_clip_coef(self.grad, self.clip)
+        ops.adam_step_(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.betas, self.eps,
+                       self.weight_decay, grad_scale=coef[1:])
+        self.last_norm = coef[:1]
+        return self.last_norm
+
+    def step(self, *batch):
+        """One training step on a batch in ``Model.forward``'s 26-tensor order; returns the (device) loss."""
+        logits = self.model(*batch)
+        loss = negative_log_softmax(logits)
+        self.backward_and_update(loss)
+        return loss.detach()

@@ -64,7 +64,8 @@ def test_assembled_batch_drives_the_model():
         batch = beh.assemble(list(range(8)))
         remaining = batch[24] - batch[23]                                   # trainer.py:126-127 (lifetime_type user_topic)
         model.training = not eval_shape
-        got = model(*batch, remaining).cpu()
+        with torch.no_grad():
+            got = model(*batch, remaining).cpu()
         cpu = {n: t.cpu() for n, t in zip(names, batch + [remaining])}
         want = O.model_forward(sd, cfg, cpu, eval_shape=eval_shape)
         assert rel_err(got.numpy().reshape(-1), want.numpy().reshape(-1)) < 1e-3
@@ -90,7 +91,8 @@ def test_cached_scoring_equals_the_eval_forward():
     batch = beh.assemble(rows)
     remaining = batch[24] - batch[23]
     model.use_graph = False
-    ref = model(*batch, remaining).cpu().reshape(-1)
+    with torch.no_grad():
+        ref = model(*batch, remaining).cpu().reshape(-1)
     assert rel_err(got.numpy(), ref.numpy()) < 2e-5
     names = list(synth.make_batch(cfg, 2, 2, seed=0).keys())
     want = O.model_forward(sd, cfg, {n: t.cpu() for n, t in zip(names, batch + [remaining])}, eval_shape=True).reshape(-1)

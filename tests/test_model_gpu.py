@@ -29,7 +29,8 @@ def run(model, batch, eval_shape):
     model.eval()
     if not eval_shape:
         model.training = True          # [B, K] inputs; children stay in eval mode (no dropout)
-    out = model(*[v.cuda() for v in batch.values()])
+    with torch.no_grad():              # scoring (with grad mode on, training = True selects the differentiable path)
+        out = model(*[v.cuda() for v in batch.values()])
     torch.cuda.synchronize()
     return out.cpu()
 

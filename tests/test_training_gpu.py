@@ -1,0 +1,140 @@
+"""The training step on the MI355X against gradients captured from the imported reference
+(tests/golden/grad_*.npz, tools/make_grad_goldens.py): loss, every parameter gradient, which parameters get none (Q20), then
+the native clip + Adam step against torch.optim.Adam / clip_grad_norm_ driven by the same gradients.  Tolerance 1e-3
+relative (north star); observed errors are printed."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases
+from helpers import load_golden, rel_err
+from lime_cikm25_amd import Model, synth
+from lime_cikm25_amd.training import TrainStep, negative_log_softmax
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+LR = 1e-5
+GRAD_CASES = ['cfg1_crown', 'spill', 'empty_history', 'full_len']
+
+
+def train_model(name):
+    cfg, batch, c = golden_cases.build_case(name)
+    model = Model(cfg)
+    model.initialize()
+    synth.fill_state_dict(model, golden_cases.WEIGHT_SEED)
+    model = model.cuda()
+    model.eval()
+    model.training = True              # [B, K] shape, children in eval mode: what the goldens were captured with
+    return cfg, model, [v.cuda() for v in batch.values()]
+
+
+def unique_named_parameters(model):
+    seen = set()
+    for k, p in model.named_parameters():
+        if id(p) not in seen:
+            seen.add(id(p))
+            yield k, p
+
+
+def compare_grads(g, named):
+    worst = ('', 0.0)
+    for k in json.loads(str(g['with_grad'])):
+        got = named[k].grad
+        assert got is not None, '%s has no gradient' % k
+        got = got.detach().cpu().double().reshape(-1)
+        assert torch.isfinite(got).all(), k
+        scale = float(g['norm:' + k]) / max(1.0, got.numel()) ** 0.5          # rms of the reference gradient
+        if 'full:' + k in g.files_:
+            want = g['full:' + k].reshape(-1)
+            e = rel_err(got.numpy(), want, floor=max(scale, 1e-6))
+        else:
+            idx, want = g['idx:' + k], g['val:' + k]
+            e = rel_err(got.numpy()[idx], want, floor=max(scale, 1e-6))
+            e = max(e, abs(float(got.norm()) - float(g['norm:' + k])) / (float(g['norm:' + k]) + 1e-6))
+        if e > worst[1]:
+            worst = (k, e)
+        assert e < TOL, '%s: gradient rel err %.3e' % (k, e)
+    return worst
+
+
+class _G(dict):
+    files_ = ()
+
+
+def golden(name):
+    d = _G(load_golden('grad_' + name))
+    d.files_ = set(d.keys())
+    return d
+
+
+@pytest.mark.parametrize('name', GRAD_CASES)
+def test_gradients_match_the_reference(name):
+    g = golden(name)
+    cfg, model, batch = train_model(name)
+    logits = model(*batch)
+    assert logits.requires_grad
+    assert rel_err(logits.detach().cpu().numpy(), g['logits']) < TOL
+    loss = negative_log_softmax(logits)
+    assert abs(float(loss.detach()) - float(g['loss'])) < TOL * max(1.0, abs(float(g['loss'])))
+    loss.backward()
+    named = dict(unique_named_parameters(model))
+    for k in json.loads(str(g['without_grad'])):
+        assert named[k].grad is None, '%s: the reference leaves this gradient at None (SURVEY Q20)' % k
+    worst = compare_grads(g, named)
+    print('%s: loss %.6f (reference %.6f), worst gradient %s rel err %.2e' % (name, float(loss.detach()), float(g['loss']), *worst))
+
+
+def test_native_step_follows_torch_adam_and_clip():
+    """TrainStep (flat buckets, HIP clip + Adam) against clip_grad_norm_ + torch.optim.Adam fed with the SAME gradients,
+    three steps; then the loss must have moved the way the torch-driven copy's did."""
+    name = 'cfg1_crown'
+    g = golden(name)
+    cfg, model, batch = train_model(name)
+    _, twin, _ = train_model(name)
+    step = TrainStep(model, lr=LR, gradient_clip_norm=4.0)
+    assert sorted(step.names) == sorted(json.loads(str(g['with_grad'])))
+    params = [p for k, p in unique_named_parameters(twin) if k in set(step.names)]
+    opt = torch.optim.Adam(params, lr=LR)
+    losses = []
+    for it in range(3):
+        loss = step.step(*batch)
+        losses.append(float(loss))
+        # the twin: our backward, torch's optimizer
+        opt.zero_grad()
+        tl = negative_log_softmax(twin(*batch))
+        tl.backward()
+        norm = torch.nn.utils.clip_grad_norm_(params, 4.0)
+        opt.step()
+        assert abs(float(tl.detach()) - losses[-1]) < 1e-4 * max(1.0, abs(losses[-1])), (it, float(tl.detach()), losses[-1])
+        assert abs(float(norm) - float(step.last_norm)) < 1e-4 * float(norm)
+    named, tnamed = dict(unique_named_parameters(model)), dict(unique_named_parameters(twin))
+    for k in step.names:
+        a, b = named[k].detach().cpu().double().reshape(-1), tnamed[k].detach().cpu().double().reshape(-1)
+        d = (a - b).abs()
+        # Adam divides by sqrt(v): an element whose gradient is at rounding-noise level (|g| ~ eps = 1e-8; the word-table
+        # scatter-add's atomic order differs run to run) can move by up to lr per step in either direction, so the bound is
+        # "the typical element agrees to 1e-4 of the parameter scale, none differs by more than the three steps could move it"
+        # (the optimizer arithmetic itself is pinned element-wise on identical gradients in test_backward_gpu.py)
+        scale = float(b.abs().mean()) + 1e-12
+        assert float(d.max()) <= 3 * LR * 1.01, '%s: max |diff| %.3e' % (k, float(d.max()))
+        q = float(torch.quantile(d[:1 << 20], 0.5))
+        assert q <= 1e-4 * scale + 1e-7, '%s after 3 steps: median |diff| %.3e (scale %.3e)' % (k, q, scale)
+    assert abs(losses[0] - float(g['loss'])) < TOL * max(1.0, abs(float(g['loss'])))
+    assert losses[2] < losses[0], 'three Adam steps on one batch must lower its loss: %s' % losses
+    # scoring still works on the updated (re-pointed) parameters, and agrees with the training forward
+    with torch.no_grad():
+        scored = model(*batch)
+    again = model(*batch)
+    assert rel_err(scored.cpu().numpy(), again.detach().cpu().numpy()) < 1e-4
+
+
+def test_training_mode_dropout_in_the_encoder_is_refused():
+    cfg, batch, c = golden_cases.build_case('cfg1_crown')
+    cfg.dropout_rate = 0.2
+    model = Model(cfg)
+    model.initialize()
+    model = model.cuda().train()
+    with pytest.raises(NotImplementedError):
+        model(*[v.cuda() for v in batch.values()])

@@ -41,6 +41,7 @@ def main():
         return w
     for n in names:
         setattr(ops, n, wrap(n, getattr(ops, n)))
+    torch.set_grad_enabled(False)
     for _ in range(2):
         model(*batch)
     torch.cuda.synchronize()
