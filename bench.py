@@ -47,6 +47,9 @@ WORKLOADS = {
              'MIND-shape synthetic, batch=256, history=50, title 32 + body 128, K=1+4, bf16 MFMA token encoders with fp32 '
              'accumulate / softmax / LayerNorm (BASELINE.json configs[2])'),
     'cfg2b_bf16': (dict(compute_dtype='bf16'), 32, 5, 'configs[1] shape (batch=32) with the bf16 token encoders of configs[2]'),
+    # one training step = forward + backward + gradient all-reduce (N > 1) + clip_grad_norm_ + Adam
+    'train2b': (dict(), 32, 5, 'training step (forward + backward + gradient all-reduce + clip + Adam), LIME-CROWN-CROWN, '
+                               'batch=32 per GPU, history=50, title 32 + body 128, K=1+4, fp32, dropout off'),
     'cfg5': (dict(batch_size=1024), 1024, 100,
              'MIND-shape inference, 1024 impressions x K=100 candidates, history=50, title 32 + body 128, scoring only, '
              'eval-mode (per-candidate) semantics with every history encoded once (BASELINE.json configs[4]), fp32'),
@@ -113,6 +116,11 @@ def main():
     batch_cpu = synth.make_batch(cfg, B, N, seed=100 + rank)
     batch = [v.cuda() for v in batch_cpu.values()]
     step = torch.no_grad()(lambda: model(*batch))      # scoring: no autograd graph (grad mode on would take the training path)
+    train = args.workload.startswith('train')
+    if train:                                    # trainer.py:131-148 on the native step (flat buckets, one all-reduce)
+        from lime_cikm25_amd.training import TrainStep
+        ts = TrainStep(model, lr=1e-5, gradient_clip_norm=4.0)
+        step = lambda: ts.step(*batch)
     if args.workload == 'cfg5':                  # Model.score_impressions: eval semantics, histories encoded once (eager)
         model.training = False
         c = {k: v.cuda() for k, v in batch_cpu.items()}
@@ -129,8 +137,11 @@ def main():
         torch.cuda.synchronize()
 
     # The forward's ~75 launches are replayed from a HIP graph captured on the first call (Model.use_graph).
-    for _ in range(args.warmup):
+    first_loss = None
+    for i in range(args.warmup):
         logits = step()
+        if i == 0 and train:
+            first_loss = float(logits)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -148,8 +159,18 @@ def main():
     if rank == 0:
         ops.PROFILE = prof
         newsEncoders.SERIAL_STREAMS = True
+        if train:                                  # rank 0 alone: the same step without the collective
+            from lime_cikm25_amd.training import negative_log_softmax
+
+            def local_step():
+                ts.grad.zero_()
+                negative_log_softmax(model(*batch)).backward()
+                ts.update()
+            prof_step = local_step
+        else:
+            prof_step = step
         for _ in range(args.steps):
-            step()
+            prof_step()
         torch.cuda.synchronize()
         newsEncoders.SERIAL_STREAMS = False
         ops.PROFILE = None
@@ -159,6 +180,8 @@ def main():
     if rank == 0:
         value = world * B * args.steps / dt
         fimp = flops_per_impression(cfg, N, per_candidate_user_side=args.workload == 'cfg5')
+        if train:
+            fimp *= 3                                   # backward = input gradients + weight gradients: 2 x the forward GEMMs
         # dominant kernel = the gemm_f32_kernel instantiation with the largest total time (out_proj + linear2 of both
         # encoders: 128x320 tiles, residual in the accumulators, LayerNorm epilogue)
         by_kernel = {}
@@ -184,20 +207,40 @@ def main():
                     'all_gemm_kernels': {k: {'tflops': round(v[0] / v[1] / 1e12, 2), 'avg_launch_us': round(v[1] / v[2] * 1e6, 1),
                                              'launches': v[2]} for k, v in by_kernel.items()}}
         out = {
-            'metric': 'impressions scored/sec', 'value': round(value, 2), 'unit': 'impressions/s', 'n_gpus': world,
+            'metric': 'impressions trained/sec' if train else 'impressions scored/sec', 'value': round(value, 2), 'unit': 'impressions/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if getattr(cfg, 'compute_dtype', 'fp32') == 'bf16' else 'f32', 'data': 'synthetic',
             'config': {'workload': desc, 'batch_per_gpu': B, 'history': cfg.max_history_num, 'candidates': N,
                        'title_len': cfg.max_title_length, 'body_len': cfg.max_abstract_length,
-                       'parallelism': 'rows sharded over %d GPU(s), no data-path collective' % world,
+                       'parallelism': ('data parallel over %d GPU(s), one all-reduce of the flat gradient bucket per step' % world) if train
+                       else 'rows sharded over %d GPU(s), no data-path collective' % world,
                        'streams': 'title / body / freshness / attention-weight branches forked' if args.overlap_streams else
                        'token encoders on one stream; freshness and attention-weight branches forked beside the head'},
             'roofline': roof,
             'end_to_end': {'flops_per_impression': fimp, 'achieved_tflops': round(value * fimp / 1e12, 2),
                            'frac_of_f32_mfma_peak': round(value * fimp / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4)},
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload != 'cfg5':
+        if world == 1 and not args.no_cpu_baseline and train:
+            from oracle import lime_oracle
+            ncore = min(len(os.sched_getaffinity(0)), 16)
+            torch.set_num_threads(ncore)
+            sd_g = {k: v.clone() for k, v in sd_cpu.items()}
+            for k in ts.names:
+                sd_g[k].requires_grad_(True)
+            for k in list(sd_g):
+                if k.startswith('user_encoder.news_encoder.'):
+                    sd_g[k] = sd_g[k[len('user_encoder.'):]]
+            c0 = time.perf_counter()
+            lg = lime_oracle.model_forward(sd_g, cfg, batch_cpu, grad=True)
+            closs = (-torch.log_softmax(lg, dim=1).select(dim=1, index=0)).mean()
+            closs.backward()
+            cdt = time.perf_counter() - c0
+            out['cpu_baseline'] = {'value': round(B / cdt, 2), 'unit': 'impressions/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                                   'sample': '1 forward + backward of the same %d-impression batch (torch CPU fp32 oracle with '
+                                             'autograd, no optimizer step, no warm-up)' % B,
+                                   'first_step_loss_cpu': float(closs), 'first_step_loss_gpu': first_loss}
+        elif world == 1 and not args.no_cpu_baseline and args.workload != 'cfg5':
             from oracle import lime_oracle
             # the GPU box gives one GPU's share of the host: 16 cores (more threads only oversubscribe)
             ncore = min(len(os.sched_getaffinity(0)), 16)

@@ -353,6 +353,11 @@ int lime_token_attention_bwd_f32(const float* q, const float* k, const float* v,
 int lime_embed_bwd_f32(const int32_t* ids, const float* dx, int64_t lddx, float* dtable, int64_t ld_table, int64_t rows,
                        int32_t dim, int32_t hot_id, void* stream);
 
+/* The same for a table of at most 32 rows (FreshnessEncoder's two 10-row bucket tables, newsEncoders.py:75-76): per-column
+ * LDS accumulation, no atomics, fixed summation order.  Rows whose id is outside [0, table_rows) are ignored. */
+int lime_embed_bwd_small_f32(const int32_t* ids, const float* dx, int64_t lddx, float* dtable, int64_t ld_table, int64_t rows,
+                             int32_t dim, int32_t table_rows, void* stream);
+
 /* out2[0] = ||g||_2 over the flat gradient buffer, out2[1] = min(1, max_norm / (out2[0] + 1e-6))  -- the coefficient of
  * torch.nn.utils.clip_grad_norm_ (trainer.py:146-147); max_norm <= 0: out2[1] = 1.  workspace >= 1024 floats. */
 int lime_grad_clip_coef_f32(const float* g, int64_t n, float max_norm, float* out2, float* workspace, int64_t workspace_floats,

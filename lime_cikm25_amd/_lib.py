@@ -117,6 +117,7 @@ SIGNATURES = {
     'lime_token_attention_bwd_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
                                                c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
     'lime_embed_bwd_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p]),
+    'lime_embed_bwd_small_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p]),
     'lime_grad_clip_coef_f32': (c_int32, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     'lime_adam_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                                 c_int32, c_void_p, c_void_p]),

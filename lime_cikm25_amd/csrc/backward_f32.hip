@@ -55,23 +55,28 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------------
-// wgrad: workgroup = one 128 x TK tile of dW over one slice of the M rows.  Four waves, each a 64 x TK/2 quadrant
-// (4 x NKT accumulator tiles of 16 x 16).  32-row chunks of dY and X go global -> registers -> LDS (two stages).
+// wgrad: workgroup = one 128 x TK tile of dW (TK = 64 NKT: the whole K of the encoder layers' 300-wide operands) over one
+// slice of the M rows.  Eight waves in a 2 x 4 grid, each a 64 x 16 NKT patch (4 x NKT accumulator tiles of 16 x 16), two
+// waves per SIMD so one wave's LDS waits sit under the other's MFMAs.  64-row chunks of dY and X go global -> registers
+// -> LDS (one stage): the loads of chunk i + 1 are issued right after chunk i has been written to LDS and are in flight
+// for the whole of its MFMA phase (56 KB per workgroup -- one 32-row chunk in flight left the kernel latency-bound).
 // ---------------------------------------------------------------------------------------------------
 constexpr int WG_TN = 128;
-constexpr int WG_MC = 32;
+constexpr int WG_MC = 64;
+constexpr int WG_THREADS = 512;
 
-template <int NKT>       // 16-column accumulator tiles per wave along K: TK = 32 * NKT
-__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dy, long ldy, const float* __restrict__ x, long ldx,
-                                                     float* __restrict__ ws, int M, int N, int K, int n_tiles, int k_tiles,
-                                                     int rows_per_split) {
-    constexpr int TK = 32 * NKT;
+template <int NKT>       // 16-column accumulator tiles per wave along K: TK = 64 * NKT
+__global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const float* __restrict__ dy, long ldy, const float* __restrict__ x,
+                                                            long ldx, float* __restrict__ ws, int M, int N, int K, int n_tiles,
+                                                            int k_tiles, int rows_per_split) {
+    constexpr int TK = 64 * NKT;
     constexpr int LDA = WG_TN + 16;          // pitch % 32 == 16: the two row groups of a half-wave hit disjoint banks
     constexpr int LDB = TK + 16;
-    constexpr int A4 = WG_MC * WG_TN / 4 / 256;            // float4 per thread per chunk (dY tile): 4
-    constexpr int B4 = (WG_MC * TK / 4 + 255) / 256;       // (X tile): 4 or 5
-    __shared__ float As[2][WG_MC * LDA];
-    __shared__ float Bs[2][WG_MC * LDB];
+    constexpr int A4 = WG_MC * WG_TN / 4 / WG_THREADS;                    // float4 per thread per chunk (dY tile): 2
+    constexpr int B4 = (WG_MC * TK / 4 + WG_THREADS - 1) / WG_THREADS;    // (X tile): 3, 4 or 5
+    extern __shared__ float wg_smem[];
+    float* const As = wg_smem;                                            // [WG_MC * LDA]
+    float* const Bs = wg_smem + WG_MC * LDA;                              // [WG_MC * LDB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, kg = lane >> 4;
@@ -81,7 +86,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dy
     const int n0 = (tile / k_tiles) * WG_TN, k0 = (tile % k_tiles) * TK;
     const long m_begin = (long)split * rows_per_split;
     const long m_end = min((long)M, m_begin + rows_per_split);
-    const int wn = (wave >> 1) * 64, wk = (wave & 1) * (TK / 2);
+    const int wn = (wave >> 2) * 64, wk = (wave & 3) * (16 * NKT);
 
     f32x4 acc[4][NKT];
 #pragma unroll
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dy
     auto load_chunk = [&](long m0) {
 #pragma unroll
         for (int j = 0; j < A4; ++j) {
-            const int f = tid + 256 * j, r = f / (WG_TN / 4), c = (f % (WG_TN / 4)) * 4;
+            const int f = tid + WG_THREADS * j, r = f / (WG_TN / 4), c = (f % (WG_TN / 4)) * 4;
             const long m = m0 + r;
             f32x4v v = {0.f, 0.f, 0.f, 0.f};
             if (m < m_end) {
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dy
         }
 #pragma unroll
         for (int j = 0; j < B4; ++j) {
-            const int f = tid + 256 * j, r = f / (TK / 4), c = (f % (TK / 4)) * 4;
+            const int f = tid + WG_THREADS * j, r = f / (TK / 4), c = (f % (TK / 4)) * 4;
             const long m = m0 + r;
             f32x4v v = {0.f, 0.f, 0.f, 0.f};
             if (f < WG_MC * TK / 4 && m < m_end) {
@@ -123,29 +128,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dy
             rb[j] = v;
         }
     };
-    auto store_chunk = [&](int stage) {
+    auto store_chunk = [&]() {
 #pragma unroll
         for (int j = 0; j < A4; ++j) {
-            const int f = tid + 256 * j, r = f / (WG_TN / 4), c = (f % (WG_TN / 4)) * 4;
-            *reinterpret_cast<f32x4v*>(&As[stage][r * LDA + c]) = ra[j];
+            const int f = tid + WG_THREADS * j, r = f / (WG_TN / 4), c = (f % (WG_TN / 4)) * 4;
+            *reinterpret_cast<f32x4v*>(&As[r * LDA + c]) = ra[j];
         }
 #pragma unroll
         for (int j = 0; j < B4; ++j) {
-            const int f = tid + 256 * j, r = f / (TK / 4), c = (f % (TK / 4)) * 4;
-            if (f < WG_MC * TK / 4) *reinterpret_cast<f32x4v*>(&Bs[stage][r * LDB + c]) = rb[j];
+            const int f = tid + WG_THREADS * j, r = f / (TK / 4), c = (f % (TK / 4)) * 4;
+            if (f < WG_MC * TK / 4) *reinterpret_cast<f32x4v*>(&Bs[r * LDB + c]) = rb[j];
         }
     };
 
     if (m_begin < m_end) {
         load_chunk(m_begin);
-        store_chunk(0);
-        __syncthreads();
-        int stage = 0;
+        const float* as = &As[kg * LDA + wn + fi];
+        const float* bs = &Bs[kg * LDB + wk + fi];
         for (long m0 = m_begin; m0 < m_end; m0 += WG_MC) {
-            const bool more = m0 + WG_MC < m_end;
-            if (more) load_chunk(m0 + WG_MC);
-            const float* as = &As[stage][kg * LDA + wn + fi];
-            const float* bs = &Bs[stage][kg * LDB + wk + fi];
+            __syncthreads();                               // every wave is done reading the previous chunk
+            store_chunk();
+            __syncthreads();
+            if (m0 + WG_MC < m_end) load_chunk(m0 + WG_MC);
 #pragma unroll
             for (int s = 0; s < WG_MC / 4; ++s) {
                 float a[4], b[NKT];
@@ -158,9 +162,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ dy
 #pragma unroll
                     for (int j = 0; j < NKT; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
             }
-            if (more) store_chunk(stage ^ 1);
-            __syncthreads();
-            stage ^= 1;
         }
     }
     // partial tile -> ws[split][n][k] over the padded [n_tiles * 128, k_tiles * TK] grid
@@ -203,7 +204,7 @@ template <int CPL>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, long lddy, int dy_div, float dy_scale,
                                                              const float* __restrict__ y, long ldy, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ rstd,
-                                                             float* __restrict__ dz, long lddz, int M, int E, int rows_per_block,
+                                                             float* __restrict__ dz, long lddz, int M, int E,
                                                              float* __restrict__ ws) {
     __shared__ float red[4][3][64 * CPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -217,9 +218,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         sg[j] = sb[j] = sz[j] = 0.f;
     }
     const float inv_e = 1.0f / (float)E;
-    const long r0 = (long)blockIdx.x * rows_per_block;
-    const long r1 = min((long)M, r0 + rows_per_block);
-    for (long r = r0 + wave; r < r1; r += 4) {
+    for (long r = (long)blockIdx.x * 4 + wave; r < M; r += (long)gridDim.x * 4) {
         const float* pdy = dy + (r / dy_div) * lddy;
         const float* py = y + r * ldy;
         float d[CPL], xh[CPL];
@@ -259,6 +258,85 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
+// The same with 16 lanes per row (four rows per wave at a time) and 16-byte accesses: E % 4 == 0, 16-byte aligned rows.
+template <int V4>        // float4 per lane: ceil(E / 64)
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ dy, long lddy, int dy_div, float dy_scale,
+                                                                 const float* __restrict__ y, long ldy,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 const float* __restrict__ rstd, float* __restrict__ dz, long lddz,
+                                                                 int M, int E, float* __restrict__ ws) {
+    __shared__ float red[4][3][64 * V4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & 15, rg = lane >> 4;
+    const f32x4v zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4v ga[V4], be[V4], iga[V4], sg[V4], sb[V4], sz[V4];
+    bool cin[V4];
+#pragma unroll
+    for (int j = 0; j < V4; ++j) {
+        const int c = 4 * (sub + 16 * j);
+        cin[j] = c < E;
+        ga[j] = cin[j] ? *reinterpret_cast<const f32x4v*>(gamma + c) : zero;
+        be[j] = cin[j] ? *reinterpret_cast<const f32x4v*>(beta + c) : zero;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) iga[j][e] = cin[j] ? 1.0f / ga[j][e] : 0.f;
+        sg[j] = sb[j] = sz[j] = zero;
+    }
+    const float inv_e = 1.0f / (float)E;
+    for (long r4 = ((long)blockIdx.x * 4 + wave) * 4; r4 < M; r4 += (long)gridDim.x * 16) {
+        const long r = r4 + rg;
+        const bool rin = r < M;
+        const float* pdy = dy + ((rin ? r : 0) / dy_div) * lddy;
+        const float* py = y + (rin ? r : 0) * ldy;
+        f32x4v d[V4], xh[V4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < V4; ++j) {
+            const int c = 4 * (sub + 16 * j);
+            const bool ok = rin && cin[j];
+            d[j] = ok ? *reinterpret_cast<const f32x4v*>(pdy + c) * dy_scale : zero;
+            const f32x4v yv = ok ? *reinterpret_cast<const f32x4v*>(py + c) : be[j];
+            xh[j] = (yv - be[j]) * iga[j];
+            const f32x4v g = d[j] * ga[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s1 += g[e]; s2 += g[e] * xh[j][e]; }
+        }
+        s1 += __shfl_xor(s1, 1); s2 += __shfl_xor(s2, 1);
+        s1 += __shfl_xor(s1, 2); s2 += __shfl_xor(s2, 2);
+        s1 += __shfl_xor(s1, 4); s2 += __shfl_xor(s2, 4);
+        s1 += __shfl_xor(s1, 8); s2 += __shfl_xor(s2, 8);
+        s1 *= inv_e; s2 *= inv_e;
+        const float rs = rin ? rstd[r] : 0.f;
+#pragma unroll
+        for (int j = 0; j < V4; ++j) {
+            const int c = 4 * (sub + 16 * j);
+            f32x4v v = (d[j] * ga[j] - s1 - xh[j] * s2) * rs;
+            if (!(rin && cin[j])) v = zero;
+            if (rin && cin[j]) *reinterpret_cast<f32x4v*>(dz + r * lddz + c) = v;
+            sg[j] += d[j] * xh[j];
+            sb[j] += d[j];
+            sz[j] += v;
+        }
+    }
+    // the four row groups of the wave, then the four waves
+#pragma unroll
+    for (int j = 0; j < V4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = sg[j][e], b = sb[j][e], c = sz[j][e];
+            a += __shfl_xor(a, 16); b += __shfl_xor(b, 16); c += __shfl_xor(c, 16);
+            a += __shfl_xor(a, 32); b += __shfl_xor(b, 32); c += __shfl_xor(c, 32);
+            if (rg == 0) {
+                const int col = 4 * (sub + 16 * j) + e;
+                red[wave][0][col] = a; red[wave][1][col] = b; red[wave][2][col] = c;
+            }
+        }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 3 * E; e += 256) {
+        const int k = e / E, c = e - k * E;
+        ws[((long)blockIdx.x * 3 + k) * E + c] = (red[0][k][c] + red[1][k][c]) + (red[2][k][c] + red[3][k][c]);
+    }
+}
+
 __global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ dh, long lddh, const float* __restrict__ h, long ldh,
                                                         long rows, int cols) {
     const long total = rows * cols;
@@ -283,7 +361,7 @@ __global__ __launch_bounds__(256) void token_attn_bwd_kernel(const float* __rest
                                                               const float* __restrict__ v, long ld, const float* __restrict__ dout,
                                                               long ldo, float* __restrict__ dq, float* __restrict__ dk,
                                                               float* __restrict__ dv, long ldd, int n_seq, int S, int n_head,
-                                                              int head_dim, int head_stride, float scale) {
+                                                              int head_dim, int head_stride, float scale, int vec) {
     constexpr int NT = SP / 16;                 // 16-column score tiles per row
     constexpr int WPP = SP / 32;                // waves per problem
     constexpr int PPW = 4 / WPP;                // problems per workgroup
@@ -309,14 +387,40 @@ __global__ __launch_bounds__(256) void token_attn_bwd_kernel(const float* __rest
     {
         const int lt = tid - pw * (64 * WPP);                           // thread index inside the problem
         const long row_base = (long)seq * S;
-        for (int e = lt; e < SP * 32; e += 64 * WPP) {
-            const int r = e >> 5, c = e & 31;
-            const bool ok = live && r < S && c < head_dim;
-            const long g = (row_base + r) * ld + (long)head * head_stride + c;
-            Qs[r * AB_LD + c] = ok ? q[g] : 0.f;
-            Ks[r * AB_LD + c] = ok ? k[g] : 0.f;
-            Vs[r * AB_LD + c] = ok ? v[g] : 0.f;
-            Os[r * AB_LD + c] = ok ? dout[(row_base + r) * ldo + (long)head * head_dim + c] : 0.f;
+        if (vec) {              // head rows of 32 floats on 16-byte boundaries (padded heads: columns >= head_dim hold zeros)
+            for (int e = lt; e < SP * 8; e += 64 * WPP) {
+                const int r = e >> 3, c = (e & 7) * 4;
+                const bool ok = live && r < S;
+                const long g = (row_base + r) * ld + (long)head * head_stride + c;
+                const f32x4v z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4v qv = ok ? *reinterpret_cast<const f32x4v*>(q + g) : z;
+                const f32x4v kv = ok ? *reinterpret_cast<const f32x4v*>(k + g) : z;
+                const f32x4v vv = ok ? *reinterpret_cast<const f32x4v*>(v + g) : z;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    Qs[r * AB_LD + c + j] = qv[j];
+                    Ks[r * AB_LD + c + j] = kv[j];
+                    Vs[r * AB_LD + c + j] = vv[j];
+                }
+            }
+            for (int e = lt; e < SP * 16; e += 64 * WPP) {              // dO rows: 8-byte aligned pairs
+                const int r = e >> 4, c = (e & 15) * 2;
+                const bool ok = live && r < S && c < head_dim;
+                f32x2 d = {0.f, 0.f};
+                if (ok) d = *reinterpret_cast<const f32x2*>(dout + (row_base + r) * ldo + (long)head * head_dim + c);
+                Os[r * AB_LD + c] = d[0];
+                Os[r * AB_LD + c + 1] = d[1];
+            }
+        } else {
+            for (int e = lt; e < SP * 32; e += 64 * WPP) {
+                const int r = e >> 5, c = e & 31;
+                const bool ok = live && r < S && c < head_dim;
+                const long g = (row_base + r) * ld + (long)head * head_stride + c;
+                Qs[r * AB_LD + c] = ok ? q[g] : 0.f;
+                Ks[r * AB_LD + c] = ok ? k[g] : 0.f;
+                Vs[r * AB_LD + c] = ok ? v[g] : 0.f;
+                Os[r * AB_LD + c] = ok ? dout[(row_base + r) * ldo + (long)head * head_dim + c] : 0.f;
+            }
         }
     }
     __syncthreads();
@@ -406,6 +510,7 @@ __global__ __launch_bounds__(256) void token_attn_bwd_kernel(const float* __rest
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) a[jt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
         for (int s = 0; s < SP / 4; ++s) {
             const int i = 4 * s + kg;
             const float a0 = Ps[i * LDP + R0 + fi], a1 = Ps[i * LDP + R0 + 16 + fi];
@@ -434,6 +539,7 @@ __global__ __launch_bounds__(256) void token_attn_bwd_kernel(const float* __rest
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) aq[jt][dt] = ak[jt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
         for (int s = 0; s < SP / 4; ++s) {
             const int j = 4 * s + kg;
             const float q0 = Ps[(R0 + fi) * LDP + j], q1 = Ps[(R0 + 16 + fi) * LDP + j];     // dS[i, j]: rows of this wave
@@ -497,6 +603,27 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ 
             if (c < dim) unsafeAtomicAdd(t + c, hot[j]);
         }
     }
+}
+
+// Tables of at most 32 rows (the freshness / lifetime bucket embeddings, 10 rows x 500): every row receives hundreds of
+// contributions, so atomics would serialise.  A workgroup owns 64 columns; its four waves walk the rows r = wave, wave + 4,
+// ... and add into a private [32][64] LDS image each; the four images are summed in a fixed order.  No atomics.
+__global__ __launch_bounds__(256) void embed_bwd_small_kernel(const int* __restrict__ ids, const float* __restrict__ dx, long lddx,
+                                                               float* __restrict__ dtable, long ldt, long rows, int dim,
+                                                               int table_rows) {
+    __shared__ float acc[4][32][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    for (int t = 0; t < 32; ++t) acc[wave][t][lane] = 0.f;
+    if (c < dim)
+        for (long r = wave; r < rows; r += 4) {
+            const int id = ids[r];
+            if (id >= 0 && id < table_rows) acc[wave][id][lane] += dx[r * lddx + c];
+        }
+    __syncthreads();
+    if (c < dim)
+        for (int t = wave; t < table_rows; t += 4)
+            dtable[(long)t * ldt + c] += (acc[0][t][lane] + acc[1][t][lane]) + (acc[2][t][lane] + acc[3][t][lane]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -578,16 +705,20 @@ struct WgradPlan { int nkt, tk, n_tiles, k_tiles, splits, rows_per_split; long n
 
 WgradPlan wgrad_plan(int M, int N, int K) {
     WgradPlan w;
-    const long k128 = ((long)K + 127) / 128 * 128, k160 = ((long)K + 159) / 160 * 160;
-    w.nkt = k160 < k128 ? 5 : 4;
-    w.tk = 32 * w.nkt;
+    long best = -1;
+    w.nkt = 4;
+    for (int nkt = 3; nkt <= 5; ++nkt) {                          // the tile width 64 * nkt that pads K the least
+        const long tk = 64L * nkt, kp = ((long)K + tk - 1) / tk * tk;
+        if (best < 0 || kp < best || (kp == best && nkt == 4)) { best = kp; w.nkt = nkt; }
+    }
+    w.tk = 64 * w.nkt;
     w.n_tiles = (N + WG_TN - 1) / WG_TN;
     w.k_tiles = (K + w.tk - 1) / w.tk;
     w.np = (long)w.n_tiles * WG_TN;
     w.kp = (long)w.k_tiles * w.tk;
     const int ntile = w.n_tiles * w.k_tiles;
-    int splits = (512 + ntile - 1) / ntile;                       // about two workgroups per CU
-    const int max_splits = (M + 255) / 256;                       // at least 8 chunks of 32 rows per workgroup
+    int splits = (256 + ntile - 1) / ntile;                       // one eight-wave workgroup per CU
+    const int max_splits = (M + 511) / 512;                       // at least 8 chunks of 64 rows per workgroup
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     int rps = (M + splits - 1) / splits;
@@ -596,6 +727,22 @@ WgradPlan wgrad_plan(int M, int N, int K) {
     w.splits = (M + rps - 1) / rps;
     if (w.splits < 1) w.splits = 1;
     return w;
+}
+
+template <int NKT>
+int launch_wgrad(const WgradPlan& w, const float* dy, long ldy, const float* x, long ldx, float* ws, int M, int N, int K,
+                 hipStream_t s) {
+    constexpr int BYTES = WG_MC * ((WG_TN + 16) + (64 * NKT + 16)) * 4;
+    static bool configured = false;
+    if (!configured) {
+        const hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+        LIME_REQUIRE(e == hipSuccess, LIME_ERR_LAUNCH, "lime_linear_wgrad_f32: cannot reserve %d bytes of LDS: %s", BYTES,
+                     hipGetErrorString(e));
+        configured = true;
+    }
+    const int grid = w.n_tiles * w.k_tiles * w.splits;
+    wgrad_kernel<NKT><<<grid, WG_THREADS, BYTES, s>>>(dy, ldy, x, ldx, ws, M, N, K, w.n_tiles, w.k_tiles, w.rows_per_split);
+    return lime_check_launch("wgrad_kernel");
 }
 
 int launch_reduce(const float* ws, long split_stride, int splits, long ldw, float* out, long ldo, int rows, int cols,
@@ -611,7 +758,7 @@ int colsum_blocks(int M) {
     return b < 1 ? 1 : (b > 256 ? 256 : b);
 }
 
-int ln_rows_per_block(int M) { return M >= 65536 ? 256 : 64; }
+int ln_blocks(int M) { const int b = (M + 15) / 16; return b > 768 ? 768 : b; }   // persistent: 3 workgroups per CU
 
 }  // namespace
 
@@ -632,12 +779,9 @@ extern "C" int lime_linear_wgrad_f32(const float* dy, int64_t ldy, const float* 
                  "lime_linear_wgrad_f32: workspace holds %ld floats, lime_linear_wgrad_workspace() asks for %ld",
                  (long)workspace_floats, (long)((int64_t)w.splits * w.np * w.kp));
     hipStream_t s = (hipStream_t)stream;
-    const int grid = w.n_tiles * w.k_tiles * w.splits;
-    if (w.nkt == 5)
-        wgrad_kernel<5><<<grid, 256, 0, s>>>(dy, ldy, x, ldx, workspace, M, N, K, w.n_tiles, w.k_tiles, w.rows_per_split);
-    else
-        wgrad_kernel<4><<<grid, 256, 0, s>>>(dy, ldy, x, ldx, workspace, M, N, K, w.n_tiles, w.k_tiles, w.rows_per_split);
-    const int st = lime_check_launch("wgrad_kernel");
+    const int st = w.nkt == 5 ? launch_wgrad<5>(w, dy, ldy, x, ldx, workspace, M, N, K, s)
+                   : w.nkt == 3 ? launch_wgrad<3>(w, dy, ldy, x, ldx, workspace, M, N, K, s)
+                                : launch_wgrad<4>(w, dy, ldy, x, ldx, workspace, M, N, K, s);
     if (st != LIME_OK) return st;
     return launch_reduce(workspace, w.np * w.kp, w.splits, w.kp, dw, lddw, N, K, accumulate, s);
 }
@@ -663,8 +807,7 @@ extern "C" int lime_colsum_f32(const float* x, int64_t ldx, int32_t M, int32_t N
 
 extern "C" int64_t lime_layernorm_bwd_workspace(int32_t M, int32_t E) {
     if (M <= 0 || E <= 0) return 0;
-    const int rpb = ln_rows_per_block(M);
-    return (int64_t)((M + rpb - 1) / rpb) * 3 * E;
+    return (int64_t)ln_blocks(M) * 3 * E;
 }
 
 extern "C" int lime_layernorm_bwd_f32(const float* dy, int64_t lddy, int32_t dy_div, float dy_scale, const float* y, int64_t ldy,
@@ -675,14 +818,22 @@ extern "C" int lime_layernorm_bwd_f32(const float* dy, int64_t lddy, int32_t dy_
     LIME_REQUIRE(M > 0 && E > 0 && dy_div >= 1, LIME_ERR_BAD_ARG, "lime_layernorm_bwd_f32: bad dimensions");
     LIME_REQUIRE(E <= 512, LIME_ERR_UNSUPPORTED, "lime_layernorm_bwd_f32: E = %d > 512", E);
     LIME_REQUIRE(lddy >= E && ldy >= E && lddz >= E, LIME_ERR_BAD_ARG, "lime_layernorm_bwd_f32: leading dimension smaller than E");
-    const int rpb = ln_rows_per_block(M);
-    const int nblk = (M + rpb - 1) / rpb;
+    const int nblk = ln_blocks(M);
     LIME_REQUIRE(workspace_floats >= (int64_t)nblk * 3 * E, LIME_ERR_BAD_ARG, "lime_layernorm_bwd_f32: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    const int cpl = (E + 63) / 64;
-#define LN_BWD(C) layernorm_bwd_kernel<C><<<nblk, 256, 0, s>>>(dy, lddy, dy_div, dy_scale, y, ldy, gamma, beta, rstd, dz, lddz, M, E, rpb, workspace)
-    if (cpl <= 2) LN_BWD(2); else if (cpl <= 5) LN_BWD(5); else LN_BWD(8);
+    const bool vec = E % 4 == 0 && lddy % 4 == 0 && ldy % 4 == 0 && lddz % 4 == 0 &&
+                     ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)dz) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0;
+    if (vec) {
+        const int v4 = (E + 63) / 64;
+#define LN_BWD_V(C) layernorm_bwd_vec_kernel<C><<<nblk, 256, 0, s>>>(dy, lddy, dy_div, dy_scale, y, ldy, gamma, beta, rstd, dz, lddz, M, E, workspace)
+        if (v4 <= 2) LN_BWD_V(2); else if (v4 <= 5) LN_BWD_V(5); else LN_BWD_V(8);
+#undef LN_BWD_V
+    } else {
+        const int cpl = (E + 63) / 64;
+#define LN_BWD(C) layernorm_bwd_kernel<C><<<nblk, 256, 0, s>>>(dy, lddy, dy_div, dy_scale, y, ldy, gamma, beta, rstd, dz, lddz, M, E, workspace)
+        if (cpl <= 2) LN_BWD(2); else if (cpl <= 5) LN_BWD(5); else LN_BWD(8);
 #undef LN_BWD
+    }
     int st = lime_check_launch("layernorm_bwd_kernel");
     if (st != LIME_OK) return st;
     float* outs[3] = {dgamma, dbeta, dzsum};
@@ -720,8 +871,11 @@ int launch_attn_bwd(const float* q, const float* k, const float* v, long ld, con
     }
     const long n_prob = (long)n_seq * n_head;
     const int grid = (int)((n_prob + PPW - 1) / PPW);
+    // vector staging: 32-float head rows on 16-byte boundaries with zero padding columns, dO pairs on 8-byte boundaries
+    const bool vec = head_stride == 32 && ld % 4 == 0 && ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) == 0 &&
+                     head_dim % 2 == 0 && ldo % 2 == 0 && (((uintptr_t)dout) & 7) == 0;
     token_attn_bwd_kernel<SP><<<grid, 256, BYTES, s>>>(q, k, v, ld, dout, ldo, dq, dk, dv, ldd, n_seq, S, n_head, head_dim,
-                                                      head_stride, scale);
+                                                      head_stride, scale, vec ? 1 : 0);
     return lime_check_launch("token_attn_bwd_kernel");
 }
 }  // namespace
@@ -756,6 +910,16 @@ extern "C" int lime_embed_bwd_f32(const int32_t* ids, const float* dx, int64_t l
     if (dim <= 320) embed_bwd_kernel<5><<<grid, 256, 0, s>>>(ids, dx, lddx, dtable, ld_table, rows, dim, hot_id, rpb);
     else embed_bwd_kernel<8><<<grid, 256, 0, s>>>(ids, dx, lddx, dtable, ld_table, rows, dim, hot_id, rpb);
     return lime_check_launch("embed_bwd_kernel");
+}
+
+extern "C" int lime_embed_bwd_small_f32(const int32_t* ids, const float* dx, int64_t lddx, float* dtable, int64_t ld_table,
+                                        int64_t rows, int32_t dim, int32_t table_rows, void* stream) {
+    LIME_REQUIRE(ids && dx && dtable, LIME_ERR_BAD_ARG, "lime_embed_bwd_small_f32: null pointer");
+    LIME_REQUIRE(rows >= 0 && dim > 0 && lddx >= dim && ld_table >= dim, LIME_ERR_BAD_ARG, "lime_embed_bwd_small_f32: bad dimensions");
+    LIME_REQUIRE(table_rows >= 1 && table_rows <= 32, LIME_ERR_UNSUPPORTED, "lime_embed_bwd_small_f32: table_rows = %d outside [1, 32]", table_rows);
+    if (rows == 0) return LIME_OK;
+    embed_bwd_small_kernel<<<(dim + 63) / 64, 256, 0, (hipStream_t)stream>>>(ids, dx, lddx, dtable, ld_table, rows, dim, table_rows);
+    return lime_check_launch("embed_bwd_small_kernel");
 }
 
 extern "C" int lime_grad_clip_coef_f32(const float* g, int64_t n, float max_norm, float* out2, float* workspace,

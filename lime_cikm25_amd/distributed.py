@@ -1,8 +1,10 @@
-"""One-process-per-GPU helpers for the scoring path.
+"""One-process-per-GPU helpers.
 
-Impression rows are independent, so ranks score disjoint row shards with no data-path collective; the only
+Scoring: impression rows are independent, so ranks score disjoint row shards with no data-path collective; the only
 collectives are the barrier / max-time reduction of the benchmark and an optional all_gather of the scores for
-metrics.  Backend: "nccl" (= RCCL over xGMI on ROCm) on GPUs, "gloo" in the CPU tests.
+metrics.  Training: the one exchange step of the path -- a single all-reduce of the flat gradient bucket per step
+(``allreduce_mean_``), between backward and clip_grad_norm_, which is what DistributedDataParallel does for the reference
+(trainer.py:250-255).  Backend: "nccl" (= RCCL over xGMI on ROCm) on GPUs, "gloo" in the CPU tests.
 """
 import os
 
@@ -51,3 +53,24 @@ def gather_scores(local_scores, n_rows):
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
     return torch.cat([b[:hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
+
+
+def allreduce_mean_(flat, group=None):
+    """In-place mean over ranks of a flat gradient bucket (one collective per training step; a no-op for one process)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return flat
+    world = dist.get_world_size(group)
+    if world == 1:
+        return flat
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat.mul_(1.0 / world)
+
+
+def sampler_rows(n_rows, rank, world, epoch_perm=None):
+    """Row indices of rank `rank` for one training epoch: rows rank, rank + world, ... of the (optionally permuted) order,
+    padded by wrapping around so every rank takes the same number of steps -- torch's DistributedSampler rule
+    (trainer.py:293-295)."""
+    order = list(range(n_rows)) if epoch_perm is None else list(epoch_perm)
+    per = (n_rows + world - 1) // world
+    order = [order[i % n_rows] for i in range(per * world)] if n_rows else []
+    return order[rank::world]

@@ -659,13 +659,17 @@ def token_attention_bwd(q, k, v, dout, n_seq, S, n_head, head_dim, scale, head_s
 
 
 def embed_bwd(ids, dx, dtable, hot_id=0):
-    """dtable[ids[r]] += dx[r]  (float atomics)."""
+    """dtable[ids[r]] += dx[r]  (float atomics; tables of <= 32 rows: atomic-free LDS accumulation)."""
     lib = _lib.load()
     _vec(ids, 'ids', dtype=torch.int32)
     _mat(dx, 'dx')
     _mat(dtable, 'dtable')
     if dx.shape[0] != ids.numel() or dx.shape[1] != dtable.shape[1]:
         raise ValueError('dx must be [len(ids), dim]')
+    if dtable.shape[0] <= 32:              # a handful of rows: per-column LDS accumulation instead of contended atomics
+        check(lib.lime_embed_bwd_small_f32(_p(ids), _p(dx), _ld(dx), _p(dtable), _ld(dtable), ids.numel(), dx.shape[1],
+                                           dtable.shape[0], _stream()), 'lime_embed_bwd_small_f32')
+        return dtable
     check(lib.lime_embed_bwd_f32(_p(ids), _p(dx), _ld(dx), _p(dtable), _ld(dtable), ids.numel(), dx.shape[1], hot_id, _stream()),
           'lime_embed_bwd_f32')
     return dtable

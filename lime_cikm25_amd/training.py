@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import distributed, ops
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -66,6 +66,37 @@ def linear(x, lin, act=None):
     shape = x.shape[:-1]
     y = _Linear.apply(x.reshape(-1, x.shape[-1]), lin.weight, lin.bias, act)
     return y.view(*shape, -1)
+
+
+class _GatherRows(torch.autograd.Function):
+    """table[idx] (nn.Embedding forward) on the gather kernel; backward = the scatter-add kernel."""
+
+    @staticmethod
+    def forward(ctx, idx, table):
+        out = torch.empty((idx.numel(), table.shape[1]), dtype=torch.float32, device=table.device)
+        ops.gather_rows(idx, table, out)
+        ctx.save_for_backward(idx)
+        ctx.shape = tuple(table.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        dtable = torch.zeros(ctx.shape, dtype=torch.float32, device=dy.device)
+        ops.embed_bwd(idx, dy.contiguous(), dtable, hot_id=-1)
+        return None, dtable
+
+
+def embedding(table, idx):
+    """table[idx] for an integer tensor idx of any shape -> [*idx.shape, dim]."""
+    flat = idx.reshape(-1)
+    flat = (flat if flat.dtype == torch.int32 else flat.to(torch.int32)).contiguous()
+    if table.requires_grad and torch.is_grad_enabled():
+        out = _GatherRows.apply(flat, table)
+    else:
+        out = torch.empty((flat.numel(), table.shape[1]), dtype=torch.float32, device=table.device)
+        ops.gather_rows(flat, table, out)
+    return out.view(*idx.shape, table.shape[1])
 
 
 def _unpad_heads(t, groups, hd, hs):
@@ -178,8 +209,8 @@ def crown_content(enc, title_text, content_text, category, subCategory):
     table = enc.word_embedding.weight
     title_p = encode_tokens(title_text, table, enc.title_pos_encoder, enc.title_transformer, enc.head_num)      # :311-317
     body_p = encode_tokens(content_text, table, enc.body_pos_encoder, enc.body_transformer, enc.head_num)       # :312-321
-    cat_e = enc.category_embedding.weight[category.long()]
-    sub_e = enc.subCategory_embedding.weight[subCategory.long()]
+    cat_e = embedding(enc.category_embedding.weight, category)
+    sub_e = embedding(enc.subCategory_embedding.weight, subCategory)
     cat_rep = linear(torch.cat([cat_e, sub_e], dim=1), enc.category_affine)                                     # :340-342
     w_int = torch.cat([lin.weight for lin in enc.intent_layers], dim=0)
     b_int = torch.cat([lin.bias for lin in enc.intent_layers], dim=0)
@@ -203,16 +234,17 @@ def lime_news(ne, title_text, content_text, category, subCategory, freshness, li
         raise NotImplementedError('the training path covers the CROWN content encoder (LIME-CROWN-CROWN)')
     content = crown_content(base, title_text, content_text, category, subCategory)
     fe = ne.freshness_encoder
-    fb = ops.bucketize(freshness).long()
-    lb = ops.bucketize(lifetime).long()
-    fresh = linear(torch.cat([fe.freshness_embedding.weight[fb], fe.lifetime_embedding.weight[lb]], dim=1), fe.dense, act='tanh')
+    fb = ops.bucketize(freshness)
+    lb = ops.bucketize(lifetime)
+    fresh = linear(torch.cat([embedding(fe.freshness_embedding.weight, fb), embedding(fe.lifetime_embedding.weight, lb)], dim=1),
+                   fe.dense, act='tanh')
     fused = torch.cat([content, fresh], dim=1)
     return fused if isinstance(ne.project, nn.Identity) else linear(fused, ne.project)
 
 
 def _topic(ne, category, subCategory):
     """userEncoders.py:103-105 / :115-117."""
-    x = torch.cat([ne.category_embedding.weight[category.long()], ne.subCategory_embedding.weight[subCategory.long()]], dim=-1)
+    x = torch.cat([embedding(ne.category_embedding.weight, category), embedding(ne.subCategory_embedding.weight, subCategory)], dim=-1)
     return linear(x, ne.category_affine)
 
 
@@ -341,9 +373,12 @@ class TrainStep:
             seen.add(id(p))
             named.append((name, p))
         self.names = [n for n, _ in named]
-        total = sum(p.numel() for _, p in named)
+        # every parameter starts on a 256-byte boundary of the bucket (the LDS-DMA GEMM wants 16-byte aligned operands);
+        # the padding stays zero in all four buffers
+        align = lambda n: (n + 63) // 64 * 64
+        total = sum(align(p.numel()) for _, p in named)
         dev = named[0][1].device
-        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -354,23 +389,15 @@ class TrainStep:
                 self.flat[off:off + n].copy_(p.detach().reshape(-1))
                 p.data = self.flat[off:off + n].view(p.shape)
                 p.grad = self.grad[off:off + n].view(p.shape)
-                off += n
+                off += align(n)
         self.step_count = 0
         self.last_norm = None
-
-    def world_size(self):
-        import torch.distributed as dist
-        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
     def backward_and_update(self, loss):
         """loss.backward() into the flat bucket, all-reduce, clip, Adam.  Returns the (device) gradient norm."""
         self.grad.zero_()
         loss.backward()
-        ws = self.world_size()
-        if ws > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.grad, group=self.group)
-            self.grad.mul_(1.0 / ws)
+        distributed.allreduce_mean_(self.grad, self.group)
         return self.update()
 
     def update(self):

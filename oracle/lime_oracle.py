@@ -249,12 +249,13 @@ def remaining_lifetime_weighting(cfg, user, news, remaining):
     return base * w
 
 
-def model_forward(sd, cfg, inputs, eval_shape=False, taps=None):
+def model_forward(sd, cfg, inputs, eval_shape=False, taps=None, grad=False):
     """Model.forward, model.py:151-187, for LIME-{CROWN,MHSA}-CROWN with the dot-product predictor.
 
     ``inputs``: the 26 tensors in signature order (dict or sequence).  ``eval_shape``: candidates
     arrive without the N axis and are unsqueezed (model.py:158-169).  Returns logits [B, N];
-    intermediates are appended to ``taps`` when given.
+    intermediates are appended to ``taps`` when given.  ``grad``: record torch's autograd graph (the checker of the
+    training step: gradients w.r.t. the ``sd`` tensors that require them).
     """
     v = list(inputs.values()) if isinstance(inputs, dict) else list(inputs)
     (user_ID, user_category, user_subCategory, user_title_text, user_title_mask, _ute, user_content_text, _ucm, _uce,
@@ -267,7 +268,7 @@ def model_forward(sd, cfg, inputs, eval_shape=False, taps=None):
              news_lifetime, remaining)]
     ne = 'news_encoder.'
     ue = 'user_encoder.'
-    with torch.no_grad():
+    with torch.set_grad_enabled(bool(grad)):
         cand = lime_news_encoder(sd, ne, cfg, news_title_text, news_title_mask, news_content_text, news_category,
                                  news_subCategory, news_freshness, news_lifetime, taps)              # model.py:171-173
         hist = lime_news_encoder(sd, ne, cfg, user_title_text, user_title_mask, user_content_text, user_category,

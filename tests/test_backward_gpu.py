@@ -134,6 +134,19 @@ def test_embed_bwd(ops):
     close(got, want, tol=2e-4, what='embedding gradient, no hot row')
 
 
+def test_embed_bwd_small_table(ops):
+    T, D, rows = 10, 500, 1760
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, 3, (rows,), generator=g, dtype=torch.int32)          # realistic inputs reach buckets {0, 1, 2} only
+    dx = rnd(rows, D, seed=6)
+    base = rnd(T, D, seed=7)
+    want = base.double().index_add_(0, ids.long(), dx.double()).float()
+    got = ops.embed_bwd(ids.cuda(), dx.cuda(), base.clone().cuda(), hot_id=-1)
+    close(got, want, tol=2e-4, what='small-table gradient')
+    again = ops.embed_bwd(ids.cuda(), dx.cuda(), base.clone().cuda(), hot_id=-1)
+    assert torch.equal(got, again), 'the small-table path has a fixed summation order'
+
+
 def test_nll_softmax(ops):
     logits = rnd(37, 5, seed=1, scale=4.0)
     x = logits.double().requires_grad_()
