@@ -313,10 +313,13 @@ int lime_gather_rows_multi(const int32_t* idx, int64_t n_rows, const lime_gather
 
 /* dW[n, k] (+)= sum_m dy[m, n] * x[m, k]: the weight gradient of y = x W^T (nn.Linear backward; loss.backward() at
  * trainer.py:145).  dy [M, N], x [M, K], dw [N, K]; exact-fp32 MFMA, M split over workgroups, partial tiles in
- * `workspace` (lime_linear_wgrad_workspace(M, N, K) floats), summed in split order.  accumulate != 0: dw += ... */
+ * `workspace` (lime_linear_wgrad_workspace(M, N, K) floats), summed in split order.  accumulate != 0: dw += ...
+ * db (optional, [N]) (+)= sum_m dy[m, n], the bias gradient: taken in the same pass as an extra all-ones column of x when
+ * the padded tile grid has room for one (K = 300 of the encoder layers does), else by a column-sum pass. */
 int64_t lime_linear_wgrad_workspace(int32_t M, int32_t N, int32_t K);
-int lime_linear_wgrad_f32(const float* dy, int64_t ldy, const float* x, int64_t ldx, float* dw, int64_t lddw, int32_t M,
-                          int32_t N, int32_t K, int32_t accumulate, float* workspace, int64_t workspace_floats, void* stream);
+int lime_linear_wgrad_f32(const float* dy, int64_t ldy, const float* x, int64_t ldx, float* dw, int64_t lddw, float* db,
+                          int32_t M, int32_t N, int32_t K, int32_t accumulate, float* workspace, int64_t workspace_floats,
+                          void* stream);
 
 /* out[n] (+)= sum_m x[m, n]: the bias gradient.  workspace: lime_colsum_workspace(M, N) floats. */
 int64_t lime_colsum_workspace(int32_t M, int32_t N);

@@ -105,8 +105,8 @@ SIGNATURES = {
     'lime_mean_pool_bf16': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     # training step
     'lime_linear_wgrad_workspace': (c_int64, [c_int32, c_int32, c_int32]),
-    'lime_linear_wgrad_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32,
-                                        c_void_p, c_int64, c_void_p]),
+    'lime_linear_wgrad_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_int32,
+                                        c_int32, c_void_p, c_int64, c_void_p]),
     'lime_colsum_workspace': (c_int64, [c_int32, c_int32]),
     'lime_colsum_f32': (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
     'lime_layernorm_bwd_workspace': (c_int64, [c_int32, c_int32]),

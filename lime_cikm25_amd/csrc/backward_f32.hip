@@ -16,6 +16,18 @@ namespace {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+// buffer addressing (as in gemm_f32.hip): wave-uniform base + 32-bit lane offset, an out-of-range offset reads as zero
+constexpr unsigned OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFF0, 0x00020000);
+}
+__device__ __forceinline__ f32x4v buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     // v_mfma_f32_16x16x4_f32: lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]; c[r] = C[4 (l >> 4) + r][l & 15]
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -65,10 +77,10 @@ constexpr int WG_TN = 128;
 constexpr int WG_MC = 64;
 constexpr int WG_THREADS = 512;
 
-template <int NKT>       // 16-column accumulator tiles per wave along K: TK = 64 * NKT
+template <int NKT, bool VEC>       // NKT: 16-column accumulator tiles per wave along K (TK = 64 NKT); VEC: 16-byte loads
 __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const float* __restrict__ dy, long ldy, const float* __restrict__ x,
                                                             long ldx, float* __restrict__ ws, int M, int N, int K, int n_tiles,
-                                                            int k_tiles, int rows_per_split) {
+                                                            int k_tiles, int rows_per_split, int ones_col) {
     constexpr int TK = 64 * NKT;
     constexpr int LDA = WG_TN + 16;          // pitch % 32 == 16: the two row groups of a half-wave hit disjoint banks
     constexpr int LDB = TK + 16;
@@ -94,38 +106,57 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < NKT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Loads are branch-free buffer loads: rows beyond the slice and columns beyond N / K carry the OOB offset and read zeros.
+    // Offsets are relative to the first row of the slice (the host checks that a slice spans < 2 GB).
     f32x4v ra[A4], rb[B4];
-    const bool vec_ok = ((ldy | ldx) & 3) == 0 && ((((uintptr_t)dy) | ((uintptr_t)x)) & 15) == 0;
-    auto load_chunk = [&](long m0) {
+    const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(dy + m_begin * ldy + n0);
+    const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(x + m_begin * ldx + k0);
+    const int rows_here = (int)(m_end - m_begin);
+    unsigned a_off[A4], b_off[B4];
+    int a_row[A4], b_row[B4];
+    bool a_cin[A4][VEC ? 1 : 4], b_cin[B4][VEC ? 1 : 4];
+    int b_one[B4];                                          // which element of this lane's X float4 is the ones column (-1: none)
+#pragma unroll
+    for (int j = 0; j < A4; ++j) {
+        const int f = tid + WG_THREADS * j, r = f / (WG_TN / 4), c = (f % (WG_TN / 4)) * 4;
+        a_row[j] = r;
+        a_off[j] = (unsigned)r * (unsigned)(ldy * 4) + (unsigned)c * 4u;
+        if constexpr (VEC) a_cin[j][0] = n0 + c < N;
+        else
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a_cin[j][e] = n0 + c + e < N;
+    }
+#pragma unroll
+    for (int j = 0; j < B4; ++j) {
+        const int f = tid + WG_THREADS * j, r = f / (TK / 4), c = (f % (TK / 4)) * 4;
+        const bool in_tile = f < WG_MC * TK / 4;
+        b_row[j] = in_tile ? r : (1 << 30);
+        b_off[j] = (unsigned)r * (unsigned)(ldx * 4) + (unsigned)c * 4u;
+        b_one[j] = (ones_col && K >= k0 + c && K < k0 + c + 4) ? K - (k0 + c) : -1;
+        if constexpr (VEC) b_cin[j][0] = k0 + c < K;
+        else
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b_cin[j][e] = k0 + c + e < K;
+    }
+    auto load_chunk = [&](int mrel) {                       // mrel: first row of the chunk relative to the slice
+        const int soff_a = mrel * (int)(ldy * 4), soff_b = mrel * (int)(ldx * 4);
 #pragma unroll
         for (int j = 0; j < A4; ++j) {
-            const int f = tid + WG_THREADS * j, r = f / (WG_TN / 4), c = (f % (WG_TN / 4)) * 4;
-            const long m = m0 + r;
-            f32x4v v = {0.f, 0.f, 0.f, 0.f};
-            if (m < m_end) {
-                const float* p = dy + m * ldy + n0 + c;
-                if (vec_ok && n0 + c + 3 < N) v = *reinterpret_cast<const f32x4v*>(p);
-                else {
+            const bool rin = mrel + a_row[j] < rows_here;
+            if constexpr (VEC) ra[j] = buf_load4(rs_a, rin && a_cin[j][0] ? a_off[j] : OOB, soff_a);
+            else
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (n0 + c + e < N) v[e] = p[e];
-                }
-            }
-            ra[j] = v;
+                for (int e = 0; e < 4; ++e) ra[j][e] = buf_load1(rs_a, rin && a_cin[j][e] ? a_off[j] + 4u * e : OOB, soff_a);
         }
 #pragma unroll
         for (int j = 0; j < B4; ++j) {
-            const int f = tid + WG_THREADS * j, r = f / (TK / 4), c = (f % (TK / 4)) * 4;
-            const long m = m0 + r;
-            f32x4v v = {0.f, 0.f, 0.f, 0.f};
-            if (f < WG_MC * TK / 4 && m < m_end) {
-                const float* p = x + m * ldx + k0 + c;
-                if (vec_ok && k0 + c + 3 < K) v = *reinterpret_cast<const f32x4v*>(p);
-                else {
+            const bool rin = mrel + b_row[j] < rows_here;
+            if constexpr (VEC) rb[j] = buf_load4(rs_b, rin && b_cin[j][0] ? b_off[j] : OOB, soff_b);
+            else
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (k0 + c + e < K) v[e] = p[e];
-                }
-            }
-            rb[j] = v;
+                for (int e = 0; e < 4; ++e) rb[j][e] = buf_load1(rs_b, rin && b_cin[j][e] ? b_off[j] + 4u * e : OOB, soff_b);
+            // column K of X reads as 1 on the valid rows: column K of dW then holds sum_m dY[m, n], the bias gradient
+            if (b_one[j] >= 0 && rin) rb[j][b_one[j]] = 1.0f;
         }
     };
     auto store_chunk = [&]() {
@@ -141,15 +172,15 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const float* __restri
         }
     };
 
-    if (m_begin < m_end) {
-        load_chunk(m_begin);
+    if (rows_here > 0) {
+        load_chunk(0);
         const float* as = &As[kg * LDA + wn + fi];
         const float* bs = &Bs[kg * LDB + wk + fi];
-        for (long m0 = m_begin; m0 < m_end; m0 += WG_MC) {
+        for (int m0 = 0; m0 < rows_here; m0 += WG_MC) {
             __syncthreads();                               // every wave is done reading the previous chunk
             store_chunk();
             __syncthreads();
-            if (m0 + WG_MC < m_end) load_chunk(m0 + WG_MC);
+            if (m0 + WG_MC < rows_here) load_chunk(m0 + WG_MC);
 #pragma unroll
             for (int s = 0; s < WG_MC / 4; ++s) {
                 float a[4], b[NKT];
@@ -615,11 +646,22 @@ __global__ __launch_bounds__(256) void embed_bwd_small_kernel(const int* __restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     for (int t = 0; t < 32; ++t) acc[wave][t][lane] = 0.f;
-    if (c < dim)
-        for (long r = wave; r < rows; r += 4) {
+    if (c < dim) {
+        long r = wave;
+        for (; r + 28 < rows; r += 32) {                    // eight rows in flight per wave
+            int id[8];
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { id[u] = ids[r + 4 * u]; v[u] = dx[(r + 4 * u) * lddx + c]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (id[u] >= 0 && id[u] < table_rows) acc[wave][id[u]][lane] += v[u];
+        }
+        for (; r < rows; r += 4) {
             const int id = ids[r];
             if (id >= 0 && id < table_rows) acc[wave][id][lane] += dx[r * lddx + c];
         }
+    }
     __syncthreads();
     if (c < dim)
         for (int t = wave; t < table_rows; t += 4)
@@ -717,7 +759,7 @@ WgradPlan wgrad_plan(int M, int N, int K) {
     w.np = (long)w.n_tiles * WG_TN;
     w.kp = (long)w.k_tiles * w.tk;
     const int ntile = w.n_tiles * w.k_tiles;
-    int splits = (256 + ntile - 1) / ntile;                       // one eight-wave workgroup per CU
+    int splits = 256 / ntile;                                     // one eight-wave workgroup per CU, a single round of them
     const int max_splits = (M + 511) / 512;                       // at least 8 chunks of 64 rows per workgroup
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -729,19 +771,19 @@ WgradPlan wgrad_plan(int M, int N, int K) {
     return w;
 }
 
-template <int NKT>
+template <int NKT, bool VEC>
 int launch_wgrad(const WgradPlan& w, const float* dy, long ldy, const float* x, long ldx, float* ws, int M, int N, int K,
-                 hipStream_t s) {
+                 int ones_col, hipStream_t s) {
     constexpr int BYTES = WG_MC * ((WG_TN + 16) + (64 * NKT + 16)) * 4;
     static bool configured = false;
     if (!configured) {
-        const hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+        const hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<NKT, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
         LIME_REQUIRE(e == hipSuccess, LIME_ERR_LAUNCH, "lime_linear_wgrad_f32: cannot reserve %d bytes of LDS: %s", BYTES,
                      hipGetErrorString(e));
         configured = true;
     }
     const int grid = w.n_tiles * w.k_tiles * w.splits;
-    wgrad_kernel<NKT><<<grid, WG_THREADS, BYTES, s>>>(dy, ldy, x, ldx, ws, M, N, K, w.n_tiles, w.k_tiles, w.rows_per_split);
+    wgrad_kernel<NKT, VEC><<<grid, WG_THREADS, BYTES, s>>>(dy, ldy, x, ldx, ws, M, N, K, w.n_tiles, w.k_tiles, w.rows_per_split, ones_col);
     return lime_check_launch("wgrad_kernel");
 }
 
@@ -762,28 +804,42 @@ int ln_blocks(int M) { const int b = (M + 15) / 16; return b > 768 ? 768 : b; } 
 
 }  // namespace
 
+extern "C" int lime_colsum_f32(const float* x, int64_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate,
+                               float* workspace, int64_t workspace_floats, void* stream);
+
 extern "C" int64_t lime_linear_wgrad_workspace(int32_t M, int32_t N, int32_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const WgradPlan w = wgrad_plan(M, N, K);
-    return (int64_t)w.splits * w.np * w.kp;
+    return (int64_t)w.splits * w.np * w.kp + (int64_t)colsum_blocks(M) * N;      // + the column-sum fallback of db
 }
 
 extern "C" int lime_linear_wgrad_f32(const float* dy, int64_t ldy, const float* x, int64_t ldx, float* dw, int64_t lddw,
-                                     int32_t M, int32_t N, int32_t K, int32_t accumulate, float* workspace,
+                                     float* db, int32_t M, int32_t N, int32_t K, int32_t accumulate, float* workspace,
                                      int64_t workspace_floats, void* stream) {
     LIME_REQUIRE(dy && x && dw && workspace, LIME_ERR_BAD_ARG, "lime_linear_wgrad_f32: null pointer");
     LIME_REQUIRE(M > 0 && N > 0 && K > 0, LIME_ERR_BAD_ARG, "lime_linear_wgrad_f32: non-positive dimension");
     LIME_REQUIRE(ldy >= N && ldx >= K && lddw >= K, LIME_ERR_BAD_ARG, "lime_linear_wgrad_f32: leading dimension smaller than the row");
     const WgradPlan w = wgrad_plan(M, N, K);
-    LIME_REQUIRE(workspace_floats >= (int64_t)w.splits * w.np * w.kp, LIME_ERR_BAD_ARG,
+    LIME_REQUIRE(workspace_floats >= lime_linear_wgrad_workspace(M, N, K), LIME_ERR_BAD_ARG,
                  "lime_linear_wgrad_f32: workspace holds %ld floats, lime_linear_wgrad_workspace() asks for %ld",
-                 (long)workspace_floats, (long)((int64_t)w.splits * w.np * w.kp));
+                 (long)workspace_floats, (long)lime_linear_wgrad_workspace(M, N, K));
     hipStream_t s = (hipStream_t)stream;
-    const int st = w.nkt == 5 ? launch_wgrad<5>(w, dy, ldy, x, ldx, workspace, M, N, K, s)
-                   : w.nkt == 3 ? launch_wgrad<3>(w, dy, ldy, x, ldx, workspace, M, N, K, s)
-                                : launch_wgrad<4>(w, dy, ldy, x, ldx, workspace, M, N, K, s);
+    LIME_REQUIRE(((long)w.rows_per_split + WG_MC) * (ldy > ldx ? ldy : ldx) * 4 < 0x7FFFFFF0L, LIME_ERR_UNSUPPORTED,
+                 "lime_linear_wgrad_f32: a row slice spans more than 2 GB (rows %d, ld %ld)", w.rows_per_split, (long)(ldy > ldx ? ldy : ldx));
+    const bool vec = N % 4 == 0 && K % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ((((uintptr_t)dy) | ((uintptr_t)x)) & 15) == 0;
+    int st;
+    const int ones_col = (db != nullptr && K < w.kp) ? 1 : 0;          // room for a ones column in the padded tile grid
+#define WGRAD(NKT) (vec ? launch_wgrad<NKT, true>(w, dy, ldy, x, ldx, workspace, M, N, K, ones_col, s) \
+                        : launch_wgrad<NKT, false>(w, dy, ldy, x, ldx, workspace, M, N, K, ones_col, s))
+    if (w.nkt == 5) st = WGRAD(5); else if (w.nkt == 3) st = WGRAD(3); else st = WGRAD(4);
+#undef WGRAD
     if (st != LIME_OK) return st;
-    return launch_reduce(workspace, w.np * w.kp, w.splits, w.kp, dw, lddw, N, K, accumulate, s);
+    st = launch_reduce(workspace, w.np * w.kp, w.splits, w.kp, dw, lddw, N, K, accumulate, s);
+    if (st != LIME_OK || db == nullptr) return st;
+    if (ones_col)                                                         // column K of the partial tiles
+        return launch_reduce(workspace + K, w.np * w.kp, w.splits, w.kp, db, 1, N, 1, accumulate, s);
+    float* cws = workspace + (int64_t)w.splits * w.np * w.kp;             // K fills its tiles: a separate column-sum pass
+    return lime_colsum_f32(dy, ldy, M, N, db, accumulate, cws, workspace_floats - (int64_t)w.splits * w.np * w.kp, stream);
 }
 
 extern "C" int64_t lime_colsum_workspace(int32_t M, int32_t N) {

@@ -558,8 +558,9 @@ def _workspace(device, floats):
     return ws
 
 
-def linear_wgrad(dy, x, out=None, accumulate=False):
-    """dW [N, K] (+)= dy^T x  (dy [M, N], x [M, K])."""
+def linear_wgrad(dy, x, out=None, accumulate=False, bias_out=None, want_bias=False):
+    """dW [N, K] (+)= dy^T x  (dy [M, N], x [M, K]); with ``want_bias`` / ``bias_out`` also db [N] (+)= column sums of dy,
+    returned as (dW, db)."""
     lib = _lib.load()
     _mat(dy, 'dy')
     _mat(x, 'x')
@@ -574,13 +575,23 @@ def linear_wgrad(dy, x, out=None, accumulate=False):
     _mat(out, 'out')
     if tuple(out.shape) != (N, K):
         raise ValueError('out must be [%d, %d]' % (N, K))
+    if bias_out is None and want_bias:
+        if accumulate:
+            raise ValueError('accumulate needs bias_out')
+        bias_out = torch.empty(N, dtype=torch.float32, device=dy.device)
+    if bias_out is not None:
+        _vec(bias_out, 'bias_out', N)
     if M == 0:
-        return out if accumulate else out.zero_()
-    need = lib.lime_linear_wgrad_workspace(M, N, K)
-    ws = _workspace(dy.device, need)
-    check(lib.lime_linear_wgrad_f32(_p(dy), _ld(dy), _p(x), _ld(x), _p(out), _ld(out), M, N, K, 1 if accumulate else 0, _p(ws),
-                                    ws.numel(), _stream()), 'lime_linear_wgrad_f32')
-    return out
+        if not accumulate:
+            out.zero_()
+            if bias_out is not None:
+                bias_out.zero_()
+    else:
+        need = lib.lime_linear_wgrad_workspace(M, N, K)
+        ws = _workspace(dy.device, need)
+        check(lib.lime_linear_wgrad_f32(_p(dy), _ld(dy), _p(x), _ld(x), _p(out), _ld(out), _p(bias_out), M, N, K,
+                                        1 if accumulate else 0, _p(ws), ws.numel(), _stream()), 'lime_linear_wgrad_f32')
+    return out if bias_out is None else (out, bias_out)
 
 
 def colsum(x, out=None, accumulate=False):

@@ -54,9 +54,12 @@ class _Linear(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = ops.linear(dy, w.t().contiguous(), None)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = ops.linear_wgrad(dy, x)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dw = ops.linear_wgrad(dy, x, want_bias=want_b)
+            if want_b:
+                dw, db = dw
+        elif want_b:
             db = ops.colsum(dy)
         return dx, dw, db, None
 
@@ -151,8 +154,7 @@ class _TokenEncoder(torch.autograd.Function):
         dh = ops.linear(dz2, l2_w.t().contiguous(), None)
         ops.relu_bwd_(dh, h)
         del h
-        dl1_w = ops.linear_wgrad(dh, x1)
-        dl1_b = ops.colsum(dh)
+        dl1_w, dl1_b = ops.linear_wgrad(dh, x1, want_bias=True)
         dx1 = ops.linear(dh, l1_w.t().contiguous(), None, res=dz2)             # through linear1 + the residual branch
         del dh, dz2
         dz1, dn1_w, dn1_b, dout_b = ops.layernorm_bwd(dx1, x1, n1_w, n1_b, rstd1)
@@ -164,8 +166,8 @@ class _TokenEncoder(torch.autograd.Function):
                                        head_stride=hs)
         del dao, qkv
         x0 = ops.embed_pe(flat, table, pe, S)                                   # the layer input, re-gathered
-        din_w = _unpad_heads(ops.linear_wgrad(dqkv, x0), 3 * nhead, hd, hs)
-        din_b = _unpad_heads(ops.colsum(dqkv), 3 * nhead, hd, hs)
+        din_w, din_b = ops.linear_wgrad(dqkv, x0, want_bias=True)
+        din_w, din_b = _unpad_heads(din_w, 3 * nhead, hd, hs), _unpad_heads(din_b, 3 * nhead, hd, hs)
         del x0
         dx0 = ops.linear(dqkv, w_in.t().contiguous(), None, res=dz1)            # through in_proj + the residual branch
         dtable = None

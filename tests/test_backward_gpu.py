@@ -42,15 +42,19 @@ def close(got, want, tol=TIGHT, what=''):
 def test_wgrad(ops, M, N, K):
     dy, x = rnd(M, N, seed=1), rnd(M, K, seed=2)
     want = (dy.double().t() @ x.double()).float()
-    got = ops.linear_wgrad(dy.cuda(), x.cuda())
+    got, got_b = ops.linear_wgrad(dy.cuda(), x.cuda(), want_bias=True)
     close(got, want, what='wgrad %s' % ((M, N, K),))
+    close(got_b, dy.double().sum(0).float(), what='bias gradient %s' % ((M, N, K),))
     # accumulate into an existing gradient, strided operands
     wide_dy, wide_x = rnd(M, N + 8, seed=3).cuda(), rnd(M, K + 4, seed=4).cuda()
     base = rnd(N, K, seed=5)
     out = base.clone().cuda()
-    ops.linear_wgrad(wide_dy[:, 4:N + 4], wide_x[:, :K], out=out, accumulate=True)
+    base_b = rnd(N, seed=6)
+    out_b = base_b.clone().cuda()
+    ops.linear_wgrad(wide_dy[:, 4:N + 4], wide_x[:, :K], out=out, accumulate=True, bias_out=out_b)
     want = base + (wide_dy[:, 4:N + 4].cpu().double().t() @ wide_x[:, :K].cpu().double()).float()
     close(out, want, what='wgrad accumulate')
+    close(out_b, base_b + wide_dy[:, 4:N + 4].cpu().double().sum(0).float(), what='bias accumulate')
 
 
 @pytest.mark.parametrize('M,N', [(1, 7), (1000, 300), (70000, 960)])
