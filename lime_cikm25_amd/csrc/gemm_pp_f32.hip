@@ -132,7 +132,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 // POOL: (LayerNorm epilogue) instead of the [M, N] result, row r of C is the mean of result rows 32 r .. 32 r + 31 -- a
 //      wave's 32 output rows -- so the mean pooling over the tokens of a news (newsEncoders.py:317,321) never sees the
 //      activations in HBM: S = 32 sequences are finished here, longer ones by a mean over their S / 32 block rows.
-template <int NTL, bool LN, bool RELU, int RES, bool BF, bool POOL = false>
+template <int NTL, bool LN, bool RELU, int RES, bool BF, bool POOL = false, bool RSTD = false>
 __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
     constexpr int ES = BF ? 2 : 4;                 // operand element size
     constexpr int EPS = 16 / ES;                   // elements per 16-byte segment
@@ -395,8 +395,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
                 s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
                 mean[tt] = s1 * inv_n;
                 rstd[tt] = rsqrtf(fmaxf(s2 * inv_n - mean[tt] * mean[tt], 0.f) + p.ln_eps);
-                const int r = row0 + 32 * wave + 16 * tt + fi;
-                if (p.ln_rstd != nullptr && kg == 0 && r < p.M) p.ln_rstd[r] = rstd[tt];
+
             }
         }
         unsigned cof[2];
@@ -404,6 +403,15 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
         for (int tt = 0; tt < 2; ++tt) {
             const int rl = 32 * wave + 16 * tt + fi;
             cof[tt] = (row0 + rl < p.M) ? (unsigned)rl * (unsigned)ldc4 + (unsigned)kg * (4u * ES) : OOB;
+        }
+        if constexpr (RSTD) {                          // the training forward keeps 1 / sqrt(var + eps) for lime_layernorm_bwd_f32
+            const __amdgpu_buffer_rsrc_t rs_r = make_rsrc(p.ln_rstd + row0);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int rl = 32 * wave + 16 * tt + fi;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rstd[tt]), rs_r,
+                                                      (kg == 0 && row0 + rl < p.M) ? (unsigned)rl * 4u : OOB, 0, 0);
+            }
         }
         const float* const gs = Gs + 4 * kg;
         const float* const es = Es + 4 * kg;
@@ -527,7 +535,7 @@ int num_cus() {
     return n;
 }
 
-template <int NTL, bool LN, bool RELU, int RES, bool BF = false, bool POOL = false>
+template <int NTL, bool LN, bool RELU, int RES, bool BF = false, bool POOL = false, bool RSTD = false>
 int launch(const PPParams& p0, hipStream_t stream) {
     PPParams p = p0;
     p.n_row_blocks = (p.M + BM - 1) / BM;
@@ -538,9 +546,9 @@ int launch(const PPParams& p0, hipStream_t stream) {
 #ifdef LIME_STAMPS
     p.stamps = g_pp_stamp_buf;
 #endif
-    hipLaunchKernelGGL((gemm_pp_kernel<NTL, LN, RELU, RES, BF, POOL>), dim3((unsigned)nwg), dim3(256), 0, stream, p);
-    lime_set_last_linear_kernel("gemm_pp_kernel<%d, %s, %s, %d, %s, %s>", NTL, LN ? "true" : "false", RELU ? "true" : "false", RES,
-                                BF ? "true" : "false", POOL ? "true" : "false");          // as rocprofv3 prints the instantiation
+    hipLaunchKernelGGL((gemm_pp_kernel<NTL, LN, RELU, RES, BF, POOL, RSTD>), dim3((unsigned)nwg), dim3(256), 0, stream, p);
+    lime_set_last_linear_kernel("gemm_pp_kernel<%d, %s, %s, %d, %s, %s, %s>", NTL, LN ? "true" : "false", RELU ? "true" : "false", RES,
+                                BF ? "true" : "false", POOL ? "true" : "false", RSTD ? "true" : "false");   // as rocprofv3 prints it
     return lime_check_launch("lime_linear_f32");
 }
 
@@ -586,6 +594,10 @@ int lime_linear_pp(const lime_linear_args* a, hipStream_t s) {
     p.n_row_blocks = p.n_col_blocks = 0;
     if (ln) {
         if (!tail_ok(320)) return LIME_PP_NOT_APPLICABLE;
+        if (a->ln_rstd) {                              // training forward: residual + LayerNorm, rstd kept
+            if (res == 0 || a->pool32) return LIME_PP_NOT_APPLICABLE;
+            return res == 1 ? launch<10, true, false, 1, false, false, true>(p, s) : launch<10, true, false, 2, false, false, true>(p, s);
+        }
         if (res == 0) return launch<10, true, false, 0>(p, s);
         if (res == 1) return a->pool32 ? launch<10, true, false, 1, false, true>(p, s) : launch<10, true, false, 1>(p, s);
         return launch<10, true, false, 2>(p, s);
