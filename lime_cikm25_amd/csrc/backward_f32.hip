@@ -380,119 +380,160 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ dh, l
 
 // ---------------------------------------------------------------------------------------------------
 // token attention backward (unmasked encoder-layer attention, newsEncoders.py:316,320).
-// A problem = one (sequence, head); a wave owns 32 query rows (and, for dK / dV, the 32 key rows of the same numbers);
-// a problem takes SP / 32 waves, a workgroup 128 / SP problems.  Everything goes through v_mfma_f32_16x16x4_f32:
+// A problem = one (sequence, head); a wave owns 16 query rows (and, for dK / dV, the 16 key rows of the same numbers);
+// a problem takes SP / 16 waves, an eight-wave workgroup 128 / SP problems.  Everything goes through
+// v_mfma_f32_16x16x4_f32:
 //   S = scale Q K^T -> P = softmax(S) (registers) -> LDS;   dP = dO V^T (registers);  delta = rowsum(P dP)
 //   dV = P^T dO;   dS = scale P (dP - delta) -> LDS over P;   dQ = dS K;   dK = dS^T Q
+// The grid is persistent (one workgroup per CU: the P / dS image leaves room for one): a workgroup walks its problems and
+// holds the NEXT problem's Q / K / V / dO rows in registers while it computes the current one, so the global latency of
+// the staging is off the critical path; two waves per SIMD cover each other's softmax and LDS phases.
 // ---------------------------------------------------------------------------------------------------
-constexpr int AB_LD = 34;        // Q / K / V / dO rows: 32 columns + 2 (row-indexed fragment reads are conflict-free)
+constexpr int AB_LD = 36;        // Q / K / V / dO rows: 32 columns + 4: 16-byte aligned rows for ds_read_b128 / ds_write_b128
+#ifndef LIME_ATTN_BWD_ABLATE
+#define LIME_ATTN_BWD_ABLATE 0   // tools/attn_bwd_ablate.py builds variants with phases removed (results garbage)
+#endif
 
 template <int SP>
-__global__ __launch_bounds__(256) void token_attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+__global__ __launch_bounds__(512) void token_attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                               const float* __restrict__ v, long ld, const float* __restrict__ dout,
                                                               long ldo, float* __restrict__ dq, float* __restrict__ dk,
                                                               float* __restrict__ dv, long ldd, int n_seq, int S, int n_head,
                                                               int head_dim, int head_stride, float scale, int vec) {
     constexpr int NT = SP / 16;                 // 16-column score tiles per row
-    constexpr int WPP = SP / 32;                // waves per problem
-    constexpr int PPW = 4 / WPP;                // problems per workgroup
+    constexpr int WPP = SP / 16;                // waves per problem
+    constexpr int PPW = 8 / WPP;                // problems per workgroup
+    constexpr int TPP = 64 * WPP;               // threads per problem
     constexpr int LDP = SP + 2;
     constexpr int PROB_FLOATS = 4 * SP * AB_LD + SP * LDP;
+    constexpr int NV4 = SP * 8 / TPP;           // float4 per thread and operand (Q, K, V): 2
+    constexpr int NV2 = SP * 16 / TPP;          // float2 per thread (dO): 4
     extern __shared__ float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 15, kg = lane >> 4;
     const int pw = wave / WPP;                  // problem slot of this wave
-    const int wr = wave % WPP;                  // which 32-row block of the problem
-    const long prob = (long)blockIdx.x * PPW + pw;
+    const int wr = wave % WPP;                  // which 16-row block of the problem
+    const int lt = tid - pw * TPP;              // thread index inside the problem
     const long n_prob = (long)n_seq * n_head;
-    const bool live = prob < n_prob;
-    const int seq = live ? (int)(prob / n_head) : 0, head = live ? (int)(prob % n_head) : 0;
     float* Qs = smem + pw * PROB_FLOATS;
     float* Ks = Qs + SP * AB_LD;
     float* Vs = Ks + SP * AB_LD;
     float* Os = Vs + SP * AB_LD;                // dO
     float* Ps = Os + SP * AB_LD;                // P, then dS
-    const int R0 = 32 * wr;
+    const int R0 = 16 * wr;
+    const f32x4v z4 = {0.f, 0.f, 0.f, 0.f};
 
-    // ---- stage Q, K, V, dO (zero beyond S rows / head_dim columns) ----------------------------------------------
-    {
-        const int lt = tid - pw * (64 * WPP);                           // thread index inside the problem
+    f32x4v rq[NV4], rk[NV4], rv[NV4];
+    f32x2 ro[NV2];
+    auto fetch = [&](long prob) {               // rows of problem `prob` -> registers (vec layout only)
+        const bool live = prob < n_prob;
+        const int seq = live ? (int)(prob / n_head) : 0, head = live ? (int)(prob % n_head) : 0;
         const long row_base = (long)seq * S;
-        if (vec) {              // head rows of 32 floats on 16-byte boundaries (padded heads: columns >= head_dim hold zeros)
-            for (int e = lt; e < SP * 8; e += 64 * WPP) {
-                const int r = e >> 3, c = (e & 7) * 4;
-                const bool ok = live && r < S;
-                const long g = (row_base + r) * ld + (long)head * head_stride + c;
-                const f32x4v z = {0.f, 0.f, 0.f, 0.f};
-                const f32x4v qv = ok ? *reinterpret_cast<const f32x4v*>(q + g) : z;
-                const f32x4v kv = ok ? *reinterpret_cast<const f32x4v*>(k + g) : z;
-                const f32x4v vv = ok ? *reinterpret_cast<const f32x4v*>(v + g) : z;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    Qs[r * AB_LD + c + j] = qv[j];
-                    Ks[r * AB_LD + c + j] = kv[j];
-                    Vs[r * AB_LD + c + j] = vv[j];
-                }
-            }
-            for (int e = lt; e < SP * 16; e += 64 * WPP) {              // dO rows: 8-byte aligned pairs
-                const int r = e >> 4, c = (e & 15) * 2;
-                const bool ok = live && r < S && c < head_dim;
-                f32x2 d = {0.f, 0.f};
-                if (ok) d = *reinterpret_cast<const f32x2*>(dout + (row_base + r) * ldo + (long)head * head_dim + c);
-                Os[r * AB_LD + c] = d[0];
-                Os[r * AB_LD + c + 1] = d[1];
-            }
-        } else {
-            for (int e = lt; e < SP * 32; e += 64 * WPP) {
-                const int r = e >> 5, c = e & 31;
-                const bool ok = live && r < S && c < head_dim;
-                const long g = (row_base + r) * ld + (long)head * head_stride + c;
-                Qs[r * AB_LD + c] = ok ? q[g] : 0.f;
-                Ks[r * AB_LD + c] = ok ? k[g] : 0.f;
-                Vs[r * AB_LD + c] = ok ? v[g] : 0.f;
-                Os[r * AB_LD + c] = ok ? dout[(row_base + r) * ldo + (long)head * head_dim + c] : 0.f;
-            }
+        for (int u = 0; u < NV4; ++u) {
+            const int e = lt + TPP * u, r = e >> 3, c = (e & 7) * 4;
+            const bool ok = live && r < S && !(LIME_ATTN_BWD_ABLATE & 1);
+            const long g = (row_base + (ok ? r : 0)) * ld + (long)head * head_stride + c;
+            rq[u] = ok ? *reinterpret_cast<const f32x4v*>(q + g) : z4;
+            rk[u] = ok ? *reinterpret_cast<const f32x4v*>(k + g) : z4;
+            rv[u] = ok ? *reinterpret_cast<const f32x4v*>(v + g) : z4;
         }
-    }
-    __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NV2; ++u) {
+            const int e = lt + TPP * u, r = e >> 4, c = (e & 15) * 2;
+            const bool ok = live && r < S && c < head_dim && !(LIME_ATTN_BWD_ABLATE & 1);
+            f32x2 d = {0.f, 0.f};
+            if (ok) d = *reinterpret_cast<const f32x2*>(dout + (row_base + r) * ldo + (long)head * head_dim + c);
+            ro[u] = d;
+        }
+    };
+    auto commit = [&]() {                       // registers -> this problem's LDS images
+#pragma unroll
+        for (int u = 0; u < NV4; ++u) {
+            const int e = lt + TPP * u, r = e >> 3, c = (e & 7) * 4;
+            *reinterpret_cast<f32x4v*>(&Qs[r * AB_LD + c]) = rq[u];
+            *reinterpret_cast<f32x4v*>(&Ks[r * AB_LD + c]) = rk[u];
+            *reinterpret_cast<f32x4v*>(&Vs[r * AB_LD + c]) = rv[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NV2; ++u) {
+            const int e = lt + TPP * u, r = e >> 4, c = (e & 15) * 2;
+            *reinterpret_cast<f32x2*>(&Os[r * AB_LD + c]) = ro[u];
+        }
+    };
+    auto stage_scalar = [&](long prob) {        // any layout: straight into LDS (zero beyond S rows / head_dim columns)
+        const bool live = prob < n_prob;
+        const int seq = live ? (int)(prob / n_head) : 0, head = live ? (int)(prob % n_head) : 0;
+        const long row_base = (long)seq * S;
+        for (int e = lt; e < SP * 32; e += TPP) {
+            const int r = e >> 5, c = e & 31;
+            const bool ok = live && r < S && c < head_dim;
+            const long g = (row_base + r) * ld + (long)head * head_stride + c;
+            Qs[r * AB_LD + c] = ok ? q[g] : 0.f;
+            Ks[r * AB_LD + c] = ok ? k[g] : 0.f;
+            Vs[r * AB_LD + c] = ok ? v[g] : 0.f;
+            Os[r * AB_LD + c] = ok ? dout[(row_base + r) * ldo + (long)head * head_dim + c] : 0.f;
+        }
+    };
 
-    // ---- S tiles and dP tiles of this wave's 32 query rows ------------------------------------------------------
-    f32x4 p[2][NT], dp[2][NT];
-    {
-        float qa[2][8], oa[2][8];
+    const long n_group = (n_prob + PPW - 1) / PPW;
+    if (vec && (long)blockIdx.x < n_group) fetch((long)blockIdx.x * PPW + pw);
+    for (long grp = blockIdx.x; grp < n_group; grp += gridDim.x) {
+        const long prob = grp * PPW + pw;
+        const bool live = prob < n_prob;
+        const int seq = live ? (int)(prob / n_head) : 0, head = live ? (int)(prob % n_head) : 0;
+        if (vec) commit(); else stage_scalar(prob);
+        __syncthreads();
+        if (vec && grp + gridDim.x < n_group) fetch((grp + gridDim.x) * PPW + pw);       // in flight during the compute below
+
+        // ---- S tiles and dP tiles of this wave's 16 query rows ------------------------------------------------------
+        f32x4 p[NT], dp[NT];
+        {
+            // the summation index d is only a label: lane group kg takes d = 8 kg .. 8 kg + 7 over the eight MFMA steps, so a
+            // lane's eight operands are 32 consecutive bytes of its row -- two ds_read_b128 instead of eight ds_read_b32
+            f32x4v qa[2], oa[2];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                qa[rt][s] = Qs[(R0 + 16 * rt + fi) * AB_LD + 4 * s + kg];
-                oa[rt][s] = Os[(R0 + 16 * rt + fi) * AB_LD + 4 * s + kg];
+            for (int h = 0; h < 2; ++h) {
+                qa[h] = *reinterpret_cast<const f32x4v*>(&Qs[(R0 + fi) * AB_LD + 8 * kg + 4 * h]);
+                oa[h] = *reinterpret_cast<const f32x4v*>(&Os[(R0 + fi) * AB_LD + 8 * kg + 4 * h]);
             }
+            // two score tiles at a time (four independent accumulator chains), the next pair's K / V fragments are requested
+            // before this pair's MFMAs are issued
+            f32x4v kb[2][2][2], vb[2][2][2];               // [buffer][tile of the pair][half]
+            auto load_pair = [&](int buf, int ct) {
 #pragma unroll
-        for (int ct = 0; ct < NT; ++ct) {
-            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const float kb = Ks[(16 * ct + fi) * AB_LD + 4 * s + kg];
-                const float vb = Vs[(16 * ct + fi) * AB_LD + 4 * s + kg];
-                s0 = mfma16(qa[0][s], kb, s0);
-                s1 = mfma16(qa[1][s], kb, s1);
-                d0 = mfma16(oa[0][s], vb, d0);
-                d1 = mfma16(oa[1][s], vb, d1);
+                    for (int h = 0; h < 2; ++h) {
+                        kb[buf][t][h] = *reinterpret_cast<const f32x4v*>(&Ks[(16 * (ct + t) + fi) * AB_LD + 8 * kg + 4 * h]);
+                        vb[buf][t][h] = *reinterpret_cast<const f32x4v*>(&Vs[(16 * (ct + t) + fi) * AB_LD + 8 * kg + 4 * h]);
+                    }
+            };
+            load_pair(0, 0);
+#pragma unroll
+            for (int ct = 0; ct < NT; ct += 2) {
+                const int buf = (ct >> 1) & 1;
+                if (ct + 2 < NT) load_pair(buf ^ 1, ct + 2);
+                f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, d0 = s0, s1 = s0, d1 = s0;
+#pragma unroll
+                for (int s = 0; s < ((LIME_ATTN_BWD_ABLATE & 2) ? 0 : 8); ++s) {
+                    s0 = mfma16(qa[s >> 2][s & 3], kb[buf][0][s >> 2][s & 3], s0);
+                    d0 = mfma16(oa[s >> 2][s & 3], vb[buf][0][s >> 2][s & 3], d0);
+                    s1 = mfma16(qa[s >> 2][s & 3], kb[buf][1][s >> 2][s & 3], s1);
+                    d1 = mfma16(oa[s >> 2][s & 3], vb[buf][1][s >> 2][s & 3], d1);
+                }
+                p[ct] = s0; dp[ct] = d0; p[ct + 1] = s1; dp[ct + 1] = d1;
             }
-            p[0][ct] = s0; p[1][ct] = s1; dp[0][ct] = d0; dp[1][ct] = d1;
         }
-    }
-    // softmax over the row (columns: tiles ct x the 16 lanes with the same kg), then delta and dS
+        // softmax over the row (columns: tiles ct x the 16 lanes with the same kg), then delta and dS
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < ((LIME_ATTN_BWD_ABLATE & 4) ? 0 : 4); ++r) {
             float mx = -INFINITY;
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
                 const bool col_ok = 16 * ct + fi < S;
-                const float sv = col_ok ? p[rt][ct][r] * scale : -INFINITY;
-                p[rt][ct][r] = sv;
+                const float sv = col_ok ? p[ct][r] * scale : -INFINITY;
+                p[ct][r] = sv;
                 mx = fmaxf(mx, sv);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
@@ -500,8 +541,8 @@ __global__ __launch_bounds__(256) void token_attn_bwd_kernel(const float* __rest
             float sum = 0.f;
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
-                const float e = expf(p[rt][ct][r] - mx);
-                p[rt][ct][r] = e;
+                const float e = expf(p[ct][r] - mx);
+                p[ct][r] = e;
                 sum += e;
             }
             sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
@@ -509,86 +550,66 @@ __global__ __launch_bounds__(256) void token_attn_bwd_kernel(const float* __rest
             float dl = 0.f;
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
-                p[rt][ct][r] *= inv;
-                dl += p[rt][ct][r] * dp[rt][ct][r];
+                p[ct][r] *= inv;
+                dl += p[ct][r] * dp[ct][r];
             }
             dl += __shfl_xor(dl, 1); dl += __shfl_xor(dl, 2); dl += __shfl_xor(dl, 4); dl += __shfl_xor(dl, 8);
 #pragma unroll
-            for (int ct = 0; ct < NT; ++ct) dp[rt][ct][r] = scale * p[rt][ct][r] * (dp[rt][ct][r] - dl);      // dS
+            for (int ct = 0; ct < NT; ++ct) dp[ct][r] = scale * p[ct][r] * (dp[ct][r] - dl);      // dS
         }
-    // P -> LDS
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+        // P -> LDS
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Ps[(R0 + 16 * rt + 4 * kg + r) * LDP + 16 * ct + fi] = p[rt][ct][r];
-    __syncthreads();
+            for (int r = 0; r < 4; ++r) Ps[(R0 + 4 * kg + r) * LDP + 16 * ct + fi] = p[ct][r];
+        __syncthreads();
 
-    const long out_row0 = (long)seq * S + R0;
-    auto store_tile = [&](float* dst, int jt, int dt, const f32x4& a) {
+        const long out_row0 = (long)seq * S + R0;
+        auto store_tile = [&](float* dst, int dt, const f32x4& a) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * jt + 4 * kg + r, col = 16 * dt + fi;
-            if (live && R0 + row < S && col < head_stride)
-                dst[(out_row0 + row) * ldd + (long)head * head_stride + col] = a[r];
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * kg + r, col = 16 * dt + fi;
+                if (live && R0 + row < S && col < head_stride && !((LIME_ATTN_BWD_ABLATE & 32) && a[r] != 12345.f))
+                    dst[(out_row0 + row) * ldd + (long)head * head_stride + col] = a[r];
+            }
+        };
+        // ---- dV[j, d] = sum_i P[i, j] dO[i, d] for the wave's key rows j ---------------------------------------------
+        {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll 8
+            for (int s = 0; s < ((LIME_ATTN_BWD_ABLATE & 8) ? 0 : SP / 4); ++s) {
+                const int i = 4 * s + kg;
+                const float a = Ps[i * LDP + R0 + fi];
+                a0 = mfma16(a, Os[i * AB_LD + fi], a0);
+                a1 = mfma16(a, Os[i * AB_LD + 16 + fi], a1);
+            }
+            store_tile(dv, 0, a0);
+            store_tile(dv, 1, a1);
         }
-    };
-    // ---- dV[j, d] = sum_i P[i, j] dO[i, d] for the wave's key rows j ---------------------------------------------
-    {
-        f32x4 a[2][2];
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) a[jt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int s = 0; s < SP / 4; ++s) {
-            const int i = 4 * s + kg;
-            const float a0 = Ps[i * LDP + R0 + fi], a1 = Ps[i * LDP + R0 + 16 + fi];
-            const float b0 = Os[i * AB_LD + fi], b1 = Os[i * AB_LD + 16 + fi];
-            a[0][0] = mfma16(a0, b0, a[0][0]); a[0][1] = mfma16(a0, b1, a[0][1]);
-            a[1][0] = mfma16(a1, b0, a[1][0]); a[1][1] = mfma16(a1, b1, a[1][1]);
-        }
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) store_tile(dv, jt, dt, a[jt][dt]);
-    }
-    __syncthreads();
-    // dS over P
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+        __syncthreads();
+        // dS over P
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Ps[(R0 + 16 * rt + 4 * kg + r) * LDP + 16 * ct + fi] = dp[rt][ct][r];
-    __syncthreads();
-    // ---- dQ[i, d] = sum_j dS[i, j] K[j, d];  dK[j, d] = sum_i dS[i, j] Q[i, d] -----------------------------------
-    {
-        f32x4 aq[2][2], ak[2][2];
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) aq[jt][dt] = ak[jt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int s = 0; s < SP / 4; ++s) {
-            const int j = 4 * s + kg;
-            const float q0 = Ps[(R0 + fi) * LDP + j], q1 = Ps[(R0 + 16 + fi) * LDP + j];     // dS[i, j]: rows of this wave
-            const float kb0 = Ks[j * AB_LD + fi], kb1 = Ks[j * AB_LD + 16 + fi];
-            aq[0][0] = mfma16(q0, kb0, aq[0][0]); aq[0][1] = mfma16(q0, kb1, aq[0][1]);
-            aq[1][0] = mfma16(q1, kb0, aq[1][0]); aq[1][1] = mfma16(q1, kb1, aq[1][1]);
-            const float t0 = Ps[j * LDP + R0 + fi], t1 = Ps[j * LDP + R0 + 16 + fi];         // dS[i = j-index here, key row]
-            const float qb0 = Qs[j * AB_LD + fi], qb1 = Qs[j * AB_LD + 16 + fi];
-            ak[0][0] = mfma16(t0, qb0, ak[0][0]); ak[0][1] = mfma16(t0, qb1, ak[0][1]);
-            ak[1][0] = mfma16(t1, qb0, ak[1][0]); ak[1][1] = mfma16(t1, qb1, ak[1][1]);
-        }
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                store_tile(dq, jt, dt, aq[jt][dt]);
-                store_tile(dk, jt, dt, ak[jt][dt]);
+            for (int r = 0; r < 4; ++r) Ps[(R0 + 4 * kg + r) * LDP + 16 * ct + fi] = dp[ct][r];
+        __syncthreads();
+        // ---- dQ[i, d] = sum_j dS[i, j] K[j, d];  dK[j, d] = sum_i dS[i, j] Q[i, d] -----------------------------------
+        {
+            f32x4 aq0 = {0.f, 0.f, 0.f, 0.f}, aq1 = aq0, ak0 = aq0, ak1 = aq0;
+#pragma unroll 8
+            for (int s = 0; s < ((LIME_ATTN_BWD_ABLATE & 16) ? 0 : SP / 4); ++s) {
+                const int j = 4 * s + kg;
+                const float ds_row = Ps[(R0 + fi) * LDP + j];          // dS[i = this wave's query row, j]
+                aq0 = mfma16(ds_row, Ks[j * AB_LD + fi], aq0);
+                aq1 = mfma16(ds_row, Ks[j * AB_LD + 16 + fi], aq1);
+                const float ds_col = Ps[j * LDP + R0 + fi];            // dS[i = j, this wave's key row]
+                ak0 = mfma16(ds_col, Qs[j * AB_LD + fi], ak0);
+                ak1 = mfma16(ds_col, Qs[j * AB_LD + 16 + fi], ak1);
             }
+            store_tile(dq, 0, aq0); store_tile(dq, 1, aq1);
+            store_tile(dk, 0, ak0); store_tile(dk, 1, ak1);
+        }
+        __syncthreads();                        // the images are free for the next problem
     }
 }
 
@@ -916,21 +937,25 @@ template <int SP>
 int launch_attn_bwd(const float* q, const float* k, const float* v, long ld, const float* dout, long ldo, float* dq, float* dk,
                     float* dv, long ldd, int n_seq, int S, int n_head, int head_dim, int head_stride, float scale,
                     hipStream_t s) {
-    constexpr int PPW = 4 / (SP / 32);
+    constexpr int PPW = 8 / (SP / 16);
     constexpr int BYTES = PPW * (4 * SP * AB_LD + SP * (SP + 2)) * 4;
     static bool configured = false;
+    static int n_cu = 256;
     if (!configured) {
         const hipError_t e = hipFuncSetAttribute((const void*)token_attn_bwd_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
         LIME_REQUIRE(e == hipSuccess, LIME_ERR_LAUNCH, "lime_token_attention_bwd_f32: cannot reserve %d bytes of LDS: %s", BYTES,
                      hipGetErrorString(e));
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            n_cu = cus;
         configured = true;
     }
-    const long n_prob = (long)n_seq * n_head;
-    const int grid = (int)((n_prob + PPW - 1) / PPW);
+    const long n_group = ((long)n_seq * n_head + PPW - 1) / PPW;
+    const int grid = (int)(n_group < n_cu ? n_group : n_cu);             // persistent: one workgroup per CU
     // vector staging: 32-float head rows on 16-byte boundaries with zero padding columns, dO pairs on 8-byte boundaries
     const bool vec = head_stride == 32 && ld % 4 == 0 && ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) == 0 &&
                      head_dim % 2 == 0 && ldo % 2 == 0 && (((uintptr_t)dout) & 7) == 0;
-    token_attn_bwd_kernel<SP><<<grid, 256, BYTES, s>>>(q, k, v, ld, dout, ldo, dq, dk, dv, ldd, n_seq, S, n_head, head_dim,
+    token_attn_bwd_kernel<SP><<<grid, 512, BYTES, s>>>(q, k, v, ld, dout, ldo, dq, dk, dv, ldd, n_seq, S, n_head, head_dim,
                                                       head_stride, scale, vec ? 1 : 0);
     return lime_check_launch("token_attn_bwd_kernel");
 }
