@@ -50,6 +50,10 @@ WORKLOADS = {
     # one training step = forward + backward + gradient all-reduce (N > 1) + clip_grad_norm_ + Adam
     'train2b': (dict(), 32, 5, 'training step (forward + backward + gradient all-reduce + clip + Adam), LIME-CROWN-CROWN, '
                                'batch=32 per GPU, history=50, title 32 + body 128, K=1+4, fp32, dropout off'),
+    'train4': (dict(max_abstract_length=512, batch_size=256), 32, 5,
+               'training step at the BASELINE.json configs[3] shape per GPU (Adressa-shape: batch=32 per GPU, history=50, '
+               'title 32 + body 512, K=1+4, config.batch_size=256), forward + backward + gradient all-reduce + clip + Adam, fp32, '
+               'dropout off'),
     'cfg5': (dict(batch_size=1024), 1024, 100,
              'MIND-shape inference, 1024 impressions x K=100 candidates, history=50, title 32 + body 128, scoring only, '
              'eval-mode (per-candidate) semantics with every history encoded once (BASELINE.json configs[4]), fp32'),

@@ -345,10 +345,15 @@ int lime_relu_bwd_f32(float* dh, int64_t lddh, const float* h, int64_t ldh, int6
 /* Backward of lime_token_attention_f32 without a key mask (the encoder layers): given q / k / v as the forward read them
  * and dout [tokens, n_head * head_dim] (packed), writes dq / dk / dv in the layout of q / k / v (row stride ld_dqkv, head
  * h at column h * head_stride; columns head_dim .. head_stride - 1 come out as zeros).  The probabilities are recomputed.
- * S <= 128, head_dim <= head_stride <= 32. */
-int lime_token_attention_bwd_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* dout, int64_t ldo,
-                                 float* dq, float* dk, float* dv, int64_t ld_dqkv, int32_t n_seq, int32_t S, int32_t n_head,
-                                 int32_t head_dim, int32_t head_stride, float scale, void* stream);
+ * S <= 512, head_dim <= head_stride <= 32.  S <= 128: one pass per (sequence, head); `out` and `workspace` may be NULL.
+ * 128 < S <= 512 (the 512-token bodies of BASELINE config 4): 128 x 128 blocks; needs the forward output `out` (packed like
+ * dout) and lime_token_attention_bwd_workspace(n_seq, S, n_head) floats; the key blocks' shares of dq are added with float
+ * atomics. */
+int64_t lime_token_attention_bwd_workspace(int32_t n_seq, int32_t S, int32_t n_head);
+int lime_token_attention_bwd_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out, int64_t ld_out,
+                                 const float* dout, int64_t ldo, float* dq, float* dk, float* dv, int64_t ld_dqkv, int32_t n_seq,
+                                 int32_t S, int32_t n_head, int32_t head_dim, int32_t head_stride, float scale, float* workspace,
+                                 int64_t workspace_floats, void* stream);
 
 /* dtable[ids[r], :] += dx[r, :] (nn.Embedding backward, newsEncoders.py:311-312).  dtable must be initialised by the
  * caller (zeros, or a gradient to add to).  Rows with ids[r] == hot_id (the padding word, pass -1 for none) are summed

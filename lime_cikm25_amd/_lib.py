@@ -114,8 +114,10 @@ SIGNATURES = {
                                          c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
                                          c_int64, c_void_p]),
     'lime_relu_bwd_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p]),
-    'lime_token_attention_bwd_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
-                                               c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    'lime_token_attention_bwd_workspace': (c_int64, [c_int32, c_int32, c_int32]),
+    'lime_token_attention_bwd_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                               c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_float,
+                                               c_void_p, c_int64, c_void_p]),
     'lime_embed_bwd_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p]),
     'lime_embed_bwd_small_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p]),
     'lime_grad_clip_coef_f32': (c_int32, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int64, c_void_p]),

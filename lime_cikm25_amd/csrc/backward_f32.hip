@@ -614,6 +614,219 @@ __global__ __launch_bounds__(512) void token_attn_bwd_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Sequences longer than 128 tokens (BASELINE config 4: body length 512): the same mathematics in 128 x 128 blocks.
+//   attn_stats_kernel      per query row: lse = log sum_j exp(scale q.k_j) over ALL keys, delta = dO . O (O: the forward output)
+//   attn_bwd_long_kernel   one workgroup per (sequence, head, key block): P = exp(scale S - lse) needs no row reduction any
+//                          more; dK / dV of the block accumulate in registers over the query blocks, the dQ contributions of
+//                          the key blocks are added with float atomics (dq is zeroed first)
+// Eight waves, 16 rows each, as in token_attn_bwd_kernel.
+// ---------------------------------------------------------------------------------------------------
+constexpr int LB = 128;          // block edge
+
+__device__ __forceinline__ void stage_rows(float* dst, const float* src, long ld, long row0, int rows_valid, int col0, int cols_valid,
+                                           int tid) {
+    // dst[r][c] (pitch AB_LD), r < 128, c < 32  <-  src[(row0 + r) * ld + col0 + c], zero outside the valid rows / columns
+    for (int e = tid; e < LB * 32; e += 512) {
+        const int r = e >> 5, c = e & 31;
+        dst[r * AB_LD + c] = (r < rows_valid && c < cols_valid) ? src[(row0 + r) * ld + col0 + c] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(512) void attn_stats_kernel(const float* __restrict__ q, const float* __restrict__ k, long ld,
+                                                          const float* __restrict__ out, long ldout, const float* __restrict__ dout,
+                                                          long ldo, float* __restrict__ stats, int S, int n_head, int head_dim,
+                                                          int head_stride, float scale, int n_blk) {
+    __shared__ float Qs[LB * AB_LD];
+    __shared__ float Ks[LB * AB_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, kg = lane >> 4;
+    const int qb = blockIdx.x % n_blk;
+    const long prob = blockIdx.x / n_blk;
+    const int seq = (int)(prob / n_head), head = (int)(prob % n_head);
+    const long row_base = (long)seq * S;
+    const int q0 = qb * LB, q_valid = min(LB, S - q0);
+    stage_rows(Qs, q, ld, row_base + q0, q_valid, head * head_stride, head_dim, tid);
+    __syncthreads();
+    const int R0 = 16 * wave;
+    f32x4v qa[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) qa[h] = *reinterpret_cast<const f32x4v*>(&Qs[(R0 + fi) * AB_LD + 8 * kg + 4 * h]);
+    float m[4], l[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
+    for (int kb = 0; kb < n_blk; ++kb) {
+        const int k0 = kb * LB, k_valid = min(LB, S - k0);
+        __syncthreads();
+        stage_rows(Ks, k, ld, row_base + k0, k_valid, head * head_stride, head_dim, tid);
+        __syncthreads();
+        f32x4 sc[LB / 16];
+#pragma unroll
+        for (int ct = 0; ct < LB / 16; ++ct) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            f32x4v kf[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) kf[h] = *reinterpret_cast<const f32x4v*>(&Ks[(16 * ct + fi) * AB_LD + 8 * kg + 4 * h]);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) a = mfma16(qa[t >> 2][t & 3], kf[t >> 2][t & 3], a);
+            sc[ct] = a;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int ct = 0; ct < LB / 16; ++ct) {
+                const float sv = (16 * ct + fi < k_valid) ? sc[ct][r] * scale : -INFINITY;
+                sc[ct][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
+            mx = fmaxf(mx, __shfl_xor(mx, 4)); mx = fmaxf(mx, __shfl_xor(mx, 8));
+            const float mn = fmaxf(m[r], mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < LB / 16; ++ct) sum += expf(sc[ct][r] - mn);
+            sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
+            l[r] = l[r] * expf(m[r] - mn) + sum;
+            m[r] = mn;
+        }
+    }
+    // lse of this wave's rows 4 kg + r (the 16 lanes of a kg group hold the same value), delta by one thread per row
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = R0 + 4 * kg + r;
+        if (fi == 0 && row < q_valid) stats[((row_base + q0 + row) * n_head + head) * 2] = m[r] + logf(l[r]);
+    }
+    if (tid < q_valid) {
+        const float* po = out + (row_base + q0 + tid) * ldout + (long)head * head_dim;
+        const float* pd = dout + (row_base + q0 + tid) * ldo + (long)head * head_dim;
+        float d = 0.f;
+        for (int c = 0; c < head_dim; ++c) d += po[c] * pd[c];
+        stats[((row_base + q0 + tid) * n_head + head) * 2 + 1] = d;
+    }
+}
+
+__global__ __launch_bounds__(512) void attn_bwd_long_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                             const float* __restrict__ v, long ld, const float* __restrict__ dout,
+                                                             long ldo, const float* __restrict__ stats, float* __restrict__ dq,
+                                                             float* __restrict__ dk, float* __restrict__ dv, long ldd, int S,
+                                                             int n_head, int head_dim, int head_stride, float scale, int n_blk) {
+    constexpr int NT = LB / 16, LDP = LB + 2;
+    extern __shared__ float smem[];
+    float* Qs = smem;
+    float* Ks = Qs + LB * AB_LD;
+    float* Vs = Ks + LB * AB_LD;
+    float* Os = Vs + LB * AB_LD;
+    float* Ps = Os + LB * AB_LD;
+    float* Ls = Ps + LB * LDP;                  // lse of the query block
+    float* Ds = Ls + LB;                        // delta of the query block
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, kg = lane >> 4;
+    const int kb = blockIdx.x % n_blk;
+    const long prob = blockIdx.x / n_blk;
+    const int seq = (int)(prob / n_head), head = (int)(prob % n_head);
+    const long row_base = (long)seq * S;
+    const int k0 = kb * LB, k_valid = min(LB, S - k0);
+    const int R0 = 16 * wave;
+    stage_rows(Ks, k, ld, row_base + k0, k_valid, head * head_stride, head_dim, tid);
+    stage_rows(Vs, v, ld, row_base + k0, k_valid, head * head_stride, head_dim, tid);
+    f32x4 av0 = {0.f, 0.f, 0.f, 0.f}, av1 = av0, ak0 = av0, ak1 = av0;
+    for (int qb = 0; qb < n_blk; ++qb) {
+        const int q0 = qb * LB, q_valid = min(LB, S - q0);
+        __syncthreads();                        // the previous block's images are no longer read
+        stage_rows(Qs, q, ld, row_base + q0, q_valid, head * head_stride, head_dim, tid);
+        stage_rows(Os, dout, ldo, row_base + q0, q_valid, head * head_dim, head_dim, tid);
+        if (tid < LB) {
+            const bool ok = tid < q_valid;
+            const float* st = stats + ((row_base + q0 + (ok ? tid : 0)) * n_head + head) * 2;
+            Ls[tid] = ok ? st[0] : INFINITY;    // exp(x - inf) = 0: rows beyond S contribute nothing
+            Ds[tid] = ok ? st[1] : 0.f;
+        }
+        __syncthreads();
+        f32x4 p[NT], dp[NT];
+        {
+            f32x4v qa[2], oa[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                qa[h] = *reinterpret_cast<const f32x4v*>(&Qs[(R0 + fi) * AB_LD + 8 * kg + 4 * h]);
+                oa[h] = *reinterpret_cast<const f32x4v*>(&Os[(R0 + fi) * AB_LD + 8 * kg + 4 * h]);
+            }
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, d0 = s0;
+                f32x4v kf[2], vf[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    kf[h] = *reinterpret_cast<const f32x4v*>(&Ks[(16 * ct + fi) * AB_LD + 8 * kg + 4 * h]);
+                    vf[h] = *reinterpret_cast<const f32x4v*>(&Vs[(16 * ct + fi) * AB_LD + 8 * kg + 4 * h]);
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    s0 = mfma16(qa[t >> 2][t & 3], kf[t >> 2][t & 3], s0);
+                    d0 = mfma16(oa[t >> 2][t & 3], vf[t >> 2][t & 3], d0);
+                }
+                p[ct] = s0; dp[ct] = d0;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float lse = Ls[R0 + 4 * kg + r], dl = Ds[R0 + 4 * kg + r];
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                const float pv = (16 * ct + fi < k_valid) ? expf(p[ct][r] * scale - lse) : 0.f;
+                p[ct][r] = pv;
+                dp[ct][r] = scale * pv * (dp[ct][r] - dl);
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ps[(R0 + 4 * kg + r) * LDP + 16 * ct + fi] = p[ct][r];
+        __syncthreads();
+#pragma unroll 8
+        for (int t = 0; t < LB / 4; ++t) {      // dV[j, d] += sum_i P[i, j] dO[i, d]
+            const int i = 4 * t + kg;
+            const float a = Ps[i * LDP + R0 + fi];
+            av0 = mfma16(a, Os[i * AB_LD + fi], av0);
+            av1 = mfma16(a, Os[i * AB_LD + 16 + fi], av1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ps[(R0 + 4 * kg + r) * LDP + 16 * ct + fi] = dp[ct][r];
+        __syncthreads();
+        f32x4 aq0 = {0.f, 0.f, 0.f, 0.f}, aq1 = aq0;
+#pragma unroll 8
+        for (int t = 0; t < LB / 4; ++t) {
+            const int j = 4 * t + kg;
+            const float ds_row = Ps[(R0 + fi) * LDP + j];
+            aq0 = mfma16(ds_row, Ks[j * AB_LD + fi], aq0);
+            aq1 = mfma16(ds_row, Ks[j * AB_LD + 16 + fi], aq1);
+            const float ds_col = Ps[j * LDP + R0 + fi];
+            ak0 = mfma16(ds_col, Qs[j * AB_LD + fi], ak0);
+            ak1 = mfma16(ds_col, Qs[j * AB_LD + 16 + fi], ak1);
+        }
+        // this key block's share of dQ
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = R0 + 4 * kg + r;
+            if (row < q_valid) {
+                float* d = dq + (row_base + q0 + row) * ldd + (long)head * head_stride;
+                if (fi < head_stride) unsafeAtomicAdd(d + fi, aq0[r]);
+                if (16 + fi < head_stride) unsafeAtomicAdd(d + 16 + fi, aq1[r]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = R0 + 4 * kg + r;
+        if (row < k_valid) {
+            const long o = (row_base + k0 + row) * ldd + (long)head * head_stride;
+            if (fi < head_stride) { dv[o + fi] = av0[r]; dk[o + fi] = ak0[r]; }
+            if (16 + fi < head_stride) { dv[o + 16 + fi] = av1[r]; dk[o + 16 + fi] = ak1[r]; }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // word-table gradient: dTable[ids[r], :] += dX[r, :].  A workgroup walks 512 consecutive rows, one wave per row; rows
 // whose id is `hot_id` (the padding word, a large share of all tokens) are summed in registers and added once per wave.
 // ---------------------------------------------------------------------------------------------------
@@ -961,14 +1174,19 @@ int launch_attn_bwd(const float* q, const float* k, const float* v, long ld, con
 }
 }  // namespace
 
-extern "C" int lime_token_attention_bwd_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* dout,
-                                            int64_t ldo, float* dq, float* dk, float* dv, int64_t ld_dqkv, int32_t n_seq,
-                                            int32_t S, int32_t n_head, int32_t head_dim, int32_t head_stride, float scale,
+extern "C" int64_t lime_token_attention_bwd_workspace(int32_t n_seq, int32_t S, int32_t n_head) {
+    return S > 128 ? (int64_t)n_seq * S * n_head * 2 : 0;            // lse and delta per (token, head) for the blocked path
+}
+
+extern "C" int lime_token_attention_bwd_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out,
+                                            int64_t ld_out, const float* dout, int64_t ldo, float* dq, float* dk, float* dv,
+                                            int64_t ld_dqkv, int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim,
+                                            int32_t head_stride, float scale, float* workspace, int64_t workspace_floats,
                                             void* stream) {
     LIME_REQUIRE(q && k && v && dout && dq && dk && dv, LIME_ERR_BAD_ARG, "lime_token_attention_bwd_f32: null pointer");
     LIME_REQUIRE(n_seq >= 0 && S > 0 && n_head > 0 && head_dim > 0, LIME_ERR_BAD_ARG, "lime_token_attention_bwd_f32: bad dimensions");
-    LIME_REQUIRE(S <= 128 && head_dim <= 32 && head_stride >= head_dim && head_stride <= 32, LIME_ERR_UNSUPPORTED,
-                 "lime_token_attention_bwd_f32: needs S <= 128 and head_dim <= head_stride <= 32 (S=%d head_dim=%d head_stride=%d)",
+    LIME_REQUIRE(S <= 512 && head_dim <= 32 && head_stride >= head_dim && head_stride <= 32, LIME_ERR_UNSUPPORTED,
+                 "lime_token_attention_bwd_f32: needs S <= 512 and head_dim <= head_stride <= 32 (S=%d head_dim=%d head_stride=%d)",
                  S, head_dim, head_stride);
     LIME_REQUIRE(ld_qkv >= (int64_t)n_head * head_stride && ld_dqkv >= (int64_t)n_head * head_stride && ldo >= (int64_t)n_head * head_dim,
                  LIME_ERR_BAD_ARG, "lime_token_attention_bwd_f32: leading dimension smaller than the row");
@@ -976,7 +1194,32 @@ extern "C" int lime_token_attention_bwd_f32(const float* q, const float* k, cons
     hipStream_t s = (hipStream_t)stream;
     if (S <= 32) return launch_attn_bwd<32>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, s);
     if (S <= 64) return launch_attn_bwd<64>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, s);
-    return launch_attn_bwd<128>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, s);
+    if (S <= 128) return launch_attn_bwd<128>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, s);
+    // blocked path
+    LIME_REQUIRE(out && ld_out >= (int64_t)n_head * head_dim, LIME_ERR_BAD_ARG,
+                 "lime_token_attention_bwd_f32: S > 128 needs the forward output `out` (delta = dO . O)");
+    LIME_REQUIRE(workspace && workspace_floats >= lime_token_attention_bwd_workspace(n_seq, S, n_head), LIME_ERR_BAD_ARG,
+                 "lime_token_attention_bwd_f32: S > 128 needs lime_token_attention_bwd_workspace() floats of workspace");
+    const int n_blk = (S + LB - 1) / LB;
+    const long n_prob = (long)n_seq * n_head;
+    LIME_REQUIRE(n_prob * n_blk < 0x7FFFFFFFL, LIME_ERR_UNSUPPORTED, "lime_token_attention_bwd_f32: too many blocks");
+    hipError_t e = hipMemset2DAsync(dq, (size_t)ld_dqkv * 4, 0, (size_t)n_head * head_stride * 4, (size_t)n_seq * S, s);
+    LIME_REQUIRE(e == hipSuccess, LIME_ERR_LAUNCH, "lime_token_attention_bwd_f32: clearing dq failed: %s", hipGetErrorString(e));
+    attn_stats_kernel<<<(unsigned)(n_prob * n_blk), 512, 0, s>>>(q, k, ld_qkv, out, ld_out, dout, ldo, workspace, S, n_head, head_dim,
+                                                              head_stride, scale, n_blk);
+    int st = lime_check_launch("attn_stats_kernel");
+    if (st != LIME_OK) return st;
+    constexpr int BYTES = (4 * LB * AB_LD + LB * (LB + 2) + 2 * LB) * 4;
+    static bool configured = false;
+    if (!configured) {
+        e = hipFuncSetAttribute((const void*)attn_bwd_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+        LIME_REQUIRE(e == hipSuccess, LIME_ERR_LAUNCH, "lime_token_attention_bwd_f32: cannot reserve %d bytes of LDS: %s", BYTES,
+                     hipGetErrorString(e));
+        configured = true;
+    }
+    attn_bwd_long_kernel<<<(unsigned)(n_prob * n_blk), 512, BYTES, s>>>(q, k, v, ld_qkv, dout, ldo, workspace, dq, dk, dv, ld_dqkv, S,
+                                                                       n_head, head_dim, head_stride, scale, n_blk);
+    return lime_check_launch("attn_bwd_long_kernel");
 }
 
 extern "C" int lime_embed_bwd_f32(const int32_t* ids, const float* dx, int64_t lddx, float* dtable, int64_t ld_table, int64_t rows,

@@ -645,9 +645,9 @@ def relu_bwd_(dh, h):
     return dh
 
 
-def token_attention_bwd(q, k, v, dout, n_seq, S, n_head, head_dim, scale, head_stride=None, dqkv=None):
+def token_attention_bwd(q, k, v, dout, n_seq, S, n_head, head_dim, scale, head_stride=None, dqkv=None, out=None):
     """Backward of the unmasked ``token_attention``: q / k / v column views of one packed qkv buffer [tokens, 3 * n_head *
-    head_stride]; returns dqkv in the same layout."""
+    head_stride]; returns dqkv in the same layout.  ``out``: the forward's result (needed for S > 128)."""
     lib = _lib.load()
     hs = head_dim if head_stride is None else head_stride
     W = n_head * hs
@@ -664,8 +664,17 @@ def token_attention_bwd(q, k, v, dout, n_seq, S, n_head, head_dim, scale, head_s
         dqkv = torch.empty((n_seq * S, 3 * W), dtype=torch.float32, device=q.device)
     _mat(dqkv, 'dqkv')
     dq, dk, dv = dqkv[:, :W], dqkv[:, W:2 * W], dqkv[:, 2 * W:]
-    check(lib.lime_token_attention_bwd_f32(_p(q), _p(k), _p(v), _ld(q), _p(dout), _ld(dout), _p(dq), _p(dk), _p(dv), _ld(dqkv),
-                                           n_seq, S, n_head, head_dim, hs, scale, _stream()), 'lime_token_attention_bwd_f32')
+    ws, need = None, lib.lime_token_attention_bwd_workspace(n_seq, S, n_head)
+    if need:
+        if out is None:
+            raise ValueError('S > 128 needs the forward output `out`')
+        _mat(out, 'out')
+        if tuple(out.shape) != tuple(dout.shape):
+            raise ValueError('out must have the shape of dout')
+        ws = _workspace(q.device, need)
+    check(lib.lime_token_attention_bwd_f32(_p(q), _p(k), _p(v), _ld(q), _p(out), _ld(out) if out is not None else 0, _p(dout),
+                                           _ld(dout), _p(dq), _p(dk), _p(dv), _ld(dqkv), n_seq, S, n_head, head_dim, hs, scale,
+                                           _p(ws), ws.numel() if ws is not None else 0, _stream()), 'lime_token_attention_bwd_f32')
     return dqkv
 
 

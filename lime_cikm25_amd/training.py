@@ -119,8 +119,8 @@ class _TokenEncoder(torch.autograd.Function):
         E = table.shape[1]
         hd = E // nhead
         hs = 32 if hd <= 32 else hd
-        if hs > 32 or S > 128:
-            raise NotImplementedError('the attention backward kernel covers head_dim <= 32 and S <= 128 (got %d, %d)' % (hd, S))
+        if hs > 32 or S > 512:
+            raise NotImplementedError('the attention kernels cover head_dim <= 32 and S <= 512 (got %d, %d)' % (hd, S))
         W = nhead * hs
         flat = ids.reshape(-1).contiguous()
         tok = M * S
@@ -161,10 +161,9 @@ class _TokenEncoder(torch.autograd.Function):
         del dx1, x1
         dout_w = ops.linear_wgrad(dz1, ao)
         dao = ops.linear(dz1, out_w.t().contiguous(), None)
-        del ao
         dqkv = ops.token_attention_bwd(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], dao, M, S, nhead, hd, 1.0 / math.sqrt(hd),
-                                       head_stride=hs)
-        del dao, qkv
+                                       head_stride=hs, out=ao)
+        del dao, qkv, ao
         x0 = ops.embed_pe(flat, table, pe, S)                                   # the layer input, re-gathered
         din_w, din_b = ops.linear_wgrad(dqkv, x0, want_bias=True)
         din_w, din_b = _unpad_heads(din_w, 3 * nhead, hd, hs), _unpad_heads(din_b, 3 * nhead, hd, hs)

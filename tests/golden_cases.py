@@ -97,6 +97,10 @@ CASES = {
     # real sequence lengths (title 32, body 128) at a tiny batch: pins the S=32 / S=128 token encoder
     'full_len': dict(cfg=dict(max_history_num=3, max_title_length=32, max_abstract_length=128, batch_size=2, **_SMALL),
                      B=2, N=2, seed=18, eval_shape=False, edit='none'),
+    # BASELINE configs[3] body length (Adressa shape, 512 tokens) at a tiny batch: the S = 512 token encoder and, in the
+    # gradient goldens, the blocked attention backward
+    'long_body': dict(cfg=dict(max_history_num=2, max_title_length=32, max_abstract_length=512, batch_size=2, **_SMALL),
+                      B=2, N=2, seed=19, eval_shape=False, edit='none'),
 }
 
 WEIGHT_SEED = 7

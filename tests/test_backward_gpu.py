@@ -99,7 +99,8 @@ def test_relu_bwd(ops):
 
 
 @pytest.mark.parametrize('n_seq,S,nh,hd,hs', [(3, 16, 10, 30, 32), (5, 32, 10, 30, 32), (2, 50, 4, 20, 20), (3, 64, 10, 30, 32),
-                                              (2, 128, 10, 30, 32), (1, 100, 2, 32, 32), (37, 32, 10, 30, 32)])
+                                              (2, 128, 10, 30, 32), (1, 100, 2, 32, 32), (37, 32, 10, 30, 32),
+                                              (2, 512, 10, 30, 32), (3, 200, 3, 30, 32), (1, 129, 2, 20, 20), (2, 256, 4, 32, 32)])
 def test_token_attention_bwd(ops, n_seq, S, nh, hd, hs):
     tok = n_seq * S
     scale = 1.0 / math.sqrt(hd)
@@ -119,7 +120,8 @@ def test_token_attention_bwd(ops, n_seq, S, nh, hd, hs):
     # the forward kernel on the same operands, for completeness of the pair
     out = ops.token_attention(g[:, :W], g[:, W:2 * W], g[:, 2 * W:], n_seq, S, nh, hd, scale, head_stride=hs)
     close(out, o.detach().float(), what='attention forward')
-    dqkv = ops.token_attention_bwd(g[:, :W], g[:, W:2 * W], g[:, 2 * W:], dout.cuda(), n_seq, S, nh, hd, scale, head_stride=hs)
+    dqkv = ops.token_attention_bwd(g[:, :W], g[:, W:2 * W], g[:, 2 * W:], dout.cuda(), n_seq, S, nh, hd, scale, head_stride=hs,
+                                   out=out)
     close(dqkv, want.view(tok, 3 * W), tol=2e-4, what='dqkv')
     if hs > hd:
         assert (dqkv.view(tok, 3, nh, hs)[..., hd:] == 0).all(), 'pad columns must be exact zeros'
