@@ -50,6 +50,9 @@ WORKLOADS = {
     # one training step = forward + backward + gradient all-reduce (N > 1) + clip_grad_norm_ + Adam
     'train2b': (dict(), 32, 5, 'training step (forward + backward + gradient all-reduce + clip + Adam), LIME-CROWN-CROWN, '
                                'batch=32 per GPU, history=50, title 32 + body 128, K=1+4, fp32, dropout off'),
+    'train2b_dropout': (dict(dropout_rate=0.2), 32, 5,
+                        'training step as train2b with the reference's dropout_rate = 0.2 (config.py:78) in every encoder dropout '
+                        'site (model.train()), counter-based masks'),
     'train4': (dict(max_abstract_length=512, batch_size=256), 32, 5,
                'training step at the BASELINE.json configs[3] shape per GPU (Adressa-shape: batch=32 per GPU, history=50, '
                'title 32 + body 512, K=1+4, config.batch_size=256), forward + backward + gradient all-reduce + clip + Adam, fp32, '
@@ -123,6 +126,8 @@ def main():
     train = args.workload.startswith('train')
     if train:                                    # trainer.py:131-148 on the native step (flat buckets, one all-reduce)
         from lime_cikm25_amd.training import TrainStep
+        if cfg.dropout_rate > 0:
+            model.train()                        # every dropout active, as under trainer.py:87
         ts = TrainStep(model, lr=1e-5, gradient_clip_norm=4.0)
         step = lambda: ts.step(*batch)
     if args.workload == 'cfg5':                  # Model.score_impressions: eval semantics, histories encoded once (eager)
@@ -200,7 +205,7 @@ def main():
             ach = fl / sec / 1e12
             traffic = None
             tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-            if os.path.exists(tfile):
+            if os.path.exists(tfile) and args.workload == 'cfg2b':      # the PMC passes were taken on this workload's launches
                 traffic = json.load(open(tfile)).get(name, {}).get('hbm_bytes_per_launch')
             is_bf16 = name.startswith('gemm_pp_kernel<') and name.split(', ')[4].startswith('true')   # gemm_pp_kernel<NTL, LN, RELU, RES, BF, PING>
             peak = PEAK_BF16_MFMA_TFLOPS if is_bf16 else PEAK_F32_MFMA_TFLOPS
@@ -225,7 +230,7 @@ def main():
             'end_to_end': {'flops_per_impression': fimp, 'achieved_tflops': round(value * fimp / 1e12, 2),
                            'frac_of_f32_mfma_peak': round(value * fimp / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4)},
         }
-        if world == 1 and not args.no_cpu_baseline and train:
+        if world == 1 and not args.no_cpu_baseline and train and cfg.dropout_rate == 0:
             from oracle import lime_oracle
             ncore = min(len(os.sched_getaffinity(0)), 16)
             torch.set_num_threads(ncore)
@@ -244,7 +249,7 @@ def main():
                                    'sample': '1 forward + backward of the same %d-impression batch (torch CPU fp32 oracle with '
                                              'autograd, no optimizer step, no warm-up)' % B,
                                    'first_step_loss_cpu': float(closs), 'first_step_loss_gpu': first_loss}
-        elif world == 1 and not args.no_cpu_baseline and args.workload != 'cfg5':
+        elif world == 1 and not args.no_cpu_baseline and args.workload != 'cfg5' and not train:
             from oracle import lime_oracle
             # the GPU box gives one GPU's share of the host: 16 cores (more threads only oversubscribe)
             ncore = min(len(os.sched_getaffinity(0)), 16)

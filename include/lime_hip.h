@@ -339,8 +339,9 @@ int lime_layernorm_bwd_f32(const float* dy, int64_t lddy, int32_t dy_div, float 
                            int32_t E, float* dgamma, float* dbeta, float* dzsum, int32_t accumulate, float* workspace,
                            int64_t workspace_floats, void* stream);
 
-/* dh[r, c] = 0 where h[r, c] <= 0 (ReLU backward on the saved activation of linear1), in place */
-int lime_relu_bwd_f32(float* dh, int64_t lddh, const float* h, int64_t ldh, int64_t rows, int32_t cols, void* stream);
+/* dh[r, c] = h[r, c] > 0 ? dh[r, c] * scale : 0, in place: ReLU backward on the saved activation of linear1 (scale = 1), or
+ * ReLU + the dropout that follows it when h is the dropped-out activation (scale = 1 / (1 - p)) */
+int lime_relu_bwd_f32(float* dh, int64_t lddh, const float* h, int64_t ldh, int64_t rows, int32_t cols, float scale, void* stream);
 
 /* Backward of lime_token_attention_f32 without a key mask (the encoder layers): given q / k / v as the forward read them
  * and dout [tokens, n_head * head_dim] (packed), writes dq / dk / dv in the layout of q / k / v (row stride ld_dqkv, head
@@ -348,12 +349,41 @@ int lime_relu_bwd_f32(float* dh, int64_t lddh, const float* h, int64_t ldh, int6
  * S <= 512, head_dim <= head_stride <= 32.  S <= 128: one pass per (sequence, head); `out` and `workspace` may be NULL.
  * 128 < S <= 512 (the 512-token bodies of BASELINE config 4): 128 x 128 blocks; needs the forward output `out` (packed like
  * dout) and lime_token_attention_bwd_workspace(n_seq, S, n_head) floats; the key blocks' shares of dq are added with float
- * atomics. */
+ * atomics.  dropout_p > 0 (S <= 128): the forward was lime_token_attention_dropout_f32 with the same (dropout_p, seed, site). */
 int64_t lime_token_attention_bwd_workspace(int32_t n_seq, int32_t S, int32_t n_head);
 int lime_token_attention_bwd_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out, int64_t ld_out,
                                  const float* dout, int64_t ldo, float* dq, float* dk, float* dv, int64_t ld_dqkv, int32_t n_seq,
                                  int32_t S, int32_t n_head, int32_t head_dim, int32_t head_stride, float scale, float* workspace,
-                                 int64_t workspace_floats, void* stream);
+                                 int64_t workspace_floats, float dropout_p, uint64_t seed, uint32_t site, void* stream);
+
+/* ---- dropout inside the token encoders in training mode --------------------------------------------------------------
+ * Masks are a pure function of (seed, site, element index) (csrc/dropout.h): element e of site `site` is kept iff
+ * hash(seed, site, e) >= p * 2^32, kept values are scaled by 1 / (1 - p); the backward regenerates the mask from the same
+ * triple.  torch's Philox stream is not reproduced (it differs between torch's own CPU and GPU generators as well). */
+
+/* dst[r, c] = keep(r * cols + c) ? src[r, c] / (1 - p) : 0   (src == dst allowed).  Forward of nn.Dropout, and -- applied to a
+ * gradient with the forward's (seed, site) -- its backward. */
+int lime_dropout_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int32_t cols, float p, uint64_t seed,
+                     uint32_t site, void* stream);
+
+/* out[r, :] = drop_pe(drop_emb(table[ids[r], :]) + pe[r % period, :]): the inplace dropout on the word embeddings
+ * (newsEncoders.py:311-312) and PositionalEncoding's dropout (:827) in one pass; element index r * dim + c for both sites. */
+int lime_embed_pe_dropout_f32(const int32_t* ids, const float* table, int64_t ld_table, const float* pe, int64_t ld_pe,
+                              int32_t period, float* out, int64_t ldo, int64_t rows, int32_t dim, float p, uint64_t seed,
+                              uint32_t site_emb, uint32_t site_pe, void* stream);
+
+/* y = LayerNorm(res + drop(t)) per row (norm1(x + dropout1(sa(x))) / norm2(x + dropout2(ff(x))) of nn.TransformerEncoderLayer);
+ * rstd (optional, [M]) as lime_linear_args.ln_rstd.  E <= 512. */
+int lime_dropout_add_layernorm_f32(const float* t, int64_t ldt, const float* res, int64_t ldr, const float* gamma, const float* beta,
+                                   float eps, float* y, int64_t ldy, float* rstd, int64_t M, int32_t E, float p, uint64_t seed,
+                                   uint32_t site, void* stream);
+
+/* Encoder attention with dropout on the probabilities (nn.MultiheadAttention(dropout=p) in training mode):
+ * out = (keep * softmax(scale q k^T) / (1 - p)) v; layouts as lime_token_attention_f32 without a key mask; mask element
+ * ((seq * n_head + head) * S + i) * S + j.  S <= 128. */
+int lime_token_attention_dropout_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, float* out, int64_t ldo,
+                                     int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim, int32_t head_stride, float scale,
+                                     float dropout_p, uint64_t seed, uint32_t site, void* stream);
 
 /* dtable[ids[r], :] += dx[r, :] (nn.Embedding backward, newsEncoders.py:311-312).  dtable must be initialised by the
  * caller (zeros, or a gradient to add to).  Rows with ids[r] == hot_id (the padding word, pass -1 for none) are summed

@@ -5,7 +5,7 @@ loading raises -- the product path never routes around the HIP kernels.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblime_hip.so')
@@ -113,11 +113,18 @@ SIGNATURES = {
     'lime_layernorm_bwd_f32': (c_int32, [c_void_p, c_int64, c_int32, c_float, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
                                          c_int64, c_void_p]),
-    'lime_relu_bwd_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p]),
+    'lime_relu_bwd_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_float, c_void_p]),
     'lime_token_attention_bwd_workspace': (c_int64, [c_int32, c_int32, c_int32]),
     'lime_token_attention_bwd_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                                c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_float,
-                                               c_void_p, c_int64, c_void_p]),
+                                               c_void_p, c_int64, c_float, c_uint64, c_uint32, c_void_p]),
+    'lime_dropout_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_float, c_uint64, c_uint32, c_void_p]),
+    'lime_embed_pe_dropout_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int64, c_int32,
+                                            c_float, c_uint64, c_uint32, c_uint32, c_void_p]),
+    'lime_dropout_add_layernorm_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64,
+                                                 c_void_p, c_int64, c_int32, c_float, c_uint64, c_uint32, c_void_p]),
+    'lime_token_attention_dropout_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32,
+                                                   c_int32, c_int32, c_float, c_float, c_uint64, c_uint32, c_void_p]),
     'lime_embed_bwd_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p]),
     'lime_embed_bwd_small_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p]),
     'lime_grad_clip_coef_f32': (c_int32, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int64, c_void_p]),

@@ -11,6 +11,7 @@
 //
 // All dense reductions are fixed-order (partials in a caller workspace, then one summing pass).
 #include "common.h"
+#include "dropout.h"
 
 namespace {
 
@@ -369,12 +370,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
 }
 
 __global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ dh, long lddh, const float* __restrict__ h, long ldh,
-                                                        long rows, int cols) {
+                                                        long rows, int cols, float scale) {
     const long total = rows * cols;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const long r = e / cols;
         const int c = (int)(e - r * cols);
-        if (!(h[r * ldh + c] > 0.f)) dh[r * lddh + c] = 0.f;
+        const float g = dh[r * lddh + c];
+        dh[r * lddh + c] = h[r * ldh + c] > 0.f ? g * scale : 0.f;
     }
 }
 
@@ -399,7 +401,8 @@ __global__ __launch_bounds__(512) void token_attn_bwd_kernel(const float* __rest
                                                               const float* __restrict__ v, long ld, const float* __restrict__ dout,
                                                               long ldo, float* __restrict__ dq, float* __restrict__ dk,
                                                               float* __restrict__ dv, long ldd, int n_seq, int S, int n_head,
-                                                              int head_dim, int head_stride, float scale, int vec) {
+                                                              int head_dim, int head_stride, float scale, int vec,
+                                                              LimeDropout drop) {
     constexpr int NT = SP / 16;                 // 16-column score tiles per row
     constexpr int WPP = SP / 16;                // waves per problem
     constexpr int PPW = 8 / WPP;                // problems per workgroup
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(512) void token_attn_bwd_kernel(const float* __rest
         if (vec && grp + gridDim.x < n_group) fetch((grp + gridDim.x) * PPW + pw);       // in flight during the compute below
 
         // ---- S tiles and dP tiles of this wave's 16 query rows ------------------------------------------------------
-        f32x4 p[NT], dp[NT];
+        f32x4 p[NT], dp[NT], pd[NT];
         {
             // the summation index d is only a label: lane group kg takes d = 8 kg .. 8 kg + 7 over the eight MFMA steps, so a
             // lane's eight operands are 32 consecutive bytes of its row -- two ds_read_b128 instead of eight ds_read_b32
@@ -548,20 +551,29 @@ __global__ __launch_bounds__(512) void token_attn_bwd_kernel(const float* __rest
             sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
             const float inv = 1.0f / sum;
             float dl = 0.f;
+            // attention-probability dropout (nn.MultiheadAttention's dropout, newsEncoders.py:244-247): the forward used
+            // keep * P / (1 - p); its mask is regenerated from the element's index.  kq[ct]: the factor on P for the dV product.
+            const uint64_t mrow = ((uint64_t)prob * S + (uint64_t)(R0 + 4 * kg + r)) * (uint64_t)S;
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
                 p[ct][r] *= inv;
+                if (drop.thresh != 0) {
+                    const float f = lime_keep(drop, mrow + (uint64_t)(16 * ct + fi)) ? drop.scale : 0.f;
+                    dp[ct][r] *= f;
+                    pd[ct][r] = p[ct][r] * f;
+                }
                 dl += p[ct][r] * dp[ct][r];
             }
             dl += __shfl_xor(dl, 1); dl += __shfl_xor(dl, 2); dl += __shfl_xor(dl, 4); dl += __shfl_xor(dl, 8);
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) dp[ct][r] = scale * p[ct][r] * (dp[ct][r] - dl);      // dS
         }
-        // P -> LDS
+        // P (as the forward multiplied it into V) -> LDS
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Ps[(R0 + 4 * kg + r) * LDP + 16 * ct + fi] = p[ct][r];
+            for (int r = 0; r < 4; ++r)
+                Ps[(R0 + 4 * kg + r) * LDP + 16 * ct + fi] = drop.thresh != 0 ? pd[ct][r] : p[ct][r];
         __syncthreads();
 
         const long out_row0 = (long)seq * S + R0;
@@ -610,6 +622,103 @@ __global__ __launch_bounds__(512) void token_attn_bwd_kernel(const float* __rest
             store_tile(dk, 0, ak0); store_tile(dk, 1, ak1);
         }
         __syncthreads();                        // the images are free for the next problem
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Training-mode forward of the encoder attention WITH probability dropout: out = (keep * softmax(scale Q K^T) / (1 - p)) V.
+// Same layout as token_attn_bwd_kernel (eight waves, 16 query rows each, S <= 128); the scoring kernel in token_attn_f32.hip
+// stays free of the mask arithmetic.
+// ---------------------------------------------------------------------------------------------------
+template <int SP>
+__global__ __launch_bounds__(512) void token_attn_fwd_dropout_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                      const float* __restrict__ v, long ld, float* __restrict__ out,
+                                                                      long ldo, int n_seq, int S, int n_head, int head_dim,
+                                                                      int head_stride, float scale, LimeDropout drop) {
+    constexpr int NT = SP / 16, WPP = SP / 16, PPW = 8 / WPP, TPP = 64 * WPP, LDP = SP + 2;
+    constexpr int PROB_FLOATS = 3 * SP * AB_LD + SP * LDP;
+    extern __shared__ float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, kg = lane >> 4;
+    const int pw = wave / WPP, wr = wave % WPP, lt = tid - pw * TPP;
+    const long n_prob = (long)n_seq * n_head;
+    const long prob = (long)blockIdx.x * PPW + pw;
+    const bool live = prob < n_prob;
+    const int seq = live ? (int)(prob / n_head) : 0, head = live ? (int)(prob % n_head) : 0;
+    float* Qs = smem + pw * PROB_FLOATS;
+    float* Ks = Qs + SP * AB_LD;
+    float* Vs = Ks + SP * AB_LD;
+    float* Ps = Vs + SP * AB_LD;
+    const int R0 = 16 * wr;
+    const long row_base = (long)seq * S;
+    for (int e = lt; e < SP * 32; e += TPP) {
+        const int r = e >> 5, c = e & 31;
+        const bool ok = live && r < S && c < head_dim;
+        const long g = (row_base + r) * ld + (long)head * head_stride + c;
+        Qs[r * AB_LD + c] = ok ? q[g] : 0.f;
+        Ks[r * AB_LD + c] = ok ? k[g] : 0.f;
+        Vs[r * AB_LD + c] = ok ? v[g] : 0.f;
+    }
+    __syncthreads();
+    f32x4 p[NT];
+    {
+        f32x4v qa[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) qa[h] = *reinterpret_cast<const f32x4v*>(&Qs[(R0 + fi) * AB_LD + 8 * kg + 4 * h]);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            f32x4v kf[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) kf[h] = *reinterpret_cast<const f32x4v*>(&Ks[(16 * ct + fi) * AB_LD + 8 * kg + 4 * h]);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) a = mfma16(qa[t >> 2][t & 3], kf[t >> 2][t & 3], a);
+            p[ct] = a;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            const float sv = (16 * ct + fi < S) ? p[ct][r] * scale : -INFINITY;
+            p[ct][r] = sv;
+            mx = fmaxf(mx, sv);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
+        mx = fmaxf(mx, __shfl_xor(mx, 4)); mx = fmaxf(mx, __shfl_xor(mx, 8));
+        float sum = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            const float e = expf(p[ct][r] - mx);
+            p[ct][r] = e;
+            sum += e;
+        }
+        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
+        const float inv = 1.0f / sum;
+        const uint64_t mrow = ((uint64_t)prob * S + (uint64_t)(R0 + 4 * kg + r)) * (uint64_t)S;
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            const float f = (drop.thresh == 0 || lime_keep(drop, mrow + (uint64_t)(16 * ct + fi))) ? drop.scale * inv : 0.f;
+            Ps[(R0 + 4 * kg + r) * LDP + 16 * ct + fi] = p[ct][r] * f;
+        }
+    }
+    __syncthreads();
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
+#pragma unroll 8
+    for (int t = 0; t < SP / 4; ++t) {          // O[i, d] = sum_j P[i, j] V[j, d] for the wave's own rows
+        const int j = 4 * t + kg;
+        const float a = Ps[(R0 + fi) * LDP + j];
+        o0 = mfma16(a, Vs[j * AB_LD + fi], o0);
+        o1 = mfma16(a, Vs[j * AB_LD + 16 + fi], o1);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = R0 + 4 * kg + r;
+        if (live && row < S) {
+            float* o = out + (row_base + row) * ldo + (long)head * head_dim;
+            if (fi < head_dim) o[fi] = o0[r];
+            if (16 + fi < head_dim) o[16 + fi] = o1[r];
+        }
     }
 }
 
@@ -1135,13 +1244,14 @@ extern "C" int lime_layernorm_bwd_f32(const float* dy, int64_t lddy, int32_t dy_
     return LIME_OK;
 }
 
-extern "C" int lime_relu_bwd_f32(float* dh, int64_t lddh, const float* h, int64_t ldh, int64_t rows, int32_t cols, void* stream) {
+extern "C" int lime_relu_bwd_f32(float* dh, int64_t lddh, const float* h, int64_t ldh, int64_t rows, int32_t cols, float scale,
+                                 void* stream) {
     LIME_REQUIRE(dh && h, LIME_ERR_BAD_ARG, "lime_relu_bwd_f32: null pointer");
     LIME_REQUIRE(rows >= 0 && cols > 0 && lddh >= cols && ldh >= cols, LIME_ERR_BAD_ARG, "lime_relu_bwd_f32: bad dimensions");
     if (rows == 0) return LIME_OK;
     const long total = rows * cols;
     const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    relu_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(dh, lddh, h, ldh, rows, cols);
+    relu_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(dh, lddh, h, ldh, rows, cols, scale);
     return lime_check_launch("relu_bwd_kernel");
 }
 
@@ -1149,7 +1259,7 @@ namespace {
 template <int SP>
 int launch_attn_bwd(const float* q, const float* k, const float* v, long ld, const float* dout, long ldo, float* dq, float* dk,
                     float* dv, long ldd, int n_seq, int S, int n_head, int head_dim, int head_stride, float scale,
-                    hipStream_t s) {
+                    const LimeDropout& drop, hipStream_t s) {
     constexpr int PPW = 8 / (SP / 16);
     constexpr int BYTES = PPW * (4 * SP * AB_LD + SP * (SP + 2)) * 4;
     static bool configured = false;
@@ -1169,8 +1279,26 @@ int launch_attn_bwd(const float* q, const float* k, const float* v, long ld, con
     const bool vec = head_stride == 32 && ld % 4 == 0 && ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) == 0 &&
                      head_dim % 2 == 0 && ldo % 2 == 0 && (((uintptr_t)dout) & 7) == 0;
     token_attn_bwd_kernel<SP><<<grid, 512, BYTES, s>>>(q, k, v, ld, dout, ldo, dq, dk, dv, ldd, n_seq, S, n_head, head_dim,
-                                                      head_stride, scale, vec ? 1 : 0);
+                                                      head_stride, scale, vec ? 1 : 0, drop);
     return lime_check_launch("token_attn_bwd_kernel");
+}
+
+template <int SP>
+int launch_attn_fwd_dropout(const float* q, const float* k, const float* v, long ld, float* out, long ldo, int n_seq, int S,
+                            int n_head, int head_dim, int head_stride, float scale, const LimeDropout& drop, hipStream_t s) {
+    constexpr int PPW = 8 / (SP / 16);
+    constexpr int BYTES = PPW * (3 * SP * AB_LD + SP * (SP + 2)) * 4;
+    static bool configured = false;
+    if (!configured) {
+        const hipError_t e = hipFuncSetAttribute((const void*)token_attn_fwd_dropout_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+        LIME_REQUIRE(e == hipSuccess, LIME_ERR_LAUNCH, "lime_token_attention_dropout_f32: cannot reserve %d bytes of LDS: %s", BYTES,
+                     hipGetErrorString(e));
+        configured = true;
+    }
+    const long n_group = ((long)n_seq * n_head + PPW - 1) / PPW;
+    token_attn_fwd_dropout_kernel<SP><<<(unsigned)n_group, 512, BYTES, s>>>(q, k, v, ld, out, ldo, n_seq, S, n_head, head_dim, head_stride,
+                                                                           scale, drop);
+    return lime_check_launch("token_attn_fwd_dropout_kernel");
 }
 }  // namespace
 
@@ -1182,8 +1310,11 @@ extern "C" int lime_token_attention_bwd_f32(const float* q, const float* k, cons
                                             int64_t ld_out, const float* dout, int64_t ldo, float* dq, float* dk, float* dv,
                                             int64_t ld_dqkv, int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim,
                                             int32_t head_stride, float scale, float* workspace, int64_t workspace_floats,
-                                            void* stream) {
+                                            float dropout_p, uint64_t seed, uint32_t site, void* stream) {
     LIME_REQUIRE(q && k && v && dout && dq && dk && dv, LIME_ERR_BAD_ARG, "lime_token_attention_bwd_f32: null pointer");
+    LIME_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, LIME_ERR_BAD_ARG, "lime_token_attention_bwd_f32: dropout_p outside [0, 1)");
+    LIME_REQUIRE(dropout_p == 0.f || S <= 128, LIME_ERR_UNSUPPORTED, "lime_token_attention_bwd_f32: probability dropout needs S <= 128");
+    const LimeDropout drop = lime_make_dropout(dropout_p, seed, site);
     LIME_REQUIRE(n_seq >= 0 && S > 0 && n_head > 0 && head_dim > 0, LIME_ERR_BAD_ARG, "lime_token_attention_bwd_f32: bad dimensions");
     LIME_REQUIRE(S <= 512 && head_dim <= 32 && head_stride >= head_dim && head_stride <= 32, LIME_ERR_UNSUPPORTED,
                  "lime_token_attention_bwd_f32: needs S <= 512 and head_dim <= head_stride <= 32 (S=%d head_dim=%d head_stride=%d)",
@@ -1192,9 +1323,9 @@ extern "C" int lime_token_attention_bwd_f32(const float* q, const float* k, cons
                  LIME_ERR_BAD_ARG, "lime_token_attention_bwd_f32: leading dimension smaller than the row");
     if (n_seq == 0) return LIME_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (S <= 32) return launch_attn_bwd<32>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, s);
-    if (S <= 64) return launch_attn_bwd<64>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, s);
-    if (S <= 128) return launch_attn_bwd<128>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, s);
+    if (S <= 32) return launch_attn_bwd<32>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, drop, s);
+    if (S <= 64) return launch_attn_bwd<64>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, drop, s);
+    if (S <= 128) return launch_attn_bwd<128>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, drop, s);
     // blocked path
     LIME_REQUIRE(out && ld_out >= (int64_t)n_head * head_dim, LIME_ERR_BAD_ARG,
                  "lime_token_attention_bwd_f32: S > 128 needs the forward output `out` (delta = dO . O)");
@@ -1220,6 +1351,24 @@ extern "C" int lime_token_attention_bwd_f32(const float* q, const float* k, cons
     attn_bwd_long_kernel<<<(unsigned)(n_prob * n_blk), 512, BYTES, s>>>(q, k, v, ld_qkv, dout, ldo, workspace, dq, dk, dv, ld_dqkv, S,
                                                                        n_head, head_dim, head_stride, scale, n_blk);
     return lime_check_launch("attn_bwd_long_kernel");
+}
+
+extern "C" int lime_token_attention_dropout_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, float* out, int64_t ldo,
+                                                int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim, int32_t head_stride,
+                                                float scale, float dropout_p, uint64_t seed, uint32_t site, void* stream) {
+    LIME_REQUIRE(q && k && v && out, LIME_ERR_BAD_ARG, "lime_token_attention_dropout_f32: null pointer");
+    LIME_REQUIRE(n_seq >= 0 && S > 0 && n_head > 0 && head_dim > 0, LIME_ERR_BAD_ARG, "lime_token_attention_dropout_f32: bad dimensions");
+    LIME_REQUIRE(S <= 128 && head_dim <= 32 && head_stride >= head_dim && head_stride <= 32, LIME_ERR_UNSUPPORTED,
+                 "lime_token_attention_dropout_f32: needs S <= 128 and head_dim <= head_stride <= 32");
+    LIME_REQUIRE(ld_qkv >= (int64_t)n_head * head_stride && ldo >= (int64_t)n_head * head_dim, LIME_ERR_BAD_ARG,
+                 "lime_token_attention_dropout_f32: leading dimension smaller than the row");
+    LIME_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, LIME_ERR_BAD_ARG, "lime_token_attention_dropout_f32: dropout_p outside [0, 1)");
+    if (n_seq == 0) return LIME_OK;
+    const LimeDropout drop = lime_make_dropout(dropout_p, seed, site);
+    hipStream_t s = (hipStream_t)stream;
+    if (S <= 32) return launch_attn_fwd_dropout<32>(q, k, v, ld_qkv, out, ldo, n_seq, S, n_head, head_dim, head_stride, scale, drop, s);
+    if (S <= 64) return launch_attn_fwd_dropout<64>(q, k, v, ld_qkv, out, ldo, n_seq, S, n_head, head_dim, head_stride, scale, drop, s);
+    return launch_attn_fwd_dropout<128>(q, k, v, ld_qkv, out, ldo, n_seq, S, n_head, head_dim, head_stride, scale, drop, s);
 }
 
 extern "C" int lime_embed_bwd_f32(const int32_t* ids, const float* dx, int64_t lddx, float* dtable, int64_t ld_table, int64_t rows,

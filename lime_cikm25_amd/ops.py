@@ -634,20 +634,22 @@ def layernorm_bwd(dy, y, gamma, beta, rstd, dy_div=1, dy_scale=1.0, want_dzsum=T
     return dz, dgamma, dbeta, dzsum
 
 
-def relu_bwd_(dh, h):
-    """dh[h <= 0] = 0, in place."""
+def relu_bwd_(dh, h, scale=1.0):
+    """dh = dh * scale where h > 0, else 0 -- in place."""
     lib = _lib.load()
     _mat(dh, 'dh')
     _mat(h, 'h')
     if dh.shape != h.shape:
         raise ValueError('dh and h differ in shape')
-    check(lib.lime_relu_bwd_f32(_p(dh), _ld(dh), _p(h), _ld(h), dh.shape[0], dh.shape[1], _stream()), 'lime_relu_bwd_f32')
+    check(lib.lime_relu_bwd_f32(_p(dh), _ld(dh), _p(h), _ld(h), dh.shape[0], dh.shape[1], scale, _stream()), 'lime_relu_bwd_f32')
     return dh
 
 
-def token_attention_bwd(q, k, v, dout, n_seq, S, n_head, head_dim, scale, head_stride=None, dqkv=None, out=None):
+def token_attention_bwd(q, k, v, dout, n_seq, S, n_head, head_dim, scale, head_stride=None, dqkv=None, out=None,
+                        dropout=None):
     """Backward of the unmasked ``token_attention``: q / k / v column views of one packed qkv buffer [tokens, 3 * n_head *
-    head_stride]; returns dqkv in the same layout.  ``out``: the forward's result (needed for S > 128)."""
+    head_stride]; returns dqkv in the same layout.  ``out``: the forward's result (needed for S > 128).  ``dropout``:
+    (p, seed, site) of the ``token_attention_dropout`` forward."""
     lib = _lib.load()
     hs = head_dim if head_stride is None else head_stride
     W = n_head * hs
@@ -674,8 +676,67 @@ def token_attention_bwd(q, k, v, dout, n_seq, S, n_head, head_dim, scale, head_s
         ws = _workspace(q.device, need)
     check(lib.lime_token_attention_bwd_f32(_p(q), _p(k), _p(v), _ld(q), _p(out), _ld(out) if out is not None else 0, _p(dout),
                                            _ld(dout), _p(dq), _p(dk), _p(dv), _ld(dqkv), n_seq, S, n_head, head_dim, hs, scale,
-                                           _p(ws), ws.numel() if ws is not None else 0, _stream()), 'lime_token_attention_bwd_f32')
+                                           _p(ws), ws.numel() if ws is not None else 0, *(dropout or (0.0, 0, 0)), _stream()),
+          'lime_token_attention_bwd_f32')
     return dqkv
+
+
+def dropout(src, p, seed, site, out=None):
+    """keep * src / (1 - p) with the counter-based mask of (seed, site); ``out`` may be ``src`` (in place)."""
+    lib = _lib.load()
+    _mat(src, 'src')
+    if out is None:
+        out = torch.empty(tuple(src.shape), dtype=torch.float32, device=src.device)
+    _mat(out, 'out')
+    if out.shape != src.shape:
+        raise ValueError('out must have the shape of src')
+    check(lib.lime_dropout_f32(_p(src), _ld(src), _p(out), _ld(out), src.shape[0], src.shape[1], p, seed, site, _stream()), 'lime_dropout_f32')
+    return out
+
+
+def embed_pe_dropout(ids, table, pe, period, p, seed, site_emb, site_pe):
+    """drop(drop(table[ids]) + pe[r % period]) -> [len(ids), dim]."""
+    lib = _lib.load()
+    _vec(ids, 'ids', dtype=torch.int32)
+    _mat(table, 'table')
+    _mat(pe, 'pe')
+    out = torch.empty((ids.numel(), table.shape[1]), dtype=torch.float32, device=table.device)
+    check(lib.lime_embed_pe_dropout_f32(_p(ids), _p(table), _ld(table), _p(pe), _ld(pe), period, _p(out), _ld(out), ids.numel(),
+                                        table.shape[1], p, seed, site_emb, site_pe, _stream()), 'lime_embed_pe_dropout_f32')
+    return out
+
+
+def dropout_add_layernorm(t, res, gamma, beta, eps, p, seed, site, want_rstd=True):
+    """(LayerNorm(res + drop(t)), rstd)."""
+    lib = _lib.load()
+    _mat(t, 't')
+    _mat(res, 'res')
+    M, E = t.shape
+    if res.shape != t.shape:
+        raise ValueError('res must have the shape of t')
+    _vec(gamma, 'gamma', E)
+    _vec(beta, 'beta', E)
+    y = torch.empty((M, E), dtype=torch.float32, device=t.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=t.device) if want_rstd else None
+    check(lib.lime_dropout_add_layernorm_f32(_p(t), _ld(t), _p(res), _ld(res), _p(gamma), _p(beta), eps, _p(y), _ld(y), _p(rstd), M, E,
+                                             p, seed, site, _stream()), 'lime_dropout_add_layernorm_f32')
+    return y, rstd
+
+
+def token_attention_dropout(q, k, v, n_seq, S, n_head, head_dim, scale, p, seed, site, head_stride=None):
+    """Unmasked encoder attention with dropout on the probabilities (training mode); layouts as ``token_attention``."""
+    lib = _lib.load()
+    hs = head_dim if head_stride is None else head_stride
+    for t, name in ((q, 'q'), (k, 'k'), (v, 'v')):
+        _mat(t, name)
+        if t.shape[0] != n_seq * S or t.shape[1] != n_head * hs:
+            raise ValueError('%s must be [n_seq * S, n_head * head_stride]' % name)
+    if not (_ld(q) == _ld(k) == _ld(v)):
+        raise ValueError('q, k, v must share one leading dimension')
+    out = torch.empty((n_seq * S, n_head * head_dim), dtype=torch.float32, device=q.device)
+    check(lib.lime_token_attention_dropout_f32(_p(q), _p(k), _p(v), _ld(q), _p(out), _ld(out), n_seq, S, n_head, head_dim, hs, scale,
+                                               p, seed, site, _stream()), 'lime_token_attention_dropout_f32')
+    return out
 
 
 def embed_bwd(ids, dx, dtable, hot_id=0):

@@ -12,9 +12,11 @@ Where the arithmetic runs
     gated LayerNorm, GraphSAGE mean, history-vs-candidate softmax, lifetime weight): torch ops on the device with torch's
     autograd.  The fused scoring kernels of that glue have no hand-written backward yet.
 
-Dropout: the reference trains with dropout_rate 0.2 inside the encoder layers; the HIP encoder has no dropout masks, so a
-model whose token encoders are in training mode with dropout_rate > 0 raises NotImplementedError.  Dropout in the torch
-glue (feature_fusion, user_node_embedding, the hard-coded p = 0.2 of the candidate-aware attention) is honoured.
+Dropout (the reference trains with dropout_rate 0.2): the six dropouts inside a token encoder run on the dropout kernels
+with counter-based masks (csrc/dropout.h; torch's Philox stream is not reproduced -- the arithmetic is pinned against a torch
+statement of the layer fed with the same masks, tests/test_dropout_gpu.py); sequences longer than 128 tokens are refused with
+dropout on.  Dropout in the torch glue (feature_fusion, user_node_embedding, the hard-coded p = 0.2 of the candidate-aware
+attention) uses torch's own generator.
 """
 import math
 
@@ -110,85 +112,134 @@ def _unpad_heads(t, groups, hd, hs):
     return t.view(groups, hs, *rest)[:, :hd].reshape(groups * hd, *rest)
 
 
+# dropout sites of one encoder call (csrc/dropout.h): the mask of a site is a function of (seed, site, element index)
+_SITE_EMB, _SITE_PE, _SITE_ATTN, _SITE_DROP1, _SITE_FF, _SITE_DROP2 = range(6)
+
+
 class _TokenEncoder(torch.autograd.Function):
-    """pooled [M, E] = mean_S(EncoderLayer(E[ids] + PE))  (newsEncoders.py:311-321 for one of title / body)."""
+    """pooled [M, E] = mean_S(EncoderLayer(E[ids] + PE))  (newsEncoders.py:311-321 for one of title / body).
+
+    p = 0: the fused forward of the scoring path (word gather inside the in_proj GEMM, residual + LayerNorm in the GEMM
+    epilogues).  p > 0 (training-mode dropout, seeded per call): the same layer with its six dropouts -- word embeddings and
+    positional sum (:311-312, :827), attention probabilities, dropout1 / dropout / dropout2 of the encoder layer -- on the
+    dropout kernels; masks are regenerated in the backward from (seed, site)."""
 
     @staticmethod
-    def forward(ctx, ids, nhead, eps1, eps2, table, pe, in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b):
+    def forward(ctx, ids, nhead, eps1, eps2, p, seed, table, pe, in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w,
+                n2_b):
         M, S = ids.shape
         E = table.shape[1]
         hd = E // nhead
         hs = 32 if hd <= 32 else hd
         if hs > 32 or S > 512:
             raise NotImplementedError('the attention kernels cover head_dim <= 32 and S <= 512 (got %d, %d)' % (hd, S))
+        if p > 0 and S > 128:
+            raise NotImplementedError('attention-probability dropout is implemented for sequences of at most 128 tokens (got %d)' % S)
         W = nhead * hs
         flat = ids.reshape(-1).contiguous()
         tok = M * S
         dev = table.device
+        scale = 1.0 / math.sqrt(hd)
         w_in = ops.pad_heads(in_w, 3 * nhead, hd, hs) if hs != hd else in_w
         b_in = ops.pad_heads(in_b, 3 * nhead, hd, hs) if hs != hd else in_b
-        pew = ops.linear(pe[:S], w_in, b_in)
-        qkv = ops.linear(table, w_in, None, a_ids=flat, res=pew, res_mod=S)
-        ao = ops.token_attention(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, 1.0 / math.sqrt(hd), head_stride=hs)
-        rstd1 = torch.empty(tok, dtype=torch.float32, device=dev)
-        x1 = ops.linear(ao, out_w, out_b, res=table, res_ids=flat, res_pe=pe, res_period=S, ln=(n1_w, n1_b), ln_eps=eps1,
-                        ln_rstd=rstd1)
-        h = ops.linear(x1, l1_w, l1_b, act='relu')
-        rstd2 = torch.empty(tok, dtype=torch.float32, device=dev)
-        y = ops.linear(h, l2_w, l2_b, res=x1, ln=(n2_w, n2_b), ln_eps=eps2, ln_rstd=rstd2)
+        x0 = None
+        if p > 0:
+            x0 = ops.embed_pe_dropout(flat, table, pe, S, p, seed, _SITE_EMB, _SITE_PE)
+            qkv = ops.linear(x0, w_in, b_in)
+            ao = ops.token_attention_dropout(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, scale, p, seed, _SITE_ATTN,
+                                             head_stride=hs)
+            x1, rstd1 = ops.dropout_add_layernorm(ops.linear(ao, out_w, out_b), x0, n1_w, n1_b, eps1, p, seed, _SITE_DROP1)
+            h = ops.linear(x1, l1_w, l1_b, act='relu')
+            ops.dropout(h, p, seed, _SITE_FF, out=h)
+            y, rstd2 = ops.dropout_add_layernorm(ops.linear(h, l2_w, l2_b), x1, n2_w, n2_b, eps2, p, seed, _SITE_DROP2)
+        else:
+            pew = ops.linear(pe[:S], w_in, b_in)
+            qkv = ops.linear(table, w_in, None, a_ids=flat, res=pew, res_mod=S)
+            ao = ops.token_attention(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, scale, head_stride=hs)
+            rstd1 = torch.empty(tok, dtype=torch.float32, device=dev)
+            x1 = ops.linear(ao, out_w, out_b, res=table, res_ids=flat, res_pe=pe, res_period=S, ln=(n1_w, n1_b), ln_eps=eps1,
+                            ln_rstd=rstd1)
+            h = ops.linear(x1, l1_w, l1_b, act='relu')
+            rstd2 = torch.empty(tok, dtype=torch.float32, device=dev)
+            y = ops.linear(h, l2_w, l2_b, res=x1, ln=(n2_w, n2_b), ln_eps=eps2, ln_rstd=rstd2)
         pooled = ops.mean_pool(y, M, S)
-        ctx.dims = (M, S, E, nhead, hd, hs)
-        ctx.save_for_backward(flat, table, pe, w_in, out_w, l1_w, l2_w, n1_w, n1_b, n2_w, n2_b, qkv, ao, x1, rstd1, h, y, rstd2)
+        ctx.dims = (M, S, E, nhead, hd, hs, p, seed)
+        ctx.save_for_backward(flat, table, pe, w_in, out_w, l1_w, l2_w, n1_w, n1_b, n2_w, n2_b, qkv, ao, x1, rstd1, h, y, rstd2, x0)
         return pooled
 
     @staticmethod
     def backward(ctx, dpooled):
-        (flat, table, pe, w_in, out_w, l1_w, l2_w, n1_w, n1_b, n2_w, n2_b, qkv, ao, x1, rstd1, h, y, rstd2) = ctx.saved_tensors
-        M, S, E, nhead, hd, hs = ctx.dims
+        (flat, table, pe, w_in, out_w, l1_w, l2_w, n1_w, n1_b, n2_w, n2_b, qkv, ao, x1, rstd1, h, y, rstd2, x0) = ctx.saved_tensors
+        M, S, E, nhead, hd, hs, p, seed = ctx.dims
         W = nhead * hs
+        drop = p > 0
+        keep_scale = 1.0 / (1.0 - p) if drop else 1.0
         dpooled = dpooled.contiguous()
         # norm2 <- mean pool: every token of a sequence receives dpooled / S
-        dz2, dn2_w, dn2_b, dl2_b = ops.layernorm_bwd(dpooled, y, n2_w, n2_b, rstd2, dy_div=S, dy_scale=1.0 / S)
+        dz2, dn2_w, dn2_b, dl2_b = ops.layernorm_bwd(dpooled, y, n2_w, n2_b, rstd2, dy_div=S, dy_scale=1.0 / S, want_dzsum=not drop)
         del y
-        dl2_w = ops.linear_wgrad(dz2, h)
-        dh = ops.linear(dz2, l2_w.t().contiguous(), None)
-        ops.relu_bwd_(dh, h)
-        del h
+        dt2 = ops.dropout(dz2, p, seed, _SITE_DROP2) if drop else dz2              # the branch through dropout2 into linear2
+        if drop:
+            dl2_w, dl2_b = ops.linear_wgrad(dt2, h, want_bias=True)
+        else:
+            dl2_w = ops.linear_wgrad(dt2, h)
+        dh = ops.linear(dt2, l2_w.t().contiguous(), None)
+        ops.relu_bwd_(dh, h, keep_scale)                                           # h > 0 <=> ReLU passed and the mask kept
+        del h, dt2
         dl1_w, dl1_b = ops.linear_wgrad(dh, x1, want_bias=True)
-        dx1 = ops.linear(dh, l1_w.t().contiguous(), None, res=dz2)             # through linear1 + the residual branch
+        dx1 = ops.linear(dh, l1_w.t().contiguous(), None, res=dz2)                 # through linear1 + the residual branch
         del dh, dz2
-        dz1, dn1_w, dn1_b, dout_b = ops.layernorm_bwd(dx1, x1, n1_w, n1_b, rstd1)
+        dz1, dn1_w, dn1_b, dout_b = ops.layernorm_bwd(dx1, x1, n1_w, n1_b, rstd1, want_dzsum=not drop)
         del dx1, x1
-        dout_w = ops.linear_wgrad(dz1, ao)
-        dao = ops.linear(dz1, out_w.t().contiguous(), None)
+        dt1 = ops.dropout(dz1, p, seed, _SITE_DROP1) if drop else dz1
+        if drop:
+            dout_w, dout_b = ops.linear_wgrad(dt1, ao, want_bias=True)
+        else:
+            dout_w = ops.linear_wgrad(dt1, ao)
+        dao = ops.linear(dt1, out_w.t().contiguous(), None)
         dqkv = ops.token_attention_bwd(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], dao, M, S, nhead, hd, 1.0 / math.sqrt(hd),
-                                       head_stride=hs, out=ao)
-        del dao, qkv, ao
-        x0 = ops.embed_pe(flat, table, pe, S)                                   # the layer input, re-gathered
+                                       head_stride=hs, out=ao, dropout=(p, seed, _SITE_ATTN) if drop else None)
+        del dao, qkv, ao, dt1
+        if x0 is None:
+            x0 = ops.embed_pe(flat, table, pe, S)                                  # the layer input, re-gathered
         din_w, din_b = ops.linear_wgrad(dqkv, x0, want_bias=True)
         din_w, din_b = _unpad_heads(din_w, 3 * nhead, hd, hs), _unpad_heads(din_b, 3 * nhead, hd, hs)
         del x0
-        dx0 = ops.linear(dqkv, w_in.t().contiguous(), None, res=dz1)            # through in_proj + the residual branch
+        dx0 = ops.linear(dqkv, w_in.t().contiguous(), None, res=dz1)               # through in_proj + the residual branch
         dtable = None
-        if ctx.needs_input_grad[4]:
+        if ctx.needs_input_grad[6]:
+            if drop:                                                               # back through the two input dropouts
+                ops.dropout(dx0, p, seed, _SITE_PE, out=dx0)
+                ops.dropout(dx0, p, seed, _SITE_EMB, out=dx0)
             dtable = torch.zeros_like(table)
             ops.embed_bwd(flat, dx0, dtable, hot_id=0)
-        return (None, None, None, None, dtable, None, din_w, din_b, dout_w, dout_b, dl1_w, dl1_b, dl2_w, dl2_b, dn1_w, dn1_b,
-                dn2_w, dn2_b)
+        return (None, None, None, None, None, None, dtable, None, din_w, din_b, dout_w, dout_b, dl1_w, dl1_b, dl2_w, dl2_b, dn1_w,
+                dn1_b, dn2_w, dn2_b)
 
 
-def encode_tokens(ids, table, pos_encoder, transformer, nhead):
+def _draw_seed():
+    """A fresh 62-bit seed from torch's CPU generator (torch.manual_seed makes a run repeatable)."""
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+def encode_tokens(ids, table, pos_encoder, transformer, nhead, p_embedding=0.0):
+    """``p_embedding``: the probability of the inplace dropout the caller's encoder applies to the word embeddings (0 in eval
+    mode).  The HIP layer applies ONE probability to its six dropout sites, which is how the reference builds it
+    (config.dropout_rate everywhere); anything else is refused."""
     if len(transformer.layers) != 1 or transformer.norm is not None:
         raise NotImplementedError('the training path covers num_layers = 1 without a final norm (config.py default)')
     layer = transformer.layers[0]
-    if layer.training and (layer.dropout.p > 0 or layer.self_attn.dropout > 0 or pos_encoder.dropout.p > 0):
-        raise NotImplementedError('training-mode dropout inside the encoder layers is not implemented on the HIP path: '
-                                  'train with dropout_rate = 0 or keep the token encoders in eval mode')
     sa = layer.self_attn
-    return _TokenEncoder.apply(ids.contiguous(), nhead, layer.norm1.eps, layer.norm2.eps, table, pos_encoder.table(),
-                               sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, layer.linear1.weight,
-                               layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, layer.norm1.weight, layer.norm1.bias,
-                               layer.norm2.weight, layer.norm2.bias)
+    ps = [p_embedding, pos_encoder.dropout.p if pos_encoder.training else 0.0]
+    ps += [sa.dropout, layer.dropout1.p, layer.dropout.p, layer.dropout2.p] if layer.training else [0.0] * 4
+    if max(ps) != min(ps):
+        raise NotImplementedError('the HIP encoder layer applies one dropout probability to all of its sites; got %s (embedding, '
+                                  'positional, attention, dropout1, dropout, dropout2): put the news encoder into one mode' % ps)
+    p = float(ps[0])
+    return _TokenEncoder.apply(ids.contiguous(), nhead, layer.norm1.eps, layer.norm2.eps, p, _draw_seed() if p > 0 else 0, table,
+                               pos_encoder.table(), sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias,
+                               layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, layer.norm1.weight,
+                               layer.norm1.bias, layer.norm2.weight, layer.norm2.bias)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -204,12 +255,10 @@ def _additive_attention(att, feature):
 
 def crown_content(enc, title_text, content_text, category, subCategory):
     """newsEncoders.CROWN.forward (newsEncoders.py:302-373) on M flat news -> [M, 900]."""
-    if enc.training and enc.dropout_rate > 0:
-        raise NotImplementedError('training-mode dropout on the word embeddings (newsEncoders.py:311-312) is not implemented '
-                                  'on the HIP path: train with dropout_rate = 0 or keep the news encoder in eval mode')
     table = enc.word_embedding.weight
-    title_p = encode_tokens(title_text, table, enc.title_pos_encoder, enc.title_transformer, enc.head_num)      # :311-317
-    body_p = encode_tokens(content_text, table, enc.body_pos_encoder, enc.body_transformer, enc.head_num)       # :312-321
+    p_emb = enc.dropout.p if enc.training else 0.0                                                              # :311-312
+    title_p = encode_tokens(title_text, table, enc.title_pos_encoder, enc.title_transformer, enc.head_num, p_emb)   # :311-317
+    body_p = encode_tokens(content_text, table, enc.body_pos_encoder, enc.body_transformer, enc.head_num, p_emb)    # :312-321
     cat_e = embedding(enc.category_embedding.weight, category)
     sub_e = embedding(enc.subCategory_embedding.weight, subCategory)
     cat_rep = linear(torch.cat([cat_e, sub_e], dim=1), enc.category_affine)                                     # :340-342

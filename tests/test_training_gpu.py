@@ -130,11 +130,13 @@ def test_native_step_follows_torch_adam_and_clip():
     assert rel_err(scored.cpu().numpy(), again.detach().cpu().numpy()) < 1e-4
 
 
-def test_training_mode_dropout_in_the_encoder_is_refused():
+def test_mixed_dropout_modes_are_refused():
+    """One probability for the six dropout sites of a token encoder: a half-train / half-eval news encoder is refused."""
     cfg, batch, c = golden_cases.build_case('cfg1_crown')
     cfg.dropout_rate = 0.2
     model = Model(cfg)
     model.initialize()
     model = model.cuda().train()
+    model.news_encoder.base_news_encoder.title_transformer.eval()
     with pytest.raises(NotImplementedError):
         model(*[v.cuda() for v in batch.values()])
