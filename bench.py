@@ -51,7 +51,7 @@ WORKLOADS = {
     'train2b': (dict(), 32, 5, 'training step (forward + backward + gradient all-reduce + clip + Adam), LIME-CROWN-CROWN, '
                                'batch=32 per GPU, history=50, title 32 + body 128, K=1+4, fp32, dropout off'),
     'train2b_dropout': (dict(dropout_rate=0.2), 32, 5,
-                        'training step as train2b with the reference's dropout_rate = 0.2 (config.py:78) in every encoder dropout '
+                        'training step as train2b with the dropout_rate = 0.2 of the reference (config.py:78) in every encoder dropout '
                         'site (model.train()), counter-based masks'),
     'train4': (dict(max_abstract_length=512, batch_size=256), 32, 5,
                'training step at the BASELINE.json configs[3] shape per GPU (Adressa-shape: batch=32 per GPU, history=50, '
