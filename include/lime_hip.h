@@ -14,8 +14,10 @@
  *   - every call enqueues work on `stream` (a hipStream_t passed as void*) and returns at once;
  *   - return value: LIME_OK (0) or a negative lime_status; lime_last_error_string() describes the
  *     last failure of the calling thread;
- *   - calls are stateless and re-entrant; results are bitwise reproducible run to run (no atomics
- *     in any reduction).
+ *   - calls are stateless and re-entrant; every entry point of the scoring path is bitwise reproducible run to run (no
+ *     atomics in any reduction).  Two training-step kernels add with float atomics and are reproducible only up to the
+ *     order of those fp32 additions: lime_embed_bwd_f32 (word rows repeat across tokens) and the S > 128 path of
+ *     lime_token_attention_bwd_f32 (dq from the key blocks).
  */
 #ifndef LIME_HIP_H
 #define LIME_HIP_H

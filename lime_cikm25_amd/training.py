@@ -458,9 +458,64 @@ class TrainStep:
         self.last_norm = coef[:1]
         return self.last_norm
 
+    # ---- checkpoint / resume ------------------------------------------------------------------------------------------
+    def state_dict(self):
+        """Optimizer state for resuming: Adam's moments per parameter NAME (so it survives a different bucket layout), the step
+        count and the hyper-parameters.  The model itself is saved the reference's way: {model_name: model.state_dict()}
+        (trainer.py:220), see ``save_checkpoint``."""
+        out = {'step': self.step_count, 'lr': self.lr, 'weight_decay': self.weight_decay, 'betas': tuple(self.betas), 'eps': self.eps,
+               'gradient_clip_norm': self.clip, 'exp_avg': {}, 'exp_avg_sq': {}}
+        for name, (off, n, shape) in self._slots().items():
+            out['exp_avg'][name] = self.exp_avg[off:off + n].view(shape).clone()
+            out['exp_avg_sq'][name] = self.exp_avg_sq[off:off + n].view(shape).clone()
+        return out
+
+    def load_state_dict(self, state):
+        slots = self._slots()
+        missing = sorted(set(slots) - set(state['exp_avg']))
+        if missing:
+            raise KeyError('optimizer state lacks %d parameters, e.g. %s' % (len(missing), missing[:3]))
+        with torch.no_grad():
+            for name, (off, n, shape) in slots.items():
+                self.exp_avg[off:off + n].copy_(state['exp_avg'][name].reshape(-1))
+                self.exp_avg_sq[off:off + n].copy_(state['exp_avg_sq'][name].reshape(-1))
+        self.step_count = int(state['step'])
+        self.lr, self.weight_decay, self.eps = state['lr'], state['weight_decay'], state['eps']
+        self.betas, self.clip = tuple(state['betas']), state['gradient_clip_norm']
+
+    def _slots(self):
+        named = dict(self.model.named_parameters())
+        base = self.flat.data_ptr()
+        return {n: ((named[n].data_ptr() - base) // 4, named[n].numel(), tuple(named[n].shape)) for n in self.names}
+
     def step(self, *batch):
         """One training step on a batch in ``Model.forward``'s 26-tensor order; returns the (device) loss."""
         logits = self.model(*batch)
         loss = negative_log_softmax(logits)
         self.backward_and_update(loss)
         return loss.detach()
+
+
+def save_checkpoint(path, model, train_step=None):
+    """The reference's checkpoint file -- torch.save({model.model_name: model.state_dict()}) (trainer.py:220), which main.py:45,
+    60 load with ``torch.load(path)[model.model_name]`` -- plus, under the extra key 'optimizer', the TrainStep state when
+    one is given (the reference saves none: its runs cannot resume mid-training)."""
+    payload = {model.model_name: {k: v.detach().cpu() for k, v in model.state_dict().items()}}
+    if train_step is not None:
+        st = train_step.state_dict()
+        for key in ('exp_avg', 'exp_avg_sq'):
+            st[key] = {k: v.cpu() for k, v in st[key].items()}
+        payload['optimizer'] = st
+    torch.save(payload, path)
+
+
+def load_checkpoint(path, model, train_step=None, map_location='cpu'):
+    """Load a checkpoint written by ``save_checkpoint`` or by the reference's trainer (tensors only: weights_only=True).
+    Parameters keep their storage (``load_state_dict`` copies in place), so a TrainStep's flat bucket stays valid."""
+    payload = torch.load(path, map_location=map_location, weights_only=True)
+    if model.model_name not in payload:
+        raise KeyError('checkpoint holds %s, not %r' % (sorted(payload), model.model_name))
+    model.load_state_dict(payload[model.model_name])
+    if train_step is not None and 'optimizer' in payload:
+        train_step.load_state_dict(payload['optimizer'])
+    return payload

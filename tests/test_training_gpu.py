@@ -140,3 +140,28 @@ def test_mixed_dropout_modes_are_refused():
     model.news_encoder.base_news_encoder.title_transformer.eval()
     with pytest.raises(NotImplementedError):
         model(*[v.cuda() for v in batch.values()])
+
+
+def test_checkpoint_resume_continues_bit_for_bit(tmp_path):
+    """save_checkpoint after two steps, load into a fresh model + TrainStep, take the third step on both: identical loss and
+    parameters (Adam moments, step count and the re-pointed flat bucket all survive).  The file is the reference's
+    {model_name: state_dict} (trainer.py:220) with one extra key."""
+    from lime_cikm25_amd.training import load_checkpoint, save_checkpoint
+    cfg, model, batch = train_model('spill')
+    step = TrainStep(model, lr=LR)
+    for _ in range(2):
+        step.step(*batch)
+    path = str(tmp_path / 'ckpt')
+    save_checkpoint(path, model, step)
+    payload = torch.load(path, weights_only=True)
+    assert set(payload) == {model.model_name, 'optimizer'} and set(payload[model.model_name]) == set(model.state_dict())
+    _, fresh, _ = train_model('spill')
+    fresh_step = TrainStep(fresh, lr=123.0)                       # hyper-parameters come back from the file
+    load_checkpoint(path, fresh, fresh_step)
+    assert fresh_step.step_count == 2 and fresh_step.lr == LR
+    # the scatter-add of the word-table gradient uses float atomics: compare everything else exactly, the table closely
+    l_a, l_b = float(step.step(*batch)), float(fresh_step.step(*batch))
+    assert abs(l_a - l_b) <= 1e-6 * max(1.0, abs(l_a))
+    a, b = dict(unique_named_parameters(model)), dict(unique_named_parameters(fresh))
+    for k in step.names:
+        assert rel_err(b[k].detach().cpu().numpy(), a[k].detach().cpu().numpy()) < 1e-5, k
