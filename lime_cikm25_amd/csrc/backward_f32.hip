@@ -391,6 +391,8 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(float* __restrict__ dh, l
 // holds the NEXT problem's Q / K / V / dO rows in registers while it computes the current one, so the global latency of
 // the staging is off the critical path; two waves per SIMD cover each other's softmax and LDS phases.
 // ---------------------------------------------------------------------------------------------------
+constexpr float LOG2E = 1.4426950408889634f;      // scores are taken to the log2 domain: p = exp2(s' - max') on v_exp_f32,
+                                                  // as the forward kernel (token_attn_f32.hip) computes them
 constexpr int AB_LD = 36;        // Q / K / V / dO rows: 32 columns + 4: 16-byte aligned rows for ds_read_b128 / ds_write_b128
 #ifndef LIME_ATTN_BWD_ABLATE
 #define LIME_ATTN_BWD_ABLATE 0   // tools/attn_bwd_ablate.py builds variants with phases removed (results garbage)
@@ -508,6 +510,11 @@ __global__ __launch_bounds__(512) void token_attn_bwd_kernel(const float* __rest
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
+                        if constexpr ((LIME_ATTN_BWD_ABLATE & 64) != 0) {      // no K / V fragment reads: MFMAs on register operands
+                            kb[buf][t][h] = qa[h] + (float)ct;
+                            vb[buf][t][h] = oa[h] + (float)ct;
+                            continue;
+                        }
                         kb[buf][t][h] = *reinterpret_cast<const f32x4v*>(&Ks[(16 * (ct + t) + fi) * AB_LD + 8 * kg + 4 * h]);
                         vb[buf][t][h] = *reinterpret_cast<const f32x4v*>(&Vs[(16 * (ct + t) + fi) * AB_LD + 8 * kg + 4 * h]);
                     }
@@ -535,7 +542,7 @@ __global__ __launch_bounds__(512) void token_attn_bwd_kernel(const float* __rest
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
                 const bool col_ok = 16 * ct + fi < S;
-                const float sv = col_ok ? p[ct][r] * scale : -INFINITY;
+                const float sv = col_ok ? p[ct][r] * (scale * LOG2E) : -INFINITY;
                 p[ct][r] = sv;
                 mx = fmaxf(mx, sv);
             }
@@ -544,7 +551,7 @@ __global__ __launch_bounds__(512) void token_attn_bwd_kernel(const float* __rest
             float sum = 0.f;
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
-                const float e = expf(p[ct][r] - mx);
+                const float e = __builtin_amdgcn_exp2f(p[ct][r] - mx);
                 p[ct][r] = e;
                 sum += e;
             }
@@ -680,7 +687,7 @@ __global__ __launch_bounds__(512) void token_attn_fwd_dropout_kernel(const float
         float mx = -INFINITY;
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) {
-            const float sv = (16 * ct + fi < S) ? p[ct][r] * scale : -INFINITY;
+            const float sv = (16 * ct + fi < S) ? p[ct][r] * (scale * LOG2E) : -INFINITY;
             p[ct][r] = sv;
             mx = fmaxf(mx, sv);
         }
@@ -689,7 +696,7 @@ __global__ __launch_bounds__(512) void token_attn_fwd_dropout_kernel(const float
         float sum = 0.f;
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) {
-            const float e = expf(p[ct][r] - mx);
+            const float e = __builtin_amdgcn_exp2f(p[ct][r] - mx);
             p[ct][r] = e;
             sum += e;
         }
@@ -724,7 +731,7 @@ __global__ __launch_bounds__(512) void token_attn_fwd_dropout_kernel(const float
 
 // ---------------------------------------------------------------------------------------------------
 // Sequences longer than 128 tokens (BASELINE config 4: body length 512): the same mathematics in 128 x 128 blocks.
-//   attn_stats_kernel      per query row: lse = log sum_j exp(scale q.k_j) over ALL keys, delta = dO . O (O: the forward output)
+//   attn_stats_kernel      per query row: lse = log2 sum_j exp(scale q.k_j) over ALL keys, delta = dO . O (O: the forward output)
 //   attn_bwd_long_kernel   one workgroup per (sequence, head, key block): P = exp(scale S - lse) needs no row reduction any
 //                          more; dK / dV of the block accumulate in registers over the query blocks, the dQ contributions of
 //                          the key blocks are added with float atomics (dq is zeroed first)
@@ -783,7 +790,7 @@ __global__ __launch_bounds__(512) void attn_stats_kernel(const float* __restrict
             float mx = -INFINITY;
 #pragma unroll
             for (int ct = 0; ct < LB / 16; ++ct) {
-                const float sv = (16 * ct + fi < k_valid) ? sc[ct][r] * scale : -INFINITY;
+                const float sv = (16 * ct + fi < k_valid) ? sc[ct][r] * (scale * LOG2E) : -INFINITY;
                 sc[ct][r] = sv;
                 mx = fmaxf(mx, sv);
             }
@@ -792,9 +799,9 @@ __global__ __launch_bounds__(512) void attn_stats_kernel(const float* __restrict
             const float mn = fmaxf(m[r], mx);
             float sum = 0.f;
 #pragma unroll
-            for (int ct = 0; ct < LB / 16; ++ct) sum += expf(sc[ct][r] - mn);
+            for (int ct = 0; ct < LB / 16; ++ct) sum += __builtin_amdgcn_exp2f(sc[ct][r] - mn);
             sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
-            l[r] = l[r] * expf(m[r] - mn) + sum;
+            l[r] = l[r] * __builtin_amdgcn_exp2f(m[r] - mn) + sum;
             m[r] = mn;
         }
     }
@@ -802,7 +809,7 @@ __global__ __launch_bounds__(512) void attn_stats_kernel(const float* __restrict
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = R0 + 4 * kg + r;
-        if (fi == 0 && row < q_valid) stats[((row_base + q0 + row) * n_head + head) * 2] = m[r] + logf(l[r]);
+        if (fi == 0 && row < q_valid) stats[((row_base + q0 + row) * n_head + head) * 2] = m[r] + log2f(l[r]);   // log2 domain
     }
     if (tid < q_valid) {
         const float* po = out + (row_base + q0 + tid) * ldout + (long)head * head_dim;
@@ -879,7 +886,7 @@ __global__ __launch_bounds__(512) void attn_bwd_long_kernel(const float* __restr
             const float lse = Ls[R0 + 4 * kg + r], dl = Ds[R0 + 4 * kg + r];
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
-                const float pv = (16 * ct + fi < k_valid) ? expf(p[ct][r] * scale - lse) : 0.f;
+                const float pv = (16 * ct + fi < k_valid) ? __builtin_amdgcn_exp2f(p[ct][r] * (scale * LOG2E) - lse) : 0.f;
                 p[ct][r] = pv;
                 dp[ct][r] = scale * pv * (dp[ct][r] - dl);
             }

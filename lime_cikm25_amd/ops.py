@@ -589,8 +589,14 @@ def linear_wgrad(dy, x, out=None, accumulate=False, bias_out=None, want_bias=Fal
     else:
         need = lib.lime_linear_wgrad_workspace(M, N, K)
         ws = _workspace(dy.device, need)
+        if PROFILE is not None:                    # bench.py: HIP events around the launch pair (wgrad + partial-sum reduction)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         check(lib.lime_linear_wgrad_f32(_p(dy), _ld(dy), _p(x), _ld(x), _p(out), _ld(out), _p(bias_out), M, N, K,
                                         1 if accumulate else 0, _p(ws), ws.numel(), _stream()), 'lime_linear_wgrad_f32')
+        if PROFILE is not None:
+            e1.record()
+            PROFILE.append(('wgrad_kernel + reduce_partials_kernel (dW = dY^T X)', M, N, K, e0, e1))
     return out if bias_out is None else (out, bias_out)
 
 

@@ -1,6 +1,6 @@
 """Diagnostic: where does token_attn_bwd_kernel spend its time?  Builds variants of backward_f32.hip with phases removed
 (-DLIME_ATTN_BWD_ABLATE=mask: 1 no global staging, 2 no S / dP MFMAs, 4 no softmax, 8 no dV, 16 no dQ / dK, 32 no stores) and
-times the body (S = 128) and title (S = 32) shapes.
+times the body (S = 128) and title (S = 32) shapes.  64: the S / dP MFMAs run on register operands (no K / V fragment reads).
 
     python tools/attn_bwd_ablate.py
 """
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-MASKS = [0, 1, 2, 4, 8, 16, 32, 2 | 4 | 8 | 16, 1 | 32, 63]
+MASKS = [0, 2, 64, 4 | 8 | 16, 4 | 8 | 16 | 64, 2 | 4 | 8 | 16]
 
 
 def build(mask):
