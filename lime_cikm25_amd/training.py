@@ -253,12 +253,8 @@ def _additive_attention(att, feature):
     return (alpha.unsqueeze(-1) * feature).sum(dim=1)
 
 
-def crown_content(enc, title_text, content_text, category, subCategory):
-    """newsEncoders.CROWN.forward (newsEncoders.py:302-373) on M flat news -> [M, 900]."""
-    table = enc.word_embedding.weight
-    p_emb = enc.dropout.p if enc.training else 0.0                                                              # :311-312
-    title_p = encode_tokens(title_text, table, enc.title_pos_encoder, enc.title_transformer, enc.head_num, p_emb)   # :311-317
-    body_p = encode_tokens(content_text, table, enc.body_pos_encoder, enc.body_transformer, enc.head_num, p_emb)    # :312-321
+def crown_tail(enc, title_p, body_p, category, subCategory):
+    """newsEncoders.CROWN.forward after the token encoders (newsEncoders.py:340-373): pooled title / body [M, 300] -> [M, 900]."""
     cat_e = embedding(enc.category_embedding.weight, category)
     sub_e = embedding(enc.subCategory_embedding.weight, subCategory)
     cat_rep = linear(torch.cat([cat_e, sub_e], dim=1), enc.category_affine)                                     # :340-342
@@ -276,13 +272,22 @@ def crown_content(enc, title_text, content_text, category, subCategory):
     return torch.cat([title_i, sim.unsqueeze(1) * body_i, enc.dropout(cat_e.clone()), enc.dropout(sub_e.clone())], dim=1)   # :221-225
 
 
-def lime_news(ne, title_text, content_text, category, subCategory, freshness, lifetime):
-    """LIME.forward, fusion 'concat' (newsEncoders.py:140-153) on M flat news -> [M, 400]."""
+def pooled_tokens(ne, title_text, content_text):
+    """The two token encoders of the CROWN content encoder (newsEncoders.py:311-321) on M flat news -> 2 x [M, 300]."""
     from .newsEncoders import CROWN
-    base = ne.base_news_encoder
-    if not isinstance(base, CROWN):
+    enc = ne.base_news_encoder
+    if not isinstance(enc, CROWN):
         raise NotImplementedError('the training path covers the CROWN content encoder (LIME-CROWN-CROWN)')
-    content = crown_content(base, title_text, content_text, category, subCategory)
+    table = enc.word_embedding.weight
+    p_emb = enc.dropout.p if enc.training else 0.0                                                              # :311-312
+    title_p = encode_tokens(title_text, table, enc.title_pos_encoder, enc.title_transformer, enc.head_num, p_emb)   # :311-317
+    body_p = encode_tokens(content_text, table, enc.body_pos_encoder, enc.body_transformer, enc.head_num, p_emb)    # :312-321
+    return title_p, body_p
+
+
+def lime_tail(ne, title_p, body_p, category, subCategory, freshness, lifetime):
+    """LIME.forward, fusion 'concat' (newsEncoders.py:140-153), after the token encoders -> [M, 400]."""
+    content = crown_tail(ne.base_news_encoder, title_p, body_p, category, subCategory)
     fe = ne.freshness_encoder
     fb = ops.bucketize(freshness)
     lb = ops.bucketize(lifetime)
@@ -350,11 +355,29 @@ def lifetime_weight(w, remaining):
     return torch.sigmoid(w.alpha * remaining.abs())
 
 
+def tail_forward(model, title_p, body_p, category, subCategory, freshness, lifetime, news_category, news_subCategory, user_category,
+                 user_subCategory, user_history_mask, remaining_lifetime):
+    """Everything of Model.forward after the token encoders: intent disentanglement / fusion / freshness / project per news,
+    then the CROWN user encoder and the lifetime-weighted dot product.  3 % of the FLOPs in some 400 small launches forward +
+    backward (4 ms of kernel time at config 2b: the launches are short, not sparse -- capturing them into HIP graphs with
+    torch.cuda.make_graphed_callables was measured and changed nothing; fewer, fused kernels are what is missing)."""
+    B, N = news_category.shape
+    H = user_category.shape[1]
+    rep = lime_tail(model.news_encoder, title_p, body_p, category, subCategory, freshness, lifetime)
+    cand = rep[:B * N].view(B, N, -1)
+    hist = rep[B * N:].view(B, H, -1)
+    user = user_match(model.user_encoder, hist, cand, news_category, news_subCategory, user_category, user_subCategory,
+                      user_history_mask)
+    logits = (user * cand).sum(dim=-1)                                                                            # util.py:37
+    w = lifetime_weight(model.remaining_lifetime_weighting, remaining_lifetime)
+    return logits if w is None else logits * w
+
+
 def forward_train(model, user_category, user_subCategory, user_title_text, user_content_text, user_freshness,
                   user_user_topic_lifetime, user_history_mask, news_category, news_subCategory, news_title_text,
                   news_content_text, news_freshness, news_user_topic_lifetime, remaining_lifetime):
     """Model.forward with [B, N] candidates (model.py:171-187), recording the autograd graph."""
-    ne, ue = model.news_encoder, model.user_encoder
+    ne = model.news_encoder
     B, N = news_category.shape
     H = user_category.shape[1]
     i32 = lambda t: t if t.dtype == torch.int32 else t.to(torch.int32)
@@ -364,16 +387,13 @@ def forward_train(model, user_category, user_subCategory, user_title_text, user_
         news_freshness = news_freshness.unsqueeze(1).expand(B, N)
     if news_user_topic_lifetime.dim() == 1:
         news_user_topic_lifetime = news_user_topic_lifetime.unsqueeze(1).expand(B, N)
-    rep = lime_news(ne, i32(flat2(news_title_text, user_title_text)), i32(flat2(news_content_text, user_content_text)),
-                    i32(flat1(news_category, user_category)), i32(flat1(news_subCategory, user_subCategory)),
-                    flat1(news_freshness.float(), user_freshness.float()).contiguous(),
-                    flat1(news_user_topic_lifetime.float(), user_user_topic_lifetime.float()).contiguous())
-    cand = rep[:B * N].view(B, N, -1)
-    hist = rep[B * N:].view(B, H, -1)
-    user = user_match(ue, hist, cand, news_category, news_subCategory, user_category, user_subCategory, user_history_mask)
-    logits = (user * cand).sum(dim=-1)                                                                            # util.py:37
-    w = lifetime_weight(model.remaining_lifetime_weighting, remaining_lifetime.float())
-    return logits if w is None else logits * w
+    title_p, body_p = pooled_tokens(ne, i32(flat2(news_title_text, user_title_text)), i32(flat2(news_content_text, user_content_text)))
+    args = (title_p, body_p, i32(flat1(news_category, user_category)), i32(flat1(news_subCategory, user_subCategory)),
+            flat1(news_freshness.float(), user_freshness.float()).contiguous(),
+            flat1(news_user_topic_lifetime.float(), user_user_topic_lifetime.float()).contiguous(),
+            i32(news_category).contiguous(), i32(news_subCategory).contiguous(), i32(user_category).contiguous(),
+            i32(user_subCategory).contiguous(), user_history_mask.contiguous(), remaining_lifetime.float().contiguous())
+    return tail_forward(model, *args)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
