@@ -412,6 +412,35 @@ int lime_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float
 int lime_nll_softmax_f32(const float* logits, int64_t ld, int32_t B, int32_t K, float* loss, float* dlogits, int64_t ldd,
                          void* stream);
 
+/* ---- backward of the fused tail kernels (csrc/tail_backward_f32.hip) -------------------------------------------------- */
+
+/* Backward of lime_intent_fuse_f32 (newsEncoders.py:355-371: intent attention over the k intents of title and body, cosine
+ * similarity, concat): dcontent [M, ldc] holds the gradient of content[:, 0:2D]; writes d_intents [2 M k, D], d_hidden
+ * [2 M k, A] and the two affine2 gradients [A] (summed over the news in a fixed order through `workspace`,
+ * lime_intent_fuse_bwd_workspace(M, A) floats). */
+int64_t lime_intent_fuse_bwd_workspace(int64_t M, int32_t A);
+int lime_intent_fuse_bwd_f32(const float* intents, const float* hidden, const float* aff2_title, const float* aff2_body,
+                             const float* dcontent, int64_t ldc, float* d_intents, float* d_hidden, float* d_aff2_title,
+                             float* d_aff2_body, int64_t M, int32_t k, int32_t D, int32_t A, float* workspace,
+                             int64_t workspace_floats, void* stream);
+
+/* Backward of lime_gate_ln_f32 (layers.py:84-89): out = LayerNorm(g s x + (1 - g) x), g = sigmoid(s y + bias), s = scale[row].
+ * Writes dy, dx [rows, D] (dx: the direct path only; y = W_g x is the caller's GEMM), dscale [rows], dbias / dgamma / dbeta
+ * [D].  workspace: lime_gate_ln_bwd_workspace(rows, D) floats. */
+int64_t lime_gate_ln_bwd_workspace(int64_t rows, int32_t D);
+int lime_gate_ln_bwd_f32(const float* y, const float* x, const float* scale, const float* bias, const float* gamma, const float* beta,
+                         float eps, const float* dout, float* dy, float* dx, float* dscale, float* dbias, float* dgamma,
+                         float* dbeta, int64_t rows, int32_t D, float* workspace, int64_t workspace_floats, void* stream);
+
+/* Backward of lime_interest_match_f32 (userEncoders.py:158-169 + util.py:23-49) from dlogits [B, N]: dkp [B, H, A], dqp
+ * [B, N, A], dg [B, H, D], dcand [B, N, D] (the lifetime weight is a constant of the parameters).  workspace:
+ * lime_interest_match_bwd_workspace(B, N, H, A, D) floats (per-candidate shares of dkp / dg, summed over n in order). */
+int64_t lime_interest_match_bwd_workspace(int32_t B, int32_t N, int32_t H, int32_t A, int32_t D);
+int lime_interest_match_bwd_f32(const float* kp, const float* qp, const float* g, const float* cand, const float* remaining,
+                                const float* dlogits, float* dkp, float* dqp, float* dg, float* dcand, int32_t B, int32_t N,
+                                int32_t H, int32_t A, int32_t D, float scale, float alpha, float beta, int32_t use_weight,
+                                int32_t use_penalty, float* workspace, int64_t workspace_floats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

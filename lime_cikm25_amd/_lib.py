@@ -130,6 +130,16 @@ SIGNATURES = {
     'lime_grad_clip_coef_f32': (c_int32, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     'lime_adam_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,
                                 c_int32, c_void_p, c_void_p]),
+    'lime_intent_fuse_bwd_workspace': (c_int64, [c_int64, c_int32]),
+    'lime_intent_fuse_bwd_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_int64, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p]),
+    'lime_gate_ln_bwd_workspace': (c_int64, [c_int64, c_int32]),
+    'lime_gate_ln_bwd_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p]),
+    'lime_interest_match_bwd_workspace': (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    'lime_interest_match_bwd_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_int32,
+                                              c_int32, c_void_p, c_int64, c_void_p]),
     'lime_nll_softmax_f32': (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
 }
 

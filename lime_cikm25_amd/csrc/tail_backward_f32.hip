@@ -1,0 +1,424 @@
+// Backward of the fused tail kernels of small_ops.hip (training step): each kernel recomputes
+// the few forward intermediates it needs (they are cheaper to redo than to keep) and writes every gradient of its stage in
+// one launch.  Reductions over the rows (bias / LayerNorm / affine2 gradients) go through per-workgroup partials in a caller
+// workspace and are summed in a fixed order by reduce_rows_kernel -- no atomics.
+//
+//   intent_fuse_bwd_kernel      layers.Attention over the k intents + cosine similarity + concat   (newsEncoders.py:355-371)
+//   gate_ln_bwd_kernel          gated residual + LayerNorm of CandidateAware_ClickedNewsAttention  (layers.py:84-89)
+//   interest_match_bwd_kernel   history-vs-candidate attention + dot product + lifetime weight     (userEncoders.py:158-169, util.py:23-49)
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_INTENT = 8;
+
+// sum over the 256 threads; `red` >= 4 floats of LDS; every thread gets the total
+__device__ __forceinline__ float bsum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// out[c] (+)= sum_s part[s * stride + c]: one thread per column chunk, fixed order
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, long stride, int splits, float* __restrict__ out,
+                                                           int cols, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int i = 0; i < splits; ++i) s += part[(long)i * stride + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// intent fuse backward.  Forward (per news m, halves tb = title / body): a_k = hidden_k . aff2, alpha = softmax_k(a),
+// pooled_tb = sum_k alpha_k intents_k;  s = (cos(t, b) + 1) / 2;  content = [t, s * b].
+// Persistent grid: a workgroup walks the rows m = blockIdx.x, + gridDim.x, ... and keeps its share of d aff2 in registers.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void intent_fuse_bwd_kernel(const float* __restrict__ intents, const float* __restrict__ hidden,
+                                                               const float* __restrict__ aff2_t, const float* __restrict__ aff2_b,
+                                                               const float* __restrict__ dcontent, long ldc, float* __restrict__ d_intents,
+                                                               float* __restrict__ d_hidden, float* __restrict__ ws, long M, int k,
+                                                               int D, int A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // pooled [2][D], dpool [2][D], red [4]
+    float* pooled = sm;
+    float* dpool = sm + 2 * D;
+    float* red = sm + 4 * D;
+    constexpr int APT = 4;                                       // affine2 columns per thread (A <= 1024)
+    float da2[2][APT];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int u = 0; u < APT; ++u) da2[tb][u] = 0.f;
+    for (long m = blockIdx.x; m < M; m += gridDim.x) {
+        float alpha[2][MAX_INTENT];
+        for (int tb = 0; tb < 2; ++tb) {
+            const float* aff2 = tb == 0 ? aff2_t : aff2_b;
+            const float* hid = hidden + ((long)tb * M + m) * k * A;
+            const float* itn = intents + ((long)tb * M + m) * k * D;
+            float mx = -INFINITY;
+            for (int kk = 0; kk < k; ++kk) {
+                float part = 0.f;
+                for (int j = threadIdx.x; j < A; j += 256) part += hid[kk * A + j] * aff2[j];
+                alpha[tb][kk] = bsum(part, red);
+                mx = fmaxf(mx, alpha[tb][kk]);
+            }
+            float den = 0.f;
+            for (int kk = 0; kk < k; ++kk) {
+                alpha[tb][kk] = expf(alpha[tb][kk] - mx);
+                den += alpha[tb][kk];
+            }
+            const float inv = 1.0f / den;
+            for (int kk = 0; kk < k; ++kk) alpha[tb][kk] *= inv;
+            for (int d = threadIdx.x; d < D; d += 256) {
+                float x = 0.f;
+                for (int kk = 0; kk < k; ++kk) x += alpha[tb][kk] * itn[kk * D + d];
+                pooled[tb * D + d] = x;
+            }
+        }
+        __syncthreads();
+        float dot = 0.f, n1 = 0.f, n2 = 0.f, dsim = 0.f;
+        for (int d = threadIdx.x; d < D; d += 256) {
+            const float t = pooled[d], b = pooled[D + d];
+            dot += t * b;
+            n1 += t * t;
+            n2 += b * b;
+            dsim += dcontent[m * ldc + D + d] * b;
+        }
+        dot = bsum(dot, red);
+        n1 = bsum(n1, red);
+        n2 = bsum(n2, red);
+        dsim = bsum(dsim, red);
+        const float nt_raw = sqrtf(n1), nb_raw = sqrtf(n2);
+        const float nt = fmaxf(nt_raw, 1e-8f), nb = fmaxf(nb_raw, 1e-8f);
+        const float cosv = dot / (nt * nb);
+        const float s = (cosv + 1.0f) * 0.5f;
+        const float dcos = 0.5f * dsim;
+        // a clamped norm is a constant: its derivative term drops out
+        const float kt = nt_raw > 1e-8f ? cosv / (nt * nt) : 0.f, kb = nb_raw > 1e-8f ? cosv / (nb * nb) : 0.f;
+        const float inv_nn = 1.0f / (nt * nb);
+        for (int d = threadIdx.x; d < D; d += 256) {
+            const float t = pooled[d], b = pooled[D + d];
+            dpool[d] = dcontent[m * ldc + d] + dcos * (b * inv_nn - kt * t);
+            dpool[D + d] = s * dcontent[m * ldc + D + d] + dcos * (t * inv_nn - kb * b);
+        }
+        __syncthreads();
+        for (int tb = 0; tb < 2; ++tb) {
+            const float* aff2 = tb == 0 ? aff2_t : aff2_b;
+            const float* hid = hidden + ((long)tb * M + m) * k * A;
+            const float* itn = intents + ((long)tb * M + m) * k * D;
+            float* dit = d_intents + ((long)tb * M + m) * k * D;
+            float* dhid = d_hidden + ((long)tb * M + m) * k * A;
+            float dal[MAX_INTENT];
+            float mix = 0.f;
+            for (int kk = 0; kk < k; ++kk) {
+                float part = 0.f;
+                for (int d = threadIdx.x; d < D; d += 256) {
+                    const float dp = dpool[tb * D + d];
+                    part += dp * itn[kk * D + d];
+                    dit[kk * D + d] = alpha[tb][kk] * dp;
+                }
+                dal[kk] = bsum(part, red);
+                mix += alpha[tb][kk] * dal[kk];
+            }
+            for (int kk = 0; kk < k; ++kk) {
+                const float ds = alpha[tb][kk] * (dal[kk] - mix);
+#pragma unroll
+                for (int u = 0; u < APT; ++u) {
+                    const int j = threadIdx.x + 256 * u;
+                    if (j < A) {
+                        dhid[kk * A + j] = ds * aff2[j];
+                        da2[tb][u] += ds * hid[kk * A + j];
+                    }
+                }
+            }
+        }
+        __syncthreads();                                          // pooled / dpool are rewritten by the next row
+    }
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int u = 0; u < APT; ++u) {
+            const int j = threadIdx.x + 256 * u;
+            if (j < A) ws[((long)blockIdx.x * 2 + tb) * A + j] = da2[tb][u];
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gated residual + LayerNorm backward.  Forward (row r, s = scale[r]): g = sigmoid(s y + bias), v = x (1 + g (s - 1)),
+// out = LayerNorm(v).  Persistent grid; column sums (d bias, d gamma, d beta) in registers, partials [grid][3][D].
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_ln_bwd_kernel(const float* __restrict__ y, const float* __restrict__ x,
+                                                           const float* __restrict__ scale, const float* __restrict__ bias,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                           const float* __restrict__ dout, float* __restrict__ dy, float* __restrict__ dx,
+                                                           float* __restrict__ dscale, float* __restrict__ ws, long rows, int D) {
+    __shared__ float red[4];
+    constexpr int DPT = 4;                                       // columns per thread (D <= 1024)
+    float cb[DPT], cg[DPT], ce[DPT];
+#pragma unroll
+    for (int u = 0; u < DPT; ++u) cb[u] = cg[u] = ce[u] = 0.f;
+    const float inv_d = 1.0f / (float)D;
+    for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float s = scale[r];
+        float xv[DPT], yv[DPT], g[DPT], v[DPT], go[DPT];
+        float part = 0.f;
+#pragma unroll
+        for (int u = 0; u < DPT; ++u) {
+            const int d = threadIdx.x + 256 * u;
+            const bool in = d < D;
+            xv[u] = in ? x[r * D + d] : 0.f;
+            yv[u] = in ? y[r * D + d] : 0.f;
+            g[u] = in ? lime_sigmoid(s * yv[u] + bias[d]) : 0.f;
+            v[u] = xv[u] * (1.0f + g[u] * (s - 1.0f));
+            go[u] = in ? dout[r * D + d] : 0.f;
+            part += v[u];
+        }
+        const float mean = bsum(part, red) * inv_d;
+        part = 0.f;
+#pragma unroll
+        for (int u = 0; u < DPT; ++u) {
+            const int d = threadIdx.x + 256 * u;
+            v[u] = d < D ? v[u] - mean : 0.f;
+            part += v[u] * v[u];
+        }
+        const float rstd = 1.0f / sqrtf(bsum(part, red) * inv_d + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < DPT; ++u) {
+            const int d = threadIdx.x + 256 * u;
+            const float xh = v[u] * rstd;
+            const float gy = d < D ? go[u] * gamma[d] : 0.f;
+            s1 += gy;
+            s2 += gy * xh;
+            cg[u] += go[u] * xh;
+            ce[u] += go[u];
+            v[u] = xh;                                            // keep xhat
+            go[u] = gy;                                           // keep dout * gamma
+        }
+        s1 = bsum(s1, red) * inv_d;
+        s2 = bsum(s2, red) * inv_d;
+        float ds = 0.f;
+#pragma unroll
+        for (int u = 0; u < DPT; ++u) {
+            const int d = threadIdx.x + 256 * u;
+            if (d < D) {
+                const float dv = rstd * (go[u] - s1 - v[u] * s2);
+                const float dg = dv * xv[u] * (s - 1.0f);
+                const float dpre = dg * g[u] * (1.0f - g[u]);
+                dx[r * D + d] = dv * (1.0f + g[u] * (s - 1.0f));
+                dy[r * D + d] = dpre * s;
+                ds += dv * xv[u] * g[u] + dpre * yv[u];
+                cb[u] += dpre;
+            }
+        }
+        ds = bsum(ds, red);
+        if (threadIdx.x == 0) dscale[r] = ds;
+    }
+#pragma unroll
+    for (int u = 0; u < DPT; ++u) {
+        const int d = threadIdx.x + 256 * u;
+        if (d < D) {
+            ws[((long)blockIdx.x * 3 + 0) * D + d] = cb[u];
+            ws[((long)blockIdx.x * 3 + 1) * D + d] = cg[u];
+            ws[((long)blockIdx.x * 3 + 2) * D + d] = ce[u];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// interest match backward: one workgroup per (impression row b, candidate n), as the forward.  d g and d kp of row b
+// collect contributions from its N candidates: each workgroup writes its share to part_g / part_kp [b][n][H][.], which the
+// host sums over n (fixed order).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void interest_match_bwd_kernel(const float* __restrict__ kp, const float* __restrict__ qp,
+                                                                  const float* __restrict__ g, const float* __restrict__ cand,
+                                                                  const float* __restrict__ remaining, const float* __restrict__ dlogits,
+                                                                  float* __restrict__ dqp, float* __restrict__ dcand,
+                                                                  float* __restrict__ part_kp, float* __restrict__ part_g, int N, int H,
+                                                                  int A, int D, float scale, float alpha_s, float beta_s, int use_weight,
+                                                                  int use_penalty) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Qs = sm;                     // [A]
+    float* al = Qs + A;                 // [H] attention weights
+    float* dal = al + H;                // [H] d alpha, then d a
+    float* du = dal + H;                // [D]
+    float* red = du + D;                // [4]
+    const long bn = blockIdx.x;
+    const long b = bn / N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < A; e += 256) Qs[e] = qp[bn * A + e];
+    __syncthreads();
+    for (int h = wave; h < H; h += 4) {
+        const float* krow = kp + (b * H + h) * A;
+        float part = 0.f;
+        for (int j = lane; j < A; j += 64) part += krow[j] * Qs[j];
+        part = wave_sum(part);
+        if (lane == 0) al[h] = part * scale;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int h = threadIdx.x; h < H; h += 256) mx = fmaxf(mx, al[h]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float den = 0.f;
+    for (int h = threadIdx.x; h < H; h += 256) {
+        const float e = expf(al[h] - mx);
+        al[h] = e;
+        den += e;
+    }
+    const float inv = 1.0f / bsum(den, red);
+    for (int h = threadIdx.x; h < H; h += 256) al[h] *= inv;
+    float w = 1.0f;
+    if (use_weight) {
+        const float r = remaining[bn];
+        if (use_penalty) {
+            w = lime_sigmoid(alpha_s * r);
+            w = (r >= 0.f ? 1.f : 0.f) * w + (r < 0.f ? 1.f : 0.f) * beta_s * w;
+        } else {
+            w = lime_sigmoid(alpha_s * fabsf(r));
+        }
+    }
+    const float dbase = dlogits[bn] * w;
+    __syncthreads();
+    // u, d cand = dbase * u, d u = dbase * cand
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float u = 0.f;
+        for (int h = 0; h < H; ++h) u += al[h] * g[(b * H + h) * D + d];
+        dcand[bn * D + d] = dbase * u;
+        du[d] = dbase * cand[bn * D + d];
+    }
+    __syncthreads();
+    // d alpha_h = du . g[b, h, :]   and   this candidate's share of d g[b, h, :] = alpha_h du
+    for (int h = wave; h < H; h += 4) {
+        const float* grow = g + (b * H + h) * D;
+        float* pg = part_g + (bn * H + h) * D;
+        const float a = al[h];
+        float part = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            part += du[d] * grow[d];
+            pg[d] = a * du[d];
+        }
+        part = wave_sum(part);
+        if (lane == 0) dal[h] = part;
+    }
+    __syncthreads();
+    float mix = 0.f;
+    for (int h = threadIdx.x; h < H; h += 256) mix += al[h] * dal[h];
+    mix = bsum(mix, red);
+    for (int h = threadIdx.x; h < H; h += 256) dal[h] = al[h] * (dal[h] - mix) * scale;        // d (kp . q), scale folded in
+    __syncthreads();
+    // d kp share and d qp
+    for (int h = wave; h < H; h += 4) {
+        float* pk = part_kp + (bn * H + h) * A;
+        const float da = dal[h];
+        for (int j = lane; j < A; j += 64) pk[j] = da * Qs[j];
+    }
+    for (int j = threadIdx.x; j < A; j += 256) {
+        float s = 0.f;
+        for (int h = 0; h < H; ++h) s += dal[h] * kp[(b * H + h) * A + j];
+        dqp[bn * A + j] = s;
+    }
+}
+
+// out[b][c] = sum_n part[(b * N + n) * cols + c]
+__global__ __launch_bounds__(256) void sum_candidates_kernel(const float* __restrict__ part, float* __restrict__ out, long B, int N,
+                                                              long cols) {
+    const long total = B * cols;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long b = e / cols, c = e - b * cols;
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += part[(b * N + n) * cols + c];
+        out[e] = s;
+    }
+}
+
+int persistent_grid(long rows) { return (int)(rows < 256 ? (rows < 1 ? 1 : rows) : 256); }
+
+}  // namespace
+
+extern "C" int64_t lime_intent_fuse_bwd_workspace(int64_t M, int32_t A) { return (int64_t)persistent_grid(M) * 2 * A; }
+
+extern "C" int lime_intent_fuse_bwd_f32(const float* intents, const float* hidden, const float* aff2_title, const float* aff2_body,
+                                        const float* dcontent, int64_t ldc, float* d_intents, float* d_hidden, float* d_aff2_title,
+                                        float* d_aff2_body, int64_t M, int32_t k, int32_t D, int32_t A, float* workspace,
+                                        int64_t workspace_floats, void* stream) {
+    LIME_REQUIRE(intents && hidden && aff2_title && aff2_body && dcontent && d_intents && d_hidden && d_aff2_title && d_aff2_body &&
+                 workspace, LIME_ERR_BAD_ARG, "lime_intent_fuse_bwd_f32: null pointer");
+    LIME_REQUIRE(M >= 0 && k >= 1 && k <= MAX_INTENT && D > 0 && A > 0 && A <= 1024 && ldc >= 2 * D, LIME_ERR_BAD_ARG,
+                 "lime_intent_fuse_bwd_f32: bad dimensions (k <= %d, A <= 1024, ldc >= 2 D)", MAX_INTENT);
+    const int grid = persistent_grid(M);
+    LIME_REQUIRE(workspace_floats >= (int64_t)grid * 2 * A, LIME_ERR_BAD_ARG, "lime_intent_fuse_bwd_f32: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    if (M == 0) {
+        hipMemsetAsync(d_aff2_title, 0, (size_t)A * 4, s);
+        hipMemsetAsync(d_aff2_body, 0, (size_t)A * 4, s);
+        return LIME_OK;
+    }
+    intent_fuse_bwd_kernel<<<grid, 256, (4 * D + 4) * sizeof(float), s>>>(intents, hidden, aff2_title, aff2_body, dcontent, ldc, d_intents,
+                                                                         d_hidden, workspace, M, k, D, A);
+    int st = lime_check_launch("intent_fuse_bwd_kernel");
+    if (st != LIME_OK) return st;
+    reduce_rows_kernel<<<(A + 255) / 256, 256, 0, s>>>(workspace, 2L * A, grid, d_aff2_title, A, 0);
+    reduce_rows_kernel<<<(A + 255) / 256, 256, 0, s>>>(workspace + A, 2L * A, grid, d_aff2_body, A, 0);
+    return lime_check_launch("reduce_rows_kernel");
+}
+
+extern "C" int64_t lime_gate_ln_bwd_workspace(int64_t rows, int32_t D) { return (int64_t)persistent_grid(rows) * 3 * D; }
+
+extern "C" int lime_gate_ln_bwd_f32(const float* y, const float* x, const float* scale, const float* bias, const float* gamma,
+                                    const float* beta, float eps, const float* dout, float* dy, float* dx, float* dscale, float* dbias,
+                                    float* dgamma, float* dbeta, int64_t rows, int32_t D, float* workspace, int64_t workspace_floats,
+                                    void* stream) {
+    LIME_REQUIRE(y && x && scale && bias && gamma && beta && dout && dy && dx && dscale && dbias && dgamma && dbeta && workspace,
+                 LIME_ERR_BAD_ARG, "lime_gate_ln_bwd_f32: null pointer");
+    LIME_REQUIRE(rows >= 0 && D > 0 && D <= 1024, LIME_ERR_BAD_ARG, "lime_gate_ln_bwd_f32: bad dimensions (D <= 1024)");
+    const int grid = persistent_grid(rows);
+    LIME_REQUIRE(workspace_floats >= (int64_t)grid * 3 * D, LIME_ERR_BAD_ARG, "lime_gate_ln_bwd_f32: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    if (rows == 0) {
+        hipMemsetAsync(dbias, 0, (size_t)D * 4, s);
+        hipMemsetAsync(dgamma, 0, (size_t)D * 4, s);
+        hipMemsetAsync(dbeta, 0, (size_t)D * 4, s);
+        return LIME_OK;
+    }
+    gate_ln_bwd_kernel<<<grid, 256, 0, s>>>(y, x, scale, bias, gamma, beta, eps, dout, dy, dx, dscale, workspace, rows, D);
+    int st = lime_check_launch("gate_ln_bwd_kernel");
+    if (st != LIME_OK) return st;
+    float* outs[3] = {dbias, dgamma, dbeta};
+    for (int i = 0; i < 3; ++i) reduce_rows_kernel<<<(D + 255) / 256, 256, 0, s>>>(workspace + (long)i * D, 3L * D, grid, outs[i], D, 0);
+    return lime_check_launch("reduce_rows_kernel");
+}
+
+extern "C" int64_t lime_interest_match_bwd_workspace(int32_t B, int32_t N, int32_t H, int32_t A, int32_t D) {
+    return (int64_t)B * N * H * ((int64_t)A + D);
+}
+
+extern "C" int lime_interest_match_bwd_f32(const float* kp, const float* qp, const float* g, const float* cand, const float* remaining,
+                                           const float* dlogits, float* dkp, float* dqp, float* dg, float* dcand, int32_t B, int32_t N,
+                                           int32_t H, int32_t A, int32_t D, float scale, float alpha, float beta, int32_t use_weight,
+                                           int32_t use_penalty, float* workspace, int64_t workspace_floats, void* stream) {
+    LIME_REQUIRE(kp && qp && g && cand && dlogits && dkp && dqp && dg && dcand && workspace, LIME_ERR_BAD_ARG,
+                 "lime_interest_match_bwd_f32: null pointer");
+    LIME_REQUIRE(!use_weight || remaining, LIME_ERR_BAD_ARG, "lime_interest_match_bwd_f32: the lifetime weight needs `remaining`");
+    LIME_REQUIRE(B >= 0 && N > 0 && H > 0 && A > 0 && D > 0, LIME_ERR_BAD_ARG, "lime_interest_match_bwd_f32: bad dimensions");
+    LIME_REQUIRE((size_t)(A + 2 * H + D + 4) * sizeof(float) <= 64 * 1024, LIME_ERR_UNSUPPORTED, "lime_interest_match_bwd_f32: A + 2 H + D too large");
+    LIME_REQUIRE(workspace_floats >= lime_interest_match_bwd_workspace(B, N, H, A, D), LIME_ERR_BAD_ARG,
+                 "lime_interest_match_bwd_f32: workspace too small");
+    if (B == 0) return LIME_OK;
+    hipStream_t s = (hipStream_t)stream;
+    float* part_kp = workspace;
+    float* part_g = workspace + (int64_t)B * N * H * A;
+    interest_match_bwd_kernel<<<B * N, 256, (A + 2 * H + D + 4) * sizeof(float), s>>>(kp, qp, g, cand, remaining, dlogits, dqp, dcand, part_kp,
+                                                                                   part_g, N, H, A, D, scale, alpha, beta, use_weight,
+                                                                                   use_penalty);
+    int st = lime_check_launch("interest_match_bwd_kernel");
+    if (st != LIME_OK) return st;
+    const long ck = (long)H * A, cg = (long)H * D;
+    sum_candidates_kernel<<<(int)((B * ck + 255) / 256 > 4096 ? 4096 : (B * ck + 255) / 256), 256, 0, s>>>(part_kp, dkp, B, N, ck);
+    sum_candidates_kernel<<<(int)((B * cg + 255) / 256 > 4096 ? 4096 : (B * cg + 255) / 256), 256, 0, s>>>(part_g, dg, B, N, cg);
+    return lime_check_launch("sum_candidates_kernel");
+}

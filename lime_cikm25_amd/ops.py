@@ -792,3 +792,64 @@ def nll_softmax(logits, want_grad=True):
     check(lib.lime_nll_softmax_f32(_p(logits), _ld(logits), B, K, _p(loss), _p(d), _ld(d) if d is not None else K, _stream()),
           'lime_nll_softmax_f32')
     return loss, d
+
+
+# ---- backward of the fused tail kernels -----------------------------------------------------------------------------------
+def intent_fuse_bwd(intents, att_hidden, affine2_t, affine2_b, dcontent, M, k, D, A):
+    """-> (d_intents [2Mk, D], d_hidden [2Mk, A], d_affine2_title [A], d_affine2_body [A])."""
+    lib = _lib.load()
+    _mat(intents, 'intents')
+    _mat(att_hidden, 'att_hidden')
+    _mat(dcontent, 'dcontent')
+    if not (intents.is_contiguous() and att_hidden.is_contiguous()) or tuple(intents.shape) != (2 * M * k, D) or \
+            tuple(att_hidden.shape) != (2 * M * k, A) or dcontent.shape[0] != M or dcontent.shape[1] < 2 * D:
+        raise ValueError('intent_fuse_bwd: operand shapes')
+    dev = intents.device
+    d_int, d_hid = torch.empty_like(intents), torch.empty_like(att_hidden)
+    da_t, da_b = torch.empty(A, dtype=torch.float32, device=dev), torch.empty(A, dtype=torch.float32, device=dev)
+    ws = _workspace(dev, lib.lime_intent_fuse_bwd_workspace(M, A))
+    check(lib.lime_intent_fuse_bwd_f32(_p(intents), _p(att_hidden), _p(_vec(affine2_t, 'affine2_t', A)), _p(_vec(affine2_b, 'affine2_b', A)),
+                                       _p(dcontent), _ld(dcontent), _p(d_int), _p(d_hid), _p(da_t), _p(da_b), M, k, D, A, _p(ws),
+                                       ws.numel(), _stream()), 'lime_intent_fuse_bwd_f32')
+    return d_int, d_hid, da_t, da_b
+
+
+def gate_ln_bwd(y, x, scale, bias, gamma, beta, eps, dout):
+    """-> (dy, dx, dscale [rows], dbias, dgamma, dbeta) of ``gate_ln``; y / x / dout: contiguous [rows, D]."""
+    lib = _lib.load()
+    D = x.shape[-1]
+    x = _vec(x.contiguous(), 'x')
+    rows = x.numel() // D
+    y = _vec(y.contiguous(), 'y', x.numel())
+    dout = _vec(dout.contiguous(), 'dout', x.numel())
+    dev = x.device
+    dy, dx = torch.empty_like(x), torch.empty_like(x)
+    dscale = torch.empty(rows, dtype=torch.float32, device=dev)
+    dbias, dgamma, dbeta = (torch.empty(D, dtype=torch.float32, device=dev) for _ in range(3))
+    ws = _workspace(dev, lib.lime_gate_ln_bwd_workspace(rows, D))
+    check(lib.lime_gate_ln_bwd_f32(_p(y), _p(x), _p(_vec(scale.contiguous(), 'scale', rows)), _p(_vec(bias, 'bias', D)),
+                                   _p(_vec(gamma, 'gamma', D)), _p(_vec(beta, 'beta', D)), eps, _p(dout), _p(dy), _p(dx), _p(dscale),
+                                   _p(dbias), _p(dgamma), _p(dbeta), rows, D, _p(ws), ws.numel(), _stream()), 'lime_gate_ln_bwd_f32')
+    return dy, dx, dscale, dbias, dgamma, dbeta
+
+
+def interest_match_bwd(kp, qp, g, cand, remaining, dlogits, B, N, H, A, D, scale, alpha, beta, use_weight, use_penalty):
+    """-> (dkp [B*H, A], dqp [B*N, A], dg [B*H, D], dcand [B*N, D])."""
+    lib = _lib.load()
+    _vec(kp, 'kp', B * H * A)
+    _vec(qp, 'qp', B * N * A)
+    _vec(g, 'g', B * H * D)
+    _vec(cand, 'cand', B * N * D)
+    dlogits = _vec(dlogits.contiguous(), 'dlogits', B * N)
+    if use_weight:
+        remaining = _vec(remaining.contiguous(), 'remaining', B * N)
+    dev = kp.device
+    dkp = torch.empty((B * H, A), dtype=torch.float32, device=dev)
+    dqp = torch.empty((B * N, A), dtype=torch.float32, device=dev)
+    dg = torch.empty((B * H, D), dtype=torch.float32, device=dev)
+    dcand = torch.empty((B * N, D), dtype=torch.float32, device=dev)
+    ws = _workspace(dev, lib.lime_interest_match_bwd_workspace(B, N, H, A, D))
+    check(lib.lime_interest_match_bwd_f32(_p(kp), _p(qp), _p(g), _p(cand), _p(remaining) if use_weight else None, _p(dlogits), _p(dkp),
+                                          _p(dqp), _p(dg), _p(dcand), B, N, H, A, D, scale, alpha, beta, int(use_weight),
+                                          int(use_penalty), _p(ws), ws.numel(), _stream()), 'lime_interest_match_bwd_f32')
+    return dkp, dqp, dg, dcand

@@ -8,9 +8,10 @@ Where the arithmetic runs
     with the LayerNorm rstd kept, backward = LayerNorm / attention / ReLU backward kernels, the MFMA weight-gradient GEMM,
     input gradients on lime_linear_f32 with transposed weights, word-table scatter-add.
   * every nn.Linear of the tail and the user encoder: ``_Linear`` (HIP GEMMs forward and backward).
-  * the small element-wise / softmax glue between them (intent attention, cosine similarity, candidate-aware weights,
-    gated LayerNorm, GraphSAGE mean, history-vs-candidate softmax, lifetime weight): torch ops on the device with torch's
-    autograd.  The fused scoring kernels of that glue have no hand-written backward yet.
+  * the fused tail kernels of the scoring path with hand-written backward kernels (csrc/tail_backward_f32.hip): intent attention
+    + cosine similarity + concat, gated residual + LayerNorm, history-vs-candidate attention + dot product + lifetime weight.
+  * still torch ops with torch's autograd: the candidate-aware attention weights (three small softmaxes over topic
+    projections, with the p = 0.2 dropout of layers.py:74), the GraphSAGE mean and a few concatenations.
 
 Dropout (the reference trains with dropout_rate 0.2): the six dropouts inside a token encoder run on the dropout kernels
 with counter-based masks (csrc/dropout.h; torch's Philox stream is not reproduced -- the arithmetic is pinned against a torch
@@ -102,6 +103,69 @@ def embedding(table, idx):
         out = torch.empty((flat.numel(), table.shape[1]), dtype=torch.float32, device=table.device)
         ops.gather_rows(flat, table, out)
     return out.view(*idx.shape, table.shape[1])
+
+
+class _IntentFuse(torch.autograd.Function):
+    """[title_i | sim * body_i] [M, 2D] from the k intents of title and body (newsEncoders.py:355-371) on the fused kernel."""
+
+    @staticmethod
+    def forward(ctx, intents, hidden, a2_t, a2_b, M, k):
+        D, A = intents.shape[1], hidden.shape[1]
+        intents, hidden = intents.contiguous(), hidden.contiguous()
+        a2_t, a2_b = a2_t.reshape(-1).contiguous(), a2_b.reshape(-1).contiguous()
+        out = torch.empty((M, 2 * D), dtype=torch.float32, device=intents.device)
+        ops.intent_fuse(intents, hidden, a2_t, a2_b, out, M, k, D, A)
+        ctx.dims = (M, k, D, A)
+        ctx.save_for_backward(intents, hidden, a2_t, a2_b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        intents, hidden, a2_t, a2_b = ctx.saved_tensors
+        M, k, D, A = ctx.dims
+        d_int, d_hid, da_t, da_b = ops.intent_fuse_bwd(intents, hidden, a2_t, a2_b, dout.contiguous(), M, k, D, A)
+        return d_int, d_hid, da_t, da_b, None, None
+
+
+class _GateLN(torch.autograd.Function):
+    """LayerNorm(g s x + (1 - g) x), g = sigmoid(s y + bias) (layers.py:84-89); y = W_g x comes from the caller's GEMM."""
+
+    @staticmethod
+    def forward(ctx, y, x, scale, bias, gamma, beta, eps):
+        y, x, scale = y.contiguous(), x.contiguous(), scale.contiguous()
+        out = ops.gate_ln(y, x, scale, bias, gamma, beta, eps)
+        ctx.eps = eps
+        ctx.save_for_backward(y, x, scale, bias, gamma, beta)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, x, scale, bias, gamma, beta = ctx.saved_tensors
+        dy, dx, dscale, dbias, dgamma, dbeta = ops.gate_ln_bwd(y, x, scale, bias, gamma, beta, ctx.eps, dout)
+        return dy.view_as(y), dx.view_as(x), dscale.view_as(scale), dbias, dgamma, dbeta, None
+
+
+class _InterestMatch(torch.autograd.Function):
+    """logits [B, N] = (softmax_h(kp . qp / sqrt(A)) g) . cand * lifetime weight (userEncoders.py:158-169, util.py:23-49)."""
+
+    @staticmethod
+    def forward(ctx, kp, qp, g, cand, remaining, dims, scale, alpha, beta, use_weight, use_penalty):
+        B, N, H, A, D = dims
+        kp, qp, g, cand = kp.contiguous(), qp.contiguous(), g.contiguous(), cand.contiguous()
+        remaining = remaining.contiguous()
+        _, logits = ops.interest_match(kp.view(-1), qp.view(-1), g.view(-1), cand.view(-1), remaining, B, N, H, A, D, scale, alpha, beta,
+                                       use_weight, use_penalty, want_logits=True, want_user=False)
+        ctx.cfg = (dims, scale, alpha, beta, use_weight, use_penalty)
+        ctx.save_for_backward(kp, qp, g, cand, remaining)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        kp, qp, g, cand, remaining = ctx.saved_tensors
+        (B, N, H, A, D), scale, alpha, beta, use_weight, use_penalty = ctx.cfg
+        dkp, dqp, dg, dcand = ops.interest_match_bwd(kp.view(-1), qp.view(-1), g.view(-1), cand.view(-1), remaining, dlogits, B, N, H, A, D,
+                                                     scale, alpha, beta, use_weight, use_penalty)
+        return dkp.view_as(kp), dqp.view_as(qp), dg.view_as(g), dcand.view_as(cand), None, None, None, None, None, None, None
 
 
 def _unpad_heads(t, groups, hd, hs):
@@ -262,14 +326,14 @@ def crown_tail(enc, title_p, body_p, category, subCategory):
     b_int = torch.cat([lin.bias for lin in enc.intent_layers], dim=0)
     k, D = enc.intent_num, enc.intent_embedding_dim
 
-    def intents(pooled):                                                                                        # :284-295
-        x = torch.cat([pooled, cat_rep], dim=1)
-        return _Linear.apply(x, w_int, b_int, 'relu').view(-1, k, D)
-
-    title_i = _additive_attention(enc.title_intent_attention, intents(title_p))                                 # :355
-    body_i = _additive_attention(enc.body_intent_attention, intents(body_p))                                    # :356
-    sim = (F.cosine_similarity(title_i, body_i, dim=1) + 1) / 2.0                                               # :297-300
-    return torch.cat([title_i, sim.unsqueeze(1) * body_i, enc.dropout(cat_e.clone()), enc.dropout(sub_e.clone())], dim=1)   # :221-225
+    M = title_p.shape[0]
+    xin = torch.cat([torch.cat([title_p, cat_rep], dim=1), torch.cat([body_p, cat_rep], dim=1)], dim=0)         # :343-344
+    iv = _Linear.apply(xin, w_int, b_int, 'relu').view(2 * M * k, D)                                            # :284-295
+    hidden = torch.cat([linear(iv[:M * k], enc.title_intent_attention.affine1, act='tanh'),
+                        linear(iv[M * k:], enc.body_intent_attention.affine1, act='tanh')], dim=0)              # layers.py:288
+    fused = _IntentFuse.apply(iv, hidden, enc.title_intent_attention.affine2.weight.view(-1),
+                              enc.body_intent_attention.affine2.weight.view(-1), M, k)                                                                             # :355-371
+    return torch.cat([fused, enc.dropout(cat_e.clone()), enc.dropout(sub_e.clone())], dim=1)                    # :221-225
 
 
 def pooled_tokens(ne, title_text, content_text):
@@ -316,16 +380,18 @@ def candidate_aware(att, hist, hist_topic, cand_topic, mask):
     a = att.dropout(torch.softmax(s, dim=-1))
     qw = torch.softmax(torch.norm(Q.transpose(1, 2).reshape(B, N, -1), dim=-1), dim=1)
     agg = torch.softmax((a.sum(dim=1) * qw.unsqueeze(-1)).sum(dim=1), dim=-1)
-    wc = agg.unsqueeze(-1) * hist
     if not att.use_residual_connection:
-        return wc
-    gate = linear(wc, att.gate_proj, act='sigmoid')
+        return agg.unsqueeze(-1) * hist
     ln = att.layernorm
-    return F.layer_norm(gate * wc + (1 - gate) * hist, (D,), ln.weight, ln.bias, ln.eps)
+    flat = hist.reshape(B * H, D)
+    y = _Linear.apply(flat, att.gate_proj.weight, None, None)                       # W_g x; the row scale agg commutes (:87)
+    return _GateLN.apply(y, flat, agg.reshape(-1), att.gate_proj.bias, ln.weight, ln.bias, ln.eps).view(B, H, D)
 
 
-def user_match(ue, hist, cand, category, subCategory, user_category, user_subCategory, user_history_mask, n_src=None):
-    """userEncoders.CROWN.forward after the history is encoded (userEncoders.py:103-105, :114-169) -> user [B, N, D]."""
+def user_logits(ue, weighting, hist, cand, category, subCategory, user_category, user_subCategory, user_history_mask,
+                remaining_lifetime, n_src=None):
+    """userEncoders.CROWN.forward after the history is encoded (userEncoders.py:103-105, :114-169) and the lifetime-weighted dot
+    product of model.py:181 / util.py:23-49 -> logits [B, N]."""
     B, H, D = hist.shape
     N = cand.shape[1]
     ne = ue.news_encoder
@@ -341,18 +407,11 @@ def user_match(ue, hist, cand, category, subCategory, user_category, user_subCat
     g = linear(X[:, :n_src].mean(dim=1), conv.lin_l).unsqueeze(1) + linear(hist, conv.lin_r)                      # :151-157
     kp = linear(g, ue.K)                                                                                         # :161
     qp = linear(cand, ue.Q)                                                                                      # :162
-    a = torch.matmul(qp, kp.transpose(1, 2)) / ue.attention_scalar                                               # [B, N, H]
-    return torch.matmul(torch.softmax(a, dim=-1), g)                                                             # :164-168
-
-
-def lifetime_weight(w, remaining):
-    """RemainingLifetimeWeighting (util.py:23-49): the factor on the dot product, a constant of the parameters."""
-    if not w.use_remaining_lifetime_weighting:
-        return None
-    if w.use_expired_penalty:
-        s = torch.sigmoid(w.alpha * remaining)
-        return torch.where(remaining >= 0, s, w.beta * s)
-    return torch.sigmoid(w.alpha * remaining.abs())
+    A = kp.shape[-1]
+    w = weighting
+    return _InterestMatch.apply(kp.reshape(B * H, A), qp.reshape(B * N, A), g.reshape(B * H, D), cand.reshape(B * N, D),
+                                remaining_lifetime, (B, N, H, A, D), 1.0 / ue.attention_scalar, float(w.alpha), float(w.beta),
+                                bool(w.use_remaining_lifetime_weighting), bool(w.use_expired_penalty))               # :163-168
 
 
 def tail_forward(model, title_p, body_p, category, subCategory, freshness, lifetime, news_category, news_subCategory, user_category,
@@ -366,11 +425,8 @@ def tail_forward(model, title_p, body_p, category, subCategory, freshness, lifet
     rep = lime_tail(model.news_encoder, title_p, body_p, category, subCategory, freshness, lifetime)
     cand = rep[:B * N].view(B, N, -1)
     hist = rep[B * N:].view(B, H, -1)
-    user = user_match(model.user_encoder, hist, cand, news_category, news_subCategory, user_category, user_subCategory,
-                      user_history_mask)
-    logits = (user * cand).sum(dim=-1)                                                                            # util.py:37
-    w = lifetime_weight(model.remaining_lifetime_weighting, remaining_lifetime)
-    return logits if w is None else logits * w
+    return user_logits(model.user_encoder, model.remaining_lifetime_weighting, hist, cand, news_category, news_subCategory,
+                       user_category, user_subCategory, user_history_mask, remaining_lifetime)
 
 
 def forward_train(model, user_category, user_subCategory, user_title_text, user_content_text, user_freshness,

@@ -179,3 +179,73 @@ def test_clip_and_adam_follow_torch(ops):
         close(coef[:1], norm.reshape(1), what='grad norm')
         ops.adam_step_(p, gg, m, v, step, 1e-3, grad_scale=coef[1:])
         close(p, ref.detach(), tol=1e-5, what='parameters after step %d' % step)
+
+
+# ---- backward of the fused tail kernels (csrc/tail_backward_f32.hip) against torch fp64 autograd of the same stage -----------
+@pytest.mark.parametrize('M,k,D,A', [(7, 3, 400, 400), (300, 3, 400, 400), (5, 2, 64, 48)])
+def test_intent_fuse_bwd(ops, M, k, D, A):
+    iv, hid = rnd(2 * M * k, D, seed=1), torch.tanh(rnd(2 * M * k, A, seed=2))
+    a2t, a2b = rnd(A, seed=3, scale=0.2), rnd(A, seed=4, scale=0.2)
+    dcontent = rnd(M, 2 * D, seed=5)
+    x, h, wt, wb = (t.double().requires_grad_() for t in (iv, hid, a2t, a2b))
+
+    def pool(xx, hh, w):
+        alpha = torch.softmax((hh.view(M, k, A) * w).sum(-1), dim=1)
+        return (alpha.unsqueeze(-1) * xx.view(M, k, D)).sum(1)
+    t, b = pool(x[:M * k], h[:M * k], wt), pool(x[M * k:], h[M * k:], wb)
+    sim = (F.cosine_similarity(t, b, dim=1) + 1) / 2
+    content = torch.cat([t, sim.unsqueeze(1) * b], dim=1)
+    content.backward(dcontent.double())
+    out = torch.empty(M, 2 * D, device='cuda')
+    ops.intent_fuse(iv.cuda(), hid.cuda(), a2t.cuda(), a2b.cuda(), out, M, k, D, A)
+    close(out, content.detach().float(), what='intent_fuse forward')
+    d_int, d_hid, da_t, da_b = ops.intent_fuse_bwd(iv.cuda(), hid.cuda(), a2t.cuda(), a2b.cuda(), dcontent.cuda(), M, k, D, A)
+    close(d_int, x.grad.float(), tol=2e-4, what='d intents')
+    close(d_hid, h.grad.float(), tol=2e-4, what='d hidden')
+    close(da_t, wt.grad.float(), tol=2e-4, what='d affine2 title')
+    close(da_b, wb.grad.float(), tol=2e-4, what='d affine2 body')
+
+
+@pytest.mark.parametrize('rows,D', [(13, 400), (1600, 400), (9, 70)])
+def test_gate_ln_bwd(ops, rows, D):
+    y, x = rnd(rows, D, seed=1), rnd(rows, D, seed=2)
+    s = torch.softmax(rnd(rows, seed=3), dim=0) * 5
+    bias, gamma, beta = rnd(D, seed=4, scale=0.3), rnd(D, seed=5, scale=0.3) + 1, rnd(D, seed=6, scale=0.3)
+    dout = rnd(rows, D, seed=7)
+    yd, xd, sd, bd, gd, ed = (t.double().requires_grad_() for t in (y, x, s, bias, gamma, beta))
+    g = torch.sigmoid(sd.unsqueeze(1) * yd + bd)
+    wc = sd.unsqueeze(1) * xd
+    out = F.layer_norm(g * wc + (1 - g) * xd, (D,), gd, ed, 1e-5)
+    out.backward(dout.double())
+    c = lambda t: t.cuda()
+    got = ops.gate_ln_bwd(c(y), c(x), c(s), c(bias), c(gamma), c(beta), 1e-5, c(dout))
+    for name, a, b in zip(('dy', 'dx', 'dscale', 'dbias', 'dgamma', 'dbeta'), got, (yd, xd, sd, bd, gd, ed)):
+        close(a.view(b.shape), b.grad.float(), tol=2e-4, what=name)
+
+
+@pytest.mark.parametrize('B,N,H,A,D,penalty', [(3, 5, 50, 400, 400, True), (32, 5, 50, 400, 400, True), (2, 1, 7, 64, 48, False)])
+def test_interest_match_bwd(ops, B, N, H, A, D, penalty):
+    kp, qp = rnd(B * H, A, seed=1, scale=0.3), rnd(B * N, A, seed=2, scale=0.3)
+    g, cand = rnd(B * H, D, seed=3), rnd(B * N, D, seed=4)
+    remaining = rnd(B, N, seed=5, scale=8.0)
+    dlogits = rnd(B, N, seed=6)
+    alpha, beta, scale = 0.3, 0.3, 1.0 / math.sqrt(A)
+    kd, qd, gd, cd = (t.double().requires_grad_() for t in (kp, qp, g, cand))
+    a = torch.einsum('bha,bna->bnh', kd.view(B, H, A), qd.view(B, N, A)) * scale
+    u = torch.softmax(a, dim=-1) @ gd.view(B, H, D)
+    base = (u * cd.view(B, N, D)).sum(-1)
+    r = remaining.double()
+    if penalty:
+        w = torch.sigmoid(alpha * r)
+        w = torch.where(r >= 0, w, beta * w)
+    else:
+        w = torch.sigmoid(alpha * r.abs())
+    (base * w).backward(dlogits.double())
+    c = lambda t: t.cuda()
+    _, logits = ops.interest_match(c(kp).view(-1), c(qp).view(-1), c(g).view(-1), c(cand).view(-1), c(remaining), B, N, H, A, D, scale,
+                                   alpha, beta, True, penalty, want_user=False)
+    close(logits, (base * w).detach().float(), what='interest_match forward')
+    got = ops.interest_match_bwd(c(kp).view(-1), c(qp).view(-1), c(g).view(-1), c(cand).view(-1), c(remaining), c(dlogits), B, N, H, A, D,
+                                 scale, alpha, beta, True, penalty)
+    for name, x, ref in zip(('dkp', 'dqp', 'dg', 'dcand'), got, (kd, qd, gd, cd)):
+        close(x, ref.grad.float(), tol=2e-4, what=name)
