@@ -21,14 +21,22 @@ __device__ __forceinline__ float bsum(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-// out[c] (+)= sum_s part[s * stride + c]: one thread per column chunk, fixed order
+// out[c] (+)= sum_s part[s * stride + c].  A workgroup owns 64 columns; its four waves take the splits s = wave, wave + 4, ...
+// (coalesced 256-byte reads) and the four sums are added in a fixed order.
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, long stride, int splits, float* __restrict__ out,
                                                            int cols, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int i = 0; i < splits; ++i) s += part[(long)i * stride + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < cols)
+        for (int i = g; i < splits; i += 4) s += part[(long)i * stride + c];
+    red[g][lane] = s;
+    __syncthreads();
+    if (g == 0 && c < cols) {
+        const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -362,8 +370,8 @@ extern "C" int lime_intent_fuse_bwd_f32(const float* intents, const float* hidde
                                                                          d_hidden, workspace, M, k, D, A);
     int st = lime_check_launch("intent_fuse_bwd_kernel");
     if (st != LIME_OK) return st;
-    reduce_rows_kernel<<<(A + 255) / 256, 256, 0, s>>>(workspace, 2L * A, grid, d_aff2_title, A, 0);
-    reduce_rows_kernel<<<(A + 255) / 256, 256, 0, s>>>(workspace + A, 2L * A, grid, d_aff2_body, A, 0);
+    reduce_rows_kernel<<<(A + 63) / 64, 256, 0, s>>>(workspace, 2L * A, grid, d_aff2_title, A, 0);
+    reduce_rows_kernel<<<(A + 63) / 64, 256, 0, s>>>(workspace + A, 2L * A, grid, d_aff2_body, A, 0);
     return lime_check_launch("reduce_rows_kernel");
 }
 
@@ -389,7 +397,7 @@ extern "C" int lime_gate_ln_bwd_f32(const float* y, const float* x, const float*
     int st = lime_check_launch("gate_ln_bwd_kernel");
     if (st != LIME_OK) return st;
     float* outs[3] = {dbias, dgamma, dbeta};
-    for (int i = 0; i < 3; ++i) reduce_rows_kernel<<<(D + 255) / 256, 256, 0, s>>>(workspace + (long)i * D, 3L * D, grid, outs[i], D, 0);
+    for (int i = 0; i < 3; ++i) reduce_rows_kernel<<<(D + 63) / 64, 256, 0, s>>>(workspace + (long)i * D, 3L * D, grid, outs[i], D, 0);
     return lime_check_launch("reduce_rows_kernel");
 }
 
