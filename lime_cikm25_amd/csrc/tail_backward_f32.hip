@@ -362,8 +362,8 @@ extern "C" int lime_intent_fuse_bwd_f32(const float* intents, const float* hidde
     LIME_REQUIRE(workspace_floats >= (int64_t)grid * 2 * A, LIME_ERR_BAD_ARG, "lime_intent_fuse_bwd_f32: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     if (M == 0) {
-        hipMemsetAsync(d_aff2_title, 0, (size_t)A * 4, s);
-        hipMemsetAsync(d_aff2_body, 0, (size_t)A * 4, s);
+        (void)hipMemsetAsync(d_aff2_title, 0, (size_t)A * 4, s);
+        (void)hipMemsetAsync(d_aff2_body, 0, (size_t)A * 4, s);
         return LIME_OK;
     }
     intent_fuse_bwd_kernel<<<grid, 256, (4 * D + 4) * sizeof(float), s>>>(intents, hidden, aff2_title, aff2_body, dcontent, ldc, d_intents,
@@ -388,9 +388,9 @@ extern "C" int lime_gate_ln_bwd_f32(const float* y, const float* x, const float*
     LIME_REQUIRE(workspace_floats >= (int64_t)grid * 3 * D, LIME_ERR_BAD_ARG, "lime_gate_ln_bwd_f32: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     if (rows == 0) {
-        hipMemsetAsync(dbias, 0, (size_t)D * 4, s);
-        hipMemsetAsync(dgamma, 0, (size_t)D * 4, s);
-        hipMemsetAsync(dbeta, 0, (size_t)D * 4, s);
+        (void)hipMemsetAsync(dbias, 0, (size_t)D * 4, s);
+        (void)hipMemsetAsync(dgamma, 0, (size_t)D * 4, s);
+        (void)hipMemsetAsync(dbeta, 0, (size_t)D * 4, s);
         return LIME_OK;
     }
     gate_ln_bwd_kernel<<<grid, 256, 0, s>>>(y, x, scale, bias, gamma, beta, eps, dout, dy, dx, dscale, workspace, rows, D);
