@@ -441,6 +441,16 @@ int lime_interest_match_bwd_f32(const float* kp, const float* qp, const float* g
                                 int32_t H, int32_t A, int32_t D, float scale, float alpha, float beta, int32_t use_weight,
                                 int32_t use_penalty, float* workspace, int64_t workspace_floats, void* stream);
 
+/* Candidate-aware attention weights (layers.py:66-81) in training mode: as lime_cand_attn_weights_f32 with the dropout of
+ * layers.py:74 on the per-head probabilities (mask element ((b * n_head + h) * N + n) * H + j; dropout_p = 0: none), and its
+ * backward from dagg [B, H] to dqp [B, N, D] / dkp [B, H, D] (the same dropout_p / seed / site regenerate the mask).
+ * N <= 16, H <= 256; Q, K and the probabilities of one impression row live in LDS. */
+int lime_cand_attn_weights_train_f32(const float* qp, const float* kp, const uint8_t* mask, float* agg, int32_t B, int32_t N, int32_t H,
+                                     int32_t D, int32_t n_head, float dropout_p, uint64_t seed, uint32_t site, void* stream);
+int lime_cand_attn_weights_bwd_f32(const float* qp, const float* kp, const uint8_t* mask, const float* dagg, float* dqp, float* dkp,
+                                   int32_t B, int32_t N, int32_t H, int32_t D, int32_t n_head, float dropout_p, uint64_t seed,
+                                   uint32_t site, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -140,6 +140,10 @@ SIGNATURES = {
     'lime_interest_match_bwd_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_int32,
                                               c_int32, c_void_p, c_int64, c_void_p]),
+    'lime_cand_attn_weights_train_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                                   c_float, c_uint64, c_uint32, c_void_p]),
+    'lime_cand_attn_weights_bwd_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                                 c_int32, c_int32, c_float, c_uint64, c_uint32, c_void_p]),
     'lime_nll_softmax_f32': (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
 }
 

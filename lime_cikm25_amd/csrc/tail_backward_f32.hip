@@ -6,7 +6,10 @@
 //   intent_fuse_bwd_kernel      layers.Attention over the k intents + cosine similarity + concat   (newsEncoders.py:355-371)
 //   gate_ln_bwd_kernel          gated residual + LayerNorm of CandidateAware_ClickedNewsAttention  (layers.py:84-89)
 //   interest_match_bwd_kernel   history-vs-candidate attention + dot product + lifetime weight     (userEncoders.py:158-169, util.py:23-49)
+//   cand_attn_train_kernel      candidate-aware attention weights, forward WITH the p = 0.2 dropout of layers.py:74 (training
+//                               mode) and backward                                                 (layers.py:66-81)
 #include "common.h"
+#include "dropout.h"
 
 namespace {
 
@@ -332,6 +335,183 @@ __global__ __launch_bounds__(256) void interest_match_bwd_kernel(const float* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// candidate-aware attention weights in training mode.  One workgroup per impression row b.
+//   s[h, n, j] = Q[n, h] . K[j, h] / sqrt(D), -1e9 where mask[j] == 0;  a = softmax_j(s);  ad = dropout(a)   (layers.py:70-74)
+//   qw = softmax_n(|Q_n|_2);  pre[j] = sum_n qw[n] sum_h ad[h, n, j];  agg = softmax_j(pre)                  (:79-81)
+// mode 0 writes agg; mode 1 recomputes the above and writes dQ [N, D], dK [H, D] from d agg.
+// LDS: Q [N D], K [H D], a and ad [n_head N H] each, a few vectors.  H <= 256 (one to four keys per lane), N <= 16.
+// ---------------------------------------------------------------------------------------------------
+constexpr int CA_MAXN = 16;
+
+__global__ __launch_bounds__(256) void cand_attn_train_kernel(const float* __restrict__ qp, const float* __restrict__ kp,
+                                                               const unsigned char* __restrict__ mask, const float* __restrict__ dagg,
+                                                               float* __restrict__ agg_out, float* __restrict__ dqp, float* __restrict__ dkp,
+                                                               int N, int H, int D, int n_head, float inv_scale, LimeDropout drop,
+                                                               int mode) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int hd = D / n_head;
+    float* Qs = sm;                              // [N][D]
+    float* Ks = Qs + N * D;                      // [H][D]
+    float* As = Ks + H * D;                      // [n_head][N][H]  a, later ds
+    float* Ad = As + n_head * N * H;             // [n_head][N][H]  dropped a, later the dropout factor
+    float* pre = Ad + n_head * N * H;            // [H]  pre, then agg, then dpre
+    float* qn = pre + H;                         // [CA_MAXN] norms
+    float* qw = qn + CA_MAXN;                    // [CA_MAXN]
+    float* tn = qw + CA_MAXN;                    // [CA_MAXN] scratch per candidate
+    float* red = tn + CA_MAXN;                   // [4]
+    const long b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < N * D; e += 256) Qs[e] = qp[b * N * D + e];
+    for (int e = tid; e < H * D; e += 256) Ks[e] = kp[b * H * D + e];
+    __syncthreads();
+    // rows (h, n) of the score tensor: a wave per row, lanes over the keys
+    for (int row = wave; row < n_head * N; row += 4) {
+        const int h = row / N, n = row - h * N;
+        const float* qv = Qs + n * D + h * hd;
+        float sv[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = lane + 64 * u;
+            float d = -INFINITY;
+            if (j < H) {
+                d = 0.f;
+                const float* kv = Ks + j * D + h * hd;
+                for (int e = 0; e < hd; ++e) d += qv[e] * kv[e];
+                d = mask[b * H + j] ? d * inv_scale : -1e9f;
+            }
+            sv[u] = d;
+            mx = fmaxf(mx, d);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            sv[u] = (lane + 64 * u < H) ? expf(sv[u] - mx) : 0.f;
+            sum += sv[u];
+        }
+        const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = lane + 64 * u;
+            if (j < H) {
+                const float a = sv[u] * inv;
+                const float f = (drop.thresh == 0 || lime_keep(drop, (uint64_t)(((b * n_head + h) * N + n) * (long)H + j))) ? drop.scale : 0.f;
+                As[row * H + j] = a;
+                Ad[row * H + j] = a * f;
+            }
+        }
+    }
+    // candidate norms and their softmax
+    for (int n = wave; n < N; n += 4) {
+        float part = 0.f;
+        for (int e = lane; e < D; e += 64) part += Qs[n * D + e] * Qs[n * D + e];
+        part = wave_sum(part);
+        if (lane == 0) qn[n] = sqrtf(part);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float mx = -INFINITY, den = 0.f;
+        for (int n = 0; n < N; ++n) mx = fmaxf(mx, qn[n]);
+        for (int n = 0; n < N; ++n) { qw[n] = expf(qn[n] - mx); den += qw[n]; }
+        for (int n = 0; n < N; ++n) qw[n] /= den;
+    }
+    __syncthreads();
+    for (int j = tid; j < H; j += 256) {
+        float p = 0.f;
+        for (int n = 0; n < N; ++n) {
+            float hsum = 0.f;
+            for (int h = 0; h < n_head; ++h) hsum += Ad[(h * N + n) * H + j];
+            p += qw[n] * hsum;
+        }
+        pre[j] = p;
+    }
+    __syncthreads();
+    {   // agg = softmax_j(pre)
+        float mx = -INFINITY;
+        for (int j = tid; j < H; j += 256) mx = fmaxf(mx, pre[j]);
+        mx = wave_max(mx);
+        __syncthreads();
+        if (lane == 0) red[wave] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float den = 0.f;
+        for (int j = tid; j < H; j += 256) den += expf(pre[j] - mx);
+        den = bsum(den, red);
+        for (int j = tid; j < H; j += 256) pre[j] = expf(pre[j] - mx) / den;
+    }
+    __syncthreads();
+    if (mode == 0) {
+        for (int j = tid; j < H; j += 256) agg_out[b * H + j] = pre[j];
+        return;
+    }
+    // ---- backward ------------------------------------------------------------------------------------------------
+    float mix = 0.f;
+    for (int j = tid; j < H; j += 256) mix += pre[j] * dagg[b * H + j];
+    mix = bsum(mix, red);
+    for (int j = tid; j < H; j += 256) pre[j] = pre[j] * (dagg[b * H + j] - mix);             // d pre
+    __syncthreads();
+    // d qw[n] = sum_j dpre[j] sum_h ad[h, n, j]
+    for (int n = wave; n < N; n += 4) {
+        float part = 0.f;
+        for (int j = lane; j < H; j += 64) {
+            float hsum = 0.f;
+            for (int h = 0; h < n_head; ++h) hsum += Ad[(h * N + n) * H + j];
+            part += pre[j] * hsum;
+        }
+        part = wave_sum(part);
+        if (lane == 0) tn[n] = part;
+    }
+    __syncthreads();
+    if (tid == 0) {                                                  // softmax over the candidates, then the norm
+        float m2 = 0.f;
+        for (int n = 0; n < N; ++n) m2 += qw[n] * tn[n];
+        for (int n = 0; n < N; ++n) {
+            const float dqn = qw[n] * (tn[n] - m2);
+            tn[n] = qn[n] > 0.f ? dqn / qn[n] : 0.f;                   // factor on Q_n
+        }
+    }
+    __syncthreads();
+    // d s[h, n, :] = a (d a - sum_j a d a), d a = qw[n] dpre[j] * dropout factor; masked keys are constants
+    for (int row = wave; row < n_head * N; row += 4) {
+        const int n = row % N;
+        float da[4];
+        float part = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = lane + 64 * u;
+            da[u] = 0.f;
+            if (j < H) {
+                const float a = As[row * H + j];
+                const float f = a > 0.f ? Ad[row * H + j] / a : 0.f;  // the dropout factor (0 or 1 / (1 - p)); a = 0 carries no gradient
+                da[u] = qw[n] * pre[j] * f;
+                part += a * da[u];
+            }
+        }
+        part = wave_sum(part);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = lane + 64 * u;
+            if (j < H) As[row * H + j] = mask[b * H + j] ? As[row * H + j] * (da[u] - part) * inv_scale : 0.f;
+        }
+    }
+    __syncthreads();
+    // d Q[n, h hd + e] = sum_j ds[h, n, j] K[j, .] + dnorm factor * Q;   d K[j, h hd + e] = sum_n ds[h, n, j] Q[n, .]
+    for (int e = tid; e < N * D; e += 256) {
+        const int n = e / D, c = e - n * D, h = c / hd;
+        float s2 = 0.f;
+        for (int j = 0; j < H; ++j) s2 += As[(h * N + n) * H + j] * Ks[j * D + c];
+        dqp[b * N * D + e] = s2 + tn[n] * Qs[e];
+    }
+    for (int e = tid; e < H * D; e += 256) {
+        const int j = e / D, c = e - j * D, h = c / hd;
+        float s2 = 0.f;
+        for (int n = 0; n < N; ++n) s2 += As[(h * N + n) * H + j] * Qs[n * D + c];
+        dkp[b * H * D + e] = s2;
+    }
+}
+
 // out[b][c] = sum_n part[(b * N + n) * cols + c]
 __global__ __launch_bounds__(256) void sum_candidates_kernel(const float* __restrict__ part, float* __restrict__ out, long B, int N,
                                                               long cols) {
@@ -429,4 +609,42 @@ extern "C" int lime_interest_match_bwd_f32(const float* kp, const float* qp, con
     sum_candidates_kernel<<<(int)((B * ck + 255) / 256 > 4096 ? 4096 : (B * ck + 255) / 256), 256, 0, s>>>(part_kp, dkp, B, N, ck);
     sum_candidates_kernel<<<(int)((B * cg + 255) / 256 > 4096 ? 4096 : (B * cg + 255) / 256), 256, 0, s>>>(part_g, dg, B, N, cg);
     return lime_check_launch("sum_candidates_kernel");
+}
+
+namespace {
+int cand_attn_train(const float* qp, const float* kp, const uint8_t* mask, const float* dagg, float* agg, float* dqp, float* dkp, int B,
+                    int N, int H, int D, int n_head, float p, uint64_t seed, uint32_t site, int mode, void* stream, const char* who) {
+    LIME_REQUIRE(qp && kp && mask, LIME_ERR_BAD_ARG, "%s: null pointer", who);
+    LIME_REQUIRE(B >= 0 && N > 0 && N <= CA_MAXN && H > 0 && H <= 256 && D > 0 && n_head > 0 && D % n_head == 0, LIME_ERR_UNSUPPORTED,
+                 "%s: needs N <= %d, H <= 256, D a multiple of n_head (N=%d H=%d D=%d n_head=%d)", who, CA_MAXN, N, H, D, n_head);
+    LIME_REQUIRE(p >= 0.f && p < 1.f, LIME_ERR_BAD_ARG, "%s: dropout p outside [0, 1)", who);
+    const size_t bytes = ((size_t)N * D + (size_t)H * D + 2 * (size_t)n_head * N * H + H + 3 * CA_MAXN + 4) * sizeof(float);
+    LIME_REQUIRE(bytes <= 160 * 1024 - 512, LIME_ERR_UNSUPPORTED, "%s: %zu bytes of LDS needed", who, bytes);
+    if (B == 0) return LIME_OK;
+    static size_t configured = 0;
+    if (bytes > configured) {
+        const hipError_t e = hipFuncSetAttribute((const void*)cand_attn_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        LIME_REQUIRE(e == hipSuccess, LIME_ERR_LAUNCH, "%s: cannot reserve %zu bytes of LDS: %s", who, bytes, hipGetErrorString(e));
+        configured = bytes;
+    }
+    cand_attn_train_kernel<<<B, 256, bytes, (hipStream_t)stream>>>(qp, kp, mask, dagg, agg, dqp, dkp, N, H, D, n_head,
+                                                                  1.0f / sqrtf((float)D), lime_make_dropout(p, seed, site), mode);
+    return lime_check_launch("cand_attn_train_kernel");
+}
+}  // namespace
+
+extern "C" int lime_cand_attn_weights_train_f32(const float* qp, const float* kp, const uint8_t* mask, float* agg, int32_t B, int32_t N,
+                                                int32_t H, int32_t D, int32_t n_head, float dropout_p, uint64_t seed, uint32_t site,
+                                                void* stream) {
+    LIME_REQUIRE(agg, LIME_ERR_BAD_ARG, "lime_cand_attn_weights_train_f32: null pointer");
+    return cand_attn_train(qp, kp, mask, nullptr, agg, nullptr, nullptr, B, N, H, D, n_head, dropout_p, seed, site, 0, stream,
+                           "lime_cand_attn_weights_train_f32");
+}
+
+extern "C" int lime_cand_attn_weights_bwd_f32(const float* qp, const float* kp, const uint8_t* mask, const float* dagg, float* dqp,
+                                              float* dkp, int32_t B, int32_t N, int32_t H, int32_t D, int32_t n_head, float dropout_p,
+                                              uint64_t seed, uint32_t site, void* stream) {
+    LIME_REQUIRE(dagg && dqp && dkp, LIME_ERR_BAD_ARG, "lime_cand_attn_weights_bwd_f32: null pointer");
+    return cand_attn_train(qp, kp, mask, dagg, nullptr, dqp, dkp, B, N, H, D, n_head, dropout_p, seed, site, 1, stream,
+                           "lime_cand_attn_weights_bwd_f32");
 }

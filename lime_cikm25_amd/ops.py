@@ -853,3 +853,31 @@ def interest_match_bwd(kp, qp, g, cand, remaining, dlogits, B, N, H, A, D, scale
                                           _p(dqp), _p(dg), _p(dcand), B, N, H, A, D, scale, alpha, beta, int(use_weight),
                                           int(use_penalty), _p(ws), ws.numel(), _stream()), 'lime_interest_match_bwd_f32')
     return dkp, dqp, dg, dcand
+
+
+def cand_attn_weights_train(qp, kp, mask, B, N, H, D, n_head, p=0.0, seed=0, site=0):
+    """agg [B, H] of layers.py:66-81 with the training-mode dropout on the per-head probabilities."""
+    lib = _lib.load()
+    _vec(qp, 'qp', B * N * D)
+    _vec(kp, 'kp', B * H * D)
+    m = _mask_u8(mask, 'mask')
+    if m.numel() != B * H:
+        raise ValueError('mask must be [B, H]')
+    agg = torch.empty((B, H), dtype=torch.float32, device=qp.device)
+    check(lib.lime_cand_attn_weights_train_f32(_p(qp), _p(kp), _p(m), _p(agg), B, N, H, D, n_head, p, seed, site, _stream()),
+          'lime_cand_attn_weights_train_f32')
+    return agg
+
+
+def cand_attn_weights_bwd(qp, kp, mask, dagg, B, N, H, D, n_head, p=0.0, seed=0, site=0):
+    """-> (dqp [B*N, D], dkp [B*H, D])."""
+    lib = _lib.load()
+    _vec(qp, 'qp', B * N * D)
+    _vec(kp, 'kp', B * H * D)
+    m = _mask_u8(mask, 'mask')
+    dagg = _vec(dagg.contiguous(), 'dagg', B * H)
+    dqp = torch.empty((B * N, D), dtype=torch.float32, device=qp.device)
+    dkp = torch.empty((B * H, D), dtype=torch.float32, device=qp.device)
+    check(lib.lime_cand_attn_weights_bwd_f32(_p(qp), _p(kp), _p(m), _p(dagg), _p(dqp), _p(dkp), B, N, H, D, n_head, p, seed, site, _stream()),
+          'lime_cand_attn_weights_bwd_f32')
+    return dqp, dkp

@@ -10,8 +10,9 @@ Where the arithmetic runs
   * every nn.Linear of the tail and the user encoder: ``_Linear`` (HIP GEMMs forward and backward).
   * the fused tail kernels of the scoring path with hand-written backward kernels (csrc/tail_backward_f32.hip): intent attention
     + cosine similarity + concat, gated residual + LayerNorm, history-vs-candidate attention + dot product + lifetime weight.
-  * still torch ops with torch's autograd: the candidate-aware attention weights (three small softmaxes over topic
-    projections, with the p = 0.2 dropout of layers.py:74), the GraphSAGE mean and a few concatenations.
+  * candidate-aware attention weights (per-head softmax with the layer's p = 0.2 dropout, query-norm softmax, aggregate
+    softmax) forward and backward in one kernel per impression row (cand_attn_train_kernel).
+  * still torch ops with torch's autograd: the GraphSAGE mean, a few concatenations and the two feature-fusion dropouts.
 
 Dropout (the reference trains with dropout_rate 0.2): the six dropouts inside a token encoder run on the dropout kernels
 with counter-based masks (csrc/dropout.h; torch's Philox stream is not reproduced -- the arithmetic is pinned against a torch
@@ -143,6 +144,27 @@ class _GateLN(torch.autograd.Function):
         y, x, scale, bias, gamma, beta = ctx.saved_tensors
         dy, dx, dscale, dbias, dgamma, dbeta = ops.gate_ln_bwd(y, x, scale, bias, gamma, beta, ctx.eps, dout)
         return dy.view_as(y), dx.view_as(x), dscale.view_as(scale), dbias, dgamma, dbeta, None
+
+
+class _CandAttnWeights(torch.autograd.Function):
+    """agg [B, H] of CandidateAware_ClickedNewsAttention (layers.py:66-81) from the topic projections, with the layer's own
+    dropout (p = 0.2, layers.py:36,74) on the per-head probabilities in training mode."""
+
+    @staticmethod
+    def forward(ctx, qp, kp, mask, dims, n_head, p, seed):
+        B, N, H, D = dims
+        qp, kp, mask = qp.contiguous(), kp.contiguous(), mask.contiguous()
+        agg = ops.cand_attn_weights_train(qp.view(-1), kp.view(-1), mask, B, N, H, D, n_head, p, seed, 0)
+        ctx.cfg = (dims, n_head, p, seed)
+        ctx.save_for_backward(qp, kp, mask)
+        return agg
+
+    @staticmethod
+    def backward(ctx, dagg):
+        qp, kp, mask = ctx.saved_tensors
+        (B, N, H, D), n_head, p, seed = ctx.cfg
+        dqp, dkp = ops.cand_attn_weights_bwd(qp.view(-1), kp.view(-1), mask, dagg, B, N, H, D, n_head, p, seed, 0)
+        return dqp.view_as(qp), dkp.view_as(kp), None, None, None, None, None
 
 
 class _InterestMatch(torch.autograd.Function):
@@ -371,15 +393,11 @@ def candidate_aware(att, hist, hist_topic, cand_topic, mask):
     """CandidateAware_ClickedNewsAttention.forward (layers.py:52-93); the value_proj branch is dead there."""
     B, H, D = hist.shape
     N = cand_topic.shape[1]
-    nh, hd = att.num_heads, att.head_dim
-    Q = linear(cand_topic, att.query_proj).view(B, N, nh, hd).transpose(1, 2)
-    K = linear(hist_topic, att.key_proj).view(B, H, nh, hd).transpose(1, 2)
-    s = torch.matmul(Q, K.transpose(-2, -1)) / att.scale
-    if mask is not None:
-        s = s.masked_fill(mask.view(B, 1, 1, H) == 0, -1e9)
-    a = att.dropout(torch.softmax(s, dim=-1))
-    qw = torch.softmax(torch.norm(Q.transpose(1, 2).reshape(B, N, -1), dim=-1), dim=1)
-    agg = torch.softmax((a.sum(dim=1) * qw.unsqueeze(-1)).sum(dim=1), dim=-1)
+    if mask is None:
+        mask = torch.ones(B, H, dtype=torch.bool, device=hist.device)
+    p = float(att.dropout.p) if att.training else 0.0                                                       # layers.py:36,74
+    agg = _CandAttnWeights.apply(linear(cand_topic, att.query_proj).reshape(B * N, D), linear(hist_topic, att.key_proj).reshape(B * H, D),
+                                 mask, (B, N, H, D), att.num_heads, p, _draw_seed() if p > 0 else 0)           # :66-81
     if not att.use_residual_connection:
         return agg.unsqueeze(-1) * hist
     ln = att.layernorm

@@ -249,3 +249,33 @@ def test_interest_match_bwd(ops, B, N, H, A, D, penalty):
                                  scale, alpha, beta, True, penalty)
     for name, x, ref in zip(('dkp', 'dqp', 'dg', 'dcand'), got, (kd, qd, gd, cd)):
         close(x, ref.grad.float(), tol=2e-4, what=name)
+
+
+@pytest.mark.parametrize('B,N,H,nh,hd,p', [(4, 5, 50, 10, 40, 0.0), (4, 5, 50, 10, 40, 0.2), (3, 1, 7, 2, 8, 0.5), (2, 3, 70, 10, 40, 0.2)])
+def test_cand_attn_weights_train_and_bwd(ops, B, N, H, nh, hd, p):
+    """layers.py:66-81 with explicit dropout masks read back from the kernels' generator, against torch fp64 autograd."""
+    D = nh * hd
+    seed = 4242
+    qp, kp = rnd(B * N, D, seed=1, scale=2.0), rnd(B * H, D, seed=2, scale=2.0)
+    g = torch.Generator().manual_seed(9)
+    mask = torch.rand(B, H, generator=g) < 0.7
+    mask[0] = False                                                  # an impression with an empty history
+    dagg = rnd(B, H, seed=3)
+    m = ops.dropout(torch.ones(B * nh * N, H, device='cuda'), p, seed, 0).cpu().double().view(B, nh, N, H)
+    qd, kd = qp.double().requires_grad_(), kp.double().requires_grad_()
+    Q = qd.view(B, N, nh, hd).transpose(1, 2)
+    K = kd.view(B, H, nh, hd).transpose(1, 2)
+    sc = (Q @ K.transpose(-2, -1)) / (D ** 0.5)
+    sc = sc.masked_fill(mask.view(B, 1, 1, H) == 0, -1e9)
+    a = torch.softmax(sc, dim=-1) * m
+    qw = torch.softmax(torch.norm(Q.transpose(1, 2).reshape(B, N, -1), dim=-1), dim=1)
+    agg = torch.softmax((a.sum(dim=1) * qw.unsqueeze(-1)).sum(dim=1), dim=-1)
+    agg.backward(dagg.double())
+    got = ops.cand_attn_weights_train(qp.cuda().view(-1), kp.cuda().view(-1), mask.cuda(), B, N, H, D, nh, p, seed, 0)
+    close(got, agg.detach().float(), what='agg')
+    if p == 0.0:
+        assert rel_err(ops.cand_attn_weights(qp.cuda().view(-1), kp.cuda().view(-1), mask.cuda(), B, N, H, D, nh).cpu().numpy(),
+                       got.cpu().numpy()) < 1e-5                        # the scoring kernel computes the same thing
+    dqp, dkp = ops.cand_attn_weights_bwd(qp.cuda().view(-1), kp.cuda().view(-1), mask.cuda(), dagg.cuda(), B, N, H, D, nh, p, seed, 0)
+    close(dqp, qd.grad.float(), tol=2e-4, what='dqp')
+    close(dkp, kd.grad.float(), tol=2e-4, what='dkp')
