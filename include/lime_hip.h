@@ -351,7 +351,7 @@ int lime_relu_bwd_f32(float* dh, int64_t lddh, const float* h, int64_t ldh, int6
  * S <= 512, head_dim <= head_stride <= 32.  S <= 128: one pass per (sequence, head); `out` and `workspace` may be NULL.
  * 128 < S <= 512 (the 512-token bodies of BASELINE config 4): 128 x 128 blocks; needs the forward output `out` (packed like
  * dout) and lime_token_attention_bwd_workspace(n_seq, S, n_head) floats; the key blocks' shares of dq are added with float
- * atomics.  dropout_p > 0 (S <= 128): the forward was lime_token_attention_dropout_f32 with the same (dropout_p, seed, site). */
+ * atomics.  dropout_p > 0: the forward was lime_token_attention_dropout_f32 with the same (dropout_p, seed, site). */
 int64_t lime_token_attention_bwd_workspace(int32_t n_seq, int32_t S, int32_t n_head);
 int lime_token_attention_bwd_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out, int64_t ld_out,
                                  const float* dout, int64_t ldo, float* dq, float* dk, float* dv, int64_t ld_dqkv, int32_t n_seq,
@@ -382,10 +382,12 @@ int lime_dropout_add_layernorm_f32(const float* t, int64_t ldt, const float* res
 
 /* Encoder attention with dropout on the probabilities (nn.MultiheadAttention(dropout=p) in training mode):
  * out = (keep * softmax(scale q k^T) / (1 - p)) v; layouts as lime_token_attention_f32 without a key mask; mask element
- * ((seq * n_head + head) * S + i) * S + j.  S <= 128. */
+ * ((seq * n_head + head) * S + i) * S + j.  S <= 512; S > 128 runs in 128 x 128 blocks and needs
+ * lime_token_attention_bwd_workspace(n_seq, S, n_head) floats of workspace (row statistics), else workspace may be NULL. */
 int lime_token_attention_dropout_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, float* out, int64_t ldo,
                                      int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim, int32_t head_stride, float scale,
-                                     float dropout_p, uint64_t seed, uint32_t site, void* stream);
+                                     float dropout_p, uint64_t seed, uint32_t site, float* workspace, int64_t workspace_floats,
+                                     void* stream);
 
 /* dtable[ids[r], :] += dx[r, :] (nn.Embedding backward, newsEncoders.py:311-312).  dtable must be initialised by the
  * caller (zeros, or a gradient to add to).  Rows with ids[r] == hot_id (the padding word, pass -1 for none) are summed

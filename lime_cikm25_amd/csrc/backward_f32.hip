@@ -811,7 +811,7 @@ __global__ __launch_bounds__(512) void attn_stats_kernel(const float* __restrict
         const int row = R0 + 4 * kg + r;
         if (fi == 0 && row < q_valid) stats[((row_base + q0 + row) * n_head + head) * 2] = m[r] + log2f(l[r]);   // log2 domain
     }
-    if (tid < q_valid) {
+    if (tid < q_valid && out != nullptr) {
         const float* po = out + (row_base + q0 + tid) * ldout + (long)head * head_dim;
         const float* pd = dout + (row_base + q0 + tid) * ldo + (long)head * head_dim;
         float d = 0.f;
@@ -820,11 +820,85 @@ __global__ __launch_bounds__(512) void attn_stats_kernel(const float* __restrict
     }
 }
 
+// Training-mode forward for 128 < S <= 512 with probability dropout: row statistics first (attn_stats_kernel), then one
+// workgroup per (sequence, head, query block) walks the key blocks: out = sum_blocks (keep * exp2(s' - lse) / (1 - p)) V.
+__global__ __launch_bounds__(512) void attn_fwd_long_dropout_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                     const float* __restrict__ v, long ld, const float* __restrict__ stats,
+                                                                     float* __restrict__ out, long ldo, int S, int n_head, int head_dim,
+                                                                     int head_stride, float scale, int n_blk, LimeDropout drop) {
+    constexpr int NT = LB / 16, LDP = LB + 2;
+    extern __shared__ float smem[];
+    float* Qs = smem;
+    float* Ks = Qs + LB * AB_LD;
+    float* Vs = Ks + LB * AB_LD;
+    float* Ps = Vs + LB * AB_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, kg = lane >> 4;
+    const int qb = blockIdx.x % n_blk;
+    const long prob = blockIdx.x / n_blk;
+    const int seq = (int)(prob / n_head), head = (int)(prob % n_head);
+    const long row_base = (long)seq * S;
+    const int q0 = qb * LB, q_valid = min(LB, S - q0);
+    const int R0 = 16 * wave;
+    stage_rows(Qs, q, ld, row_base + q0, q_valid, head * head_stride, head_dim, tid);
+    __syncthreads();
+    f32x4v qa[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) qa[h] = *reinterpret_cast<const f32x4v*>(&Qs[(R0 + fi) * AB_LD + 8 * kg + 4 * h]);
+    float lse[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = R0 + 4 * kg + r;
+        lse[r] = row < q_valid ? stats[((row_base + q0 + row) * n_head + head) * 2] : INFINITY;
+    }
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
+    for (int kb = 0; kb < n_blk; ++kb) {
+        const int k0 = kb * LB, k_valid = min(LB, S - k0);
+        __syncthreads();
+        stage_rows(Ks, k, ld, row_base + k0, k_valid, head * head_stride, head_dim, tid);
+        stage_rows(Vs, v, ld, row_base + k0, k_valid, head * head_stride, head_dim, tid);
+        __syncthreads();
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            f32x4v kf[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) kf[h] = *reinterpret_cast<const f32x4v*>(&Ks[(16 * ct + fi) * AB_LD + 8 * kg + 4 * h]);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) a = mfma16(qa[t >> 2][t & 3], kf[t >> 2][t & 3], a);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint64_t idx = ((uint64_t)prob * S + (uint64_t)(q0 + R0 + 4 * kg + r)) * (uint64_t)S + (uint64_t)(k0 + 16 * ct + fi);
+                const float pv = (16 * ct + fi < k_valid) ? __builtin_amdgcn_exp2f(a[r] * (scale * LOG2E) - lse[r]) : 0.f;
+                const float f = (drop.thresh == 0 || lime_keep(drop, idx)) ? drop.scale : 0.f;
+                Ps[(R0 + 4 * kg + r) * LDP + 16 * ct + fi] = pv * f;
+            }
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int t = 0; t < LB / 4; ++t) {
+            const int j = 4 * t + kg;
+            const float a = Ps[(R0 + fi) * LDP + j];
+            o0 = mfma16(a, Vs[j * AB_LD + fi], o0);
+            o1 = mfma16(a, Vs[j * AB_LD + 16 + fi], o1);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = R0 + 4 * kg + r;
+        if (row < q_valid) {
+            float* o = out + (row_base + q0 + row) * ldo + (long)head * head_dim;
+            if (fi < head_dim) o[fi] = o0[r];
+            if (16 + fi < head_dim) o[16 + fi] = o1[r];
+        }
+    }
+}
+
 __global__ __launch_bounds__(512) void attn_bwd_long_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                              const float* __restrict__ v, long ld, const float* __restrict__ dout,
                                                              long ldo, const float* __restrict__ stats, float* __restrict__ dq,
                                                              float* __restrict__ dk, float* __restrict__ dv, long ldd, int S,
-                                                             int n_head, int head_dim, int head_stride, float scale, int n_blk) {
+                                                             int n_head, int head_dim, int head_stride, float scale, int n_blk,
+                                                             LimeDropout drop) {
     constexpr int NT = LB / 16, LDP = LB + 2;
     extern __shared__ float smem[];
     float* Qs = smem;
@@ -884,11 +958,15 @@ __global__ __launch_bounds__(512) void attn_bwd_long_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float lse = Ls[R0 + 4 * kg + r], dl = Ds[R0 + 4 * kg + r];
+            const uint64_t mrow = ((uint64_t)prob * S + (uint64_t)(q0 + R0 + 4 * kg + r)) * (uint64_t)S + (uint64_t)k0;
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
                 const float pv = (16 * ct + fi < k_valid) ? __builtin_amdgcn_exp2f(p[ct][r] * (scale * LOG2E) - lse) : 0.f;
-                p[ct][r] = pv;
-                dp[ct][r] = scale * pv * (dp[ct][r] - dl);
+                // probability dropout: the forward multiplied keep / (1 - p) into P before the V product (delta = dO . O
+                // already contains it)
+                const float f = (drop.thresh == 0 || lime_keep(drop, mrow + (uint64_t)(16 * ct + fi))) ? drop.scale : 0.f;
+                p[ct][r] = pv * f;                                   // what the dV product needs
+                dp[ct][r] = scale * pv * (dp[ct][r] * f - dl);       // dS
             }
         }
 #pragma unroll
@@ -1320,7 +1398,6 @@ extern "C" int lime_token_attention_bwd_f32(const float* q, const float* k, cons
                                             float dropout_p, uint64_t seed, uint32_t site, void* stream) {
     LIME_REQUIRE(q && k && v && dout && dq && dk && dv, LIME_ERR_BAD_ARG, "lime_token_attention_bwd_f32: null pointer");
     LIME_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, LIME_ERR_BAD_ARG, "lime_token_attention_bwd_f32: dropout_p outside [0, 1)");
-    LIME_REQUIRE(dropout_p == 0.f || S <= 128, LIME_ERR_UNSUPPORTED, "lime_token_attention_bwd_f32: probability dropout needs S <= 128");
     const LimeDropout drop = lime_make_dropout(dropout_p, seed, site);
     LIME_REQUIRE(n_seq >= 0 && S > 0 && n_head > 0 && head_dim > 0, LIME_ERR_BAD_ARG, "lime_token_attention_bwd_f32: bad dimensions");
     LIME_REQUIRE(S <= 512 && head_dim <= 32 && head_stride >= head_dim && head_stride <= 32, LIME_ERR_UNSUPPORTED,
@@ -1356,17 +1433,18 @@ extern "C" int lime_token_attention_bwd_f32(const float* q, const float* k, cons
         configured = true;
     }
     attn_bwd_long_kernel<<<(unsigned)(n_prob * n_blk), 512, BYTES, s>>>(q, k, v, ld_qkv, dout, ldo, workspace, dq, dk, dv, ld_dqkv, S,
-                                                                       n_head, head_dim, head_stride, scale, n_blk);
+                                                                       n_head, head_dim, head_stride, scale, n_blk, drop);
     return lime_check_launch("attn_bwd_long_kernel");
 }
 
 extern "C" int lime_token_attention_dropout_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, float* out, int64_t ldo,
                                                 int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim, int32_t head_stride,
-                                                float scale, float dropout_p, uint64_t seed, uint32_t site, void* stream) {
+                                                float scale, float dropout_p, uint64_t seed, uint32_t site, float* workspace,
+                                                int64_t workspace_floats, void* stream) {
     LIME_REQUIRE(q && k && v && out, LIME_ERR_BAD_ARG, "lime_token_attention_dropout_f32: null pointer");
     LIME_REQUIRE(n_seq >= 0 && S > 0 && n_head > 0 && head_dim > 0, LIME_ERR_BAD_ARG, "lime_token_attention_dropout_f32: bad dimensions");
-    LIME_REQUIRE(S <= 128 && head_dim <= 32 && head_stride >= head_dim && head_stride <= 32, LIME_ERR_UNSUPPORTED,
-                 "lime_token_attention_dropout_f32: needs S <= 128 and head_dim <= head_stride <= 32");
+    LIME_REQUIRE(S <= 512 && head_dim <= 32 && head_stride >= head_dim && head_stride <= 32, LIME_ERR_UNSUPPORTED,
+                 "lime_token_attention_dropout_f32: needs S <= 512 and head_dim <= head_stride <= 32");
     LIME_REQUIRE(ld_qkv >= (int64_t)n_head * head_stride && ldo >= (int64_t)n_head * head_dim, LIME_ERR_BAD_ARG,
                  "lime_token_attention_dropout_f32: leading dimension smaller than the row");
     LIME_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, LIME_ERR_BAD_ARG, "lime_token_attention_dropout_f32: dropout_p outside [0, 1)");
@@ -1375,7 +1453,27 @@ extern "C" int lime_token_attention_dropout_f32(const float* q, const float* k, 
     hipStream_t s = (hipStream_t)stream;
     if (S <= 32) return launch_attn_fwd_dropout<32>(q, k, v, ld_qkv, out, ldo, n_seq, S, n_head, head_dim, head_stride, scale, drop, s);
     if (S <= 64) return launch_attn_fwd_dropout<64>(q, k, v, ld_qkv, out, ldo, n_seq, S, n_head, head_dim, head_stride, scale, drop, s);
-    return launch_attn_fwd_dropout<128>(q, k, v, ld_qkv, out, ldo, n_seq, S, n_head, head_dim, head_stride, scale, drop, s);
+    if (S <= 128) return launch_attn_fwd_dropout<128>(q, k, v, ld_qkv, out, ldo, n_seq, S, n_head, head_dim, head_stride, scale, drop, s);
+    LIME_REQUIRE(workspace && workspace_floats >= lime_token_attention_bwd_workspace(n_seq, S, n_head), LIME_ERR_BAD_ARG,
+                 "lime_token_attention_dropout_f32: S > 128 needs lime_token_attention_bwd_workspace() floats of workspace");
+    const int n_blk = (S + LB - 1) / LB;
+    const long n_prob = (long)n_seq * n_head;
+    LIME_REQUIRE(n_prob * n_blk < 0x7FFFFFFFL, LIME_ERR_UNSUPPORTED, "lime_token_attention_dropout_f32: too many blocks");
+    attn_stats_kernel<<<(unsigned)(n_prob * n_blk), 512, 0, s>>>(q, k, ld_qkv, nullptr, 0, nullptr, 0, workspace, S, n_head, head_dim,
+                                                              head_stride, scale, n_blk);
+    int st = lime_check_launch("attn_stats_kernel");
+    if (st != LIME_OK) return st;
+    constexpr int BYTES = (3 * LB * AB_LD + LB * (LB + 2)) * 4;
+    static bool configured = false;
+    if (!configured) {
+        const hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_long_dropout_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+        LIME_REQUIRE(e == hipSuccess, LIME_ERR_LAUNCH, "lime_token_attention_dropout_f32: cannot reserve %d bytes of LDS: %s", BYTES,
+                     hipGetErrorString(e));
+        configured = true;
+    }
+    attn_fwd_long_dropout_kernel<<<(unsigned)(n_prob * n_blk), 512, BYTES, s>>>(q, k, v, ld_qkv, workspace, out, ldo, S, n_head, head_dim,
+                                                                               head_stride, scale, n_blk, drop);
+    return lime_check_launch("attn_fwd_long_dropout_kernel");
 }
 
 extern "C" int lime_embed_bwd_f32(const int32_t* ids, const float* dx, int64_t lddx, float* dtable, int64_t ld_table, int64_t rows,

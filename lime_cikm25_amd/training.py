@@ -16,8 +16,7 @@ Where the arithmetic runs
 
 Dropout (the reference trains with dropout_rate 0.2): the six dropouts inside a token encoder run on the dropout kernels
 with counter-based masks (csrc/dropout.h; torch's Philox stream is not reproduced -- the arithmetic is pinned against a torch
-statement of the layer fed with the same masks, tests/test_dropout_gpu.py); sequences longer than 128 tokens are refused with
-dropout on.  Dropout in the torch glue (feature_fusion, user_node_embedding, the hard-coded p = 0.2 of the candidate-aware
+statement of the layer fed with the same masks, tests/test_dropout_gpu.py).  Dropout in the torch glue (feature_fusion, user_node_embedding, the hard-coded p = 0.2 of the candidate-aware
 attention) uses torch's own generator.
 """
 import math
@@ -219,8 +218,6 @@ class _TokenEncoder(torch.autograd.Function):
         hs = 32 if hd <= 32 else hd
         if hs > 32 or S > 512:
             raise NotImplementedError('the attention kernels cover head_dim <= 32 and S <= 512 (got %d, %d)' % (hd, S))
-        if p > 0 and S > 128:
-            raise NotImplementedError('attention-probability dropout is implemented for sequences of at most 128 tokens (got %d)' % S)
         W = nhead * hs
         flat = ids.reshape(-1).contiguous()
         tok = M * S

@@ -48,7 +48,7 @@ def test_mask_statistics_and_determinism(ops):
     assert torch.equal(y, ops.dropout(x, 0.3, 7, 0))
 
 
-@pytest.mark.parametrize('M,S', [(3, 16), (5, 32), (2, 128), (4, 50)])
+@pytest.mark.parametrize('M,S', [(3, 16), (5, 32), (2, 128), (4, 50), (2, 200), (1, 512)])
 def test_encoder_layer_with_dropout_matches_torch_on_the_same_masks(ops, M, S):
     E, nh, Fd, V, p, seed = 300, 10, 512, 400, 0.2, 987654321
     hd = E // nh
