@@ -514,6 +514,7 @@ class TrainStep:
             seen.add(id(p))
             named.append((name, p))
         self.names = [n for n, _ in named]
+        self._params = named
         # every parameter starts on a 256-byte boundary of the bucket (the LDS-DMA GEMM wants 16-byte aligned operands);
         # the padding stays zero in all four buffers
         align = lambda n: (n + 63) // 64 * 64
@@ -536,10 +537,20 @@ class TrainStep:
 
     def backward_and_update(self, loss):
         """loss.backward() into the flat bucket, all-reduce, clip, Adam.  Returns the (device) gradient norm."""
+        self._check_bucket()
         self.grad.zero_()
         loss.backward()
         distributed.allreduce_mean_(self.grad, self.group)
         return self.update()
+
+    def _check_bucket(self):
+        """Parameters and their .grad must still be the views into the flat buckets this object set up: ``model.zero_grad()``
+        (set_to_none), ``model.to(...)`` or a foreign optimizer would silently detach them."""
+        pb, gb = self.flat.data_ptr(), self.grad.data_ptr()
+        for name, p in self._params:
+            if p.grad is None or p.grad.data_ptr() - gb != p.data_ptr() - pb or not (0 <= p.data_ptr() - pb < self.flat.numel() * 4):
+                raise RuntimeError('TrainStep: parameter %s (or its .grad) no longer lives in the flat bucket -- do not call '
+                                   'model.zero_grad() / model.to() after constructing TrainStep (it zeroes the bucket itself)' % name)
 
     def update(self):
         self.step_count += 1

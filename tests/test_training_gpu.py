@@ -165,3 +165,12 @@ def test_checkpoint_resume_continues_bit_for_bit(tmp_path):
     a, b = dict(unique_named_parameters(model)), dict(unique_named_parameters(fresh))
     for k in step.names:
         assert rel_err(b[k].detach().cpu().numpy(), a[k].detach().cpu().numpy()) < 1e-5, k
+
+
+def test_detached_bucket_is_detected():
+    cfg, model, batch = train_model('spill')
+    step = TrainStep(model, lr=LR)
+    step.step(*batch)
+    model.zero_grad()                      # set_to_none: the .grad views are gone
+    with pytest.raises(RuntimeError, match='flat bucket'):
+        step.step(*batch)
