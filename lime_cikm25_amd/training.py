@@ -16,14 +16,13 @@ Where the arithmetic runs
 
 Dropout (the reference trains with dropout_rate 0.2): the six dropouts inside a token encoder run on the dropout kernels
 with counter-based masks (csrc/dropout.h; torch's Philox stream is not reproduced -- the arithmetic is pinned against a torch
-statement of the layer fed with the same masks, tests/test_dropout_gpu.py).  Dropout in the torch glue (feature_fusion, user_node_embedding, the hard-coded p = 0.2 of the candidate-aware
-attention) uses torch's own generator.
+statement of the layer fed with the same masks, tests/test_dropout_gpu.py), and so does the hard-coded p = 0.2 of the
+candidate-aware attention.  The dropouts left in the torch glue (feature_fusion, user_node_embedding) use torch's generator.
 """
 import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import distributed, ops
 
@@ -328,14 +327,6 @@ def encode_tokens(ids, table, pos_encoder, transformer, nhead, p_embedding=0.0):
 # ---------------------------------------------------------------------------------------------------------------------
 # the differentiable forward
 # ---------------------------------------------------------------------------------------------------------------------
-def _additive_attention(att, feature):
-    """layers.Attention.forward without a mask (layers.py:285-300): feature [M, k, D] -> [M, D]."""
-    a = linear(feature, att.affine1, act='tanh')
-    score = (a * att.affine2.weight.view(1, 1, -1)).sum(dim=-1)
-    alpha = torch.softmax(score, dim=1)
-    return (alpha.unsqueeze(-1) * feature).sum(dim=1)
-
-
 def crown_tail(enc, title_p, body_p, category, subCategory):
     """newsEncoders.CROWN.forward after the token encoders (newsEncoders.py:340-373): pooled title / body [M, 300] -> [M, 900]."""
     cat_e = embedding(enc.category_embedding.weight, category)
