@@ -209,6 +209,117 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------
+// wgrad with LDS-DMA staging (16-byte aligned operands): the same tiling as wgrad_kernel, but 32-row chunks go global -> LDS
+// directly (raw_ptr_buffer_load_lds, 1 KB per wave instruction, rows packed without padding), two stages, ONE barrier per
+// chunk: chunk c + 1 is in flight while chunk c is multiplied; no staging registers, no LDS stores.  116 VGPRs and 56 KB of
+// LDS: two workgroups (16 waves) per CU, one's barrier is the other's MFMA time.
+// ---------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, float* lds_base, unsigned voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)          // (inside a kernel template the builtin makes the host pass drop the launch stub)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds_base, 16, voff, soff, 0, 0);
+#endif
+}
+
+constexpr int WD_MC = 16;          // rows per chunk: two stages of 16 rows = 56 KB (TK = 320), two workgroups per CU
+
+template <int NKT>
+__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_dma_kernel(const float* __restrict__ dy, long ldy, const float* __restrict__ x,
+                                                                long ldx, float* __restrict__ ws, int M, int N, int K, int n_tiles,
+                                                                int k_tiles, int rows_per_split, int ones_col) {
+    constexpr int TK = 64 * NKT;
+    constexpr int A_FLOATS = WD_MC * WG_TN, B_FLOATS = WD_MC * TK, STAGE = A_FLOATS + B_FLOATS;
+    constexpr int A_P = A_FLOATS / 256, B_P = B_FLOATS / 256;     // 1 KB DMA pieces per chunk: 8 and 12 / 16 / 20
+    constexpr int A_PW = (A_P + 7) / 8, B_PW = (B_P + 7) / 8;     // per wave (piece q = wave + 8 j, q < P)
+    extern __shared__ float wg_smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 15, kg = lane >> 4;
+    const int ntile = n_tiles * k_tiles;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / ntile, tile = logical - split * ntile;
+    const int n0 = (tile / k_tiles) * WG_TN, k0 = (tile % k_tiles) * TK;
+    const long m_begin = (long)split * rows_per_split;
+    const int rows_here = (int)(min((long)M, m_begin + rows_per_split) - m_begin);
+    const int wn = (wave >> 2) * 64, wk = (wave & 3) * (16 * NKT);
+
+    f32x4 acc[4][NKT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NKT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (rows_here > 0) {
+        const __amdgpu_buffer_rsrc_t rs_a = make_rsrc(dy + m_begin * ldy + n0);
+        const __amdgpu_buffer_rsrc_t rs_b = make_rsrc(x + m_begin * ldx + k0);
+        // this lane's 16-byte pieces: piece q of the wave covers floats [256 q + 4 lane, + 4) of the packed [32][cols] image
+        unsigned a_off[A_PW], b_off[B_PW];
+        int a_row[A_PW], b_row[B_PW], b_one[B_PW], b_r[B_PW];
+#pragma unroll
+        for (int j = 0; j < A_PW; ++j) {
+            const int q = wave + 8 * j, f = q * 256 + 4 * lane, r = f / WG_TN, c = f % WG_TN;
+            a_row[j] = (q < A_P && n0 + c < N) ? r : (1 << 30);
+            a_off[j] = (unsigned)r * (unsigned)(ldy * 4) + (unsigned)c * 4u;
+        }
+#pragma unroll
+        for (int j = 0; j < B_PW; ++j) {
+            const int q = wave + 8 * j, f = q * 256 + 4 * lane, r = f / TK, c = f % TK;
+            b_row[j] = (q < B_P && k0 + c < K) ? r : (1 << 30);
+            b_off[j] = (unsigned)r * (unsigned)(ldx * 4) + (unsigned)c * 4u;
+            b_r[j] = r;
+            // the all-ones column of X (bias gradient) falls into this lane's piece: the lane patches it after its DMA landed
+            b_one[j] = (q < B_P && ones_col && K >= k0 + c && K < k0 + c + 4) ? K - k0 - c : -1;
+        }
+        auto issue = [&](int stage, int mrel) {
+            float* const sb = wg_smem + stage * STAGE;
+            const int soff_a = mrel * (int)(ldy * 4), soff_b = mrel * (int)(ldx * 4);
+#pragma unroll
+            for (int j = 0; j < A_PW; ++j)
+                if (wave + 8 * j < A_P)
+                    dma16(rs_a, sb + (wave + 8 * j) * 256, (mrel + a_row[j] < rows_here) ? a_off[j] : OOB, soff_a);
+#pragma unroll
+            for (int j = 0; j < B_PW; ++j)
+                if (wave + 8 * j < B_P)
+                    dma16(rs_b, sb + A_FLOATS + (wave + 8 * j) * 256, (mrel + b_row[j] < rows_here) ? b_off[j] : OOB, soff_b);
+        };
+        issue(0, 0);
+        int stage = 0;
+        for (int m0 = 0; m0 < rows_here; m0 += WD_MC) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's pieces of chunk m0 have landed
+#pragma unroll
+            for (int j = 0; j < B_PW; ++j)
+                if (b_one[j] >= 0)
+                    wg_smem[stage * STAGE + A_FLOATS + (wave + 8 * j) * 256 + 4 * lane + b_one[j]] = (m0 + b_r[j] < rows_here) ? 1.0f : 0.f;
+            __syncthreads();                                           // everybody's have; the other stage is no longer read
+            if (m0 + WD_MC < rows_here) issue(stage ^ 1, m0 + WD_MC);
+            const float* as = wg_smem + stage * STAGE + kg * WG_TN + wn + fi;
+            const float* bs = wg_smem + stage * STAGE + A_FLOATS + kg * TK + wk + fi;
+#pragma unroll
+            for (int s = 0; s < WD_MC / 4; ++s) {
+                float a[4], b[NKT];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = as[4 * s * WG_TN + 16 * i];
+#pragma unroll
+                for (int j = 0; j < NKT; ++j) b[j] = bs[4 * s * TK + 16 * j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NKT; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+            }
+            stage ^= 1;
+        }
+    }
+    const long ldw = (long)k_tiles * TK;
+    float* o = ws + (long)split * ((long)n_tiles * WG_TN) * ldw;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NKT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                o[(long)(n0 + wn + 16 * i + 4 * kg + r) * ldw + k0 + wk + 16 * j + fi] = acc[i][j][r];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // colsum: partial[blk][c] = sum of x[r, c] over the block's rows
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ldx, int M, int N, int rows_per_block,
@@ -1173,7 +1284,7 @@ namespace {
 
 struct WgradPlan { int nkt, tk, n_tiles, k_tiles, splits, rows_per_split; long np, kp; };
 
-WgradPlan wgrad_plan(int M, int N, int K) {
+WgradPlan wgrad_plan(int M, int N, int K, int wg_per_cu = 2) {
     WgradPlan w;
     long best = -1;
     w.nkt = 4;
@@ -1187,7 +1298,7 @@ WgradPlan wgrad_plan(int M, int N, int K) {
     w.np = (long)w.n_tiles * WG_TN;
     w.kp = (long)w.k_tiles * w.tk;
     const int ntile = w.n_tiles * w.k_tiles;
-    int splits = 256 / ntile;                                     // one eight-wave workgroup per CU, a single round of them
+    int splits = 256 * wg_per_cu / ntile;                         // a single round of eight-wave workgroups (two per CU on the DMA kernel)
     const int max_splits = (M + 511) / 512;                       // at least 8 chunks of 64 rows per workgroup
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -1197,6 +1308,22 @@ WgradPlan wgrad_plan(int M, int N, int K) {
     w.splits = (M + rps - 1) / rps;
     if (w.splits < 1) w.splits = 1;
     return w;
+}
+
+template <int NKT>
+int launch_wgrad_dma(const WgradPlan& w, const float* dy, long ldy, const float* x, long ldx, float* ws, int M, int N, int K,
+                     int ones_col, hipStream_t s) {
+    constexpr int BYTES = 2 * WD_MC * (WG_TN + 64 * NKT) * 4;
+    static bool configured = false;
+    if (!configured) {
+        const hipError_t e = hipFuncSetAttribute((const void*)wgrad_dma_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+        LIME_REQUIRE(e == hipSuccess, LIME_ERR_LAUNCH, "lime_linear_wgrad_f32: cannot reserve %d bytes of LDS: %s", BYTES,
+                     hipGetErrorString(e));
+        configured = true;
+    }
+    const int grid = w.n_tiles * w.k_tiles * w.splits;
+    wgrad_dma_kernel<NKT><<<grid, WG_THREADS, BYTES, s>>>(dy, ldy, x, ldx, ws, M, N, K, w.n_tiles, w.k_tiles, w.rows_per_split, ones_col);
+    return lime_check_launch("wgrad_dma_kernel");
 }
 
 template <int NKT, bool VEC>
@@ -1247,17 +1374,19 @@ extern "C" int lime_linear_wgrad_f32(const float* dy, int64_t ldy, const float* 
     LIME_REQUIRE(dy && x && dw && workspace, LIME_ERR_BAD_ARG, "lime_linear_wgrad_f32: null pointer");
     LIME_REQUIRE(M > 0 && N > 0 && K > 0, LIME_ERR_BAD_ARG, "lime_linear_wgrad_f32: non-positive dimension");
     LIME_REQUIRE(ldy >= N && ldx >= K && lddw >= K, LIME_ERR_BAD_ARG, "lime_linear_wgrad_f32: leading dimension smaller than the row");
-    const WgradPlan w = wgrad_plan(M, N, K);
+    const bool vec = N % 4 == 0 && K % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ((((uintptr_t)dy) | ((uintptr_t)x)) & 15) == 0;
+    static const bool no_dma = getenv("LIME_WGRAD_NO_DMA") != nullptr;        // A/B switch for tools/, not a product option
+    const WgradPlan w = wgrad_plan(M, N, K, (vec && !no_dma) ? 2 : 1);        // the DMA kernel fits two workgroups per CU
     LIME_REQUIRE(workspace_floats >= lime_linear_wgrad_workspace(M, N, K), LIME_ERR_BAD_ARG,
                  "lime_linear_wgrad_f32: workspace holds %ld floats, lime_linear_wgrad_workspace() asks for %ld",
                  (long)workspace_floats, (long)lime_linear_wgrad_workspace(M, N, K));
     hipStream_t s = (hipStream_t)stream;
     LIME_REQUIRE(((long)w.rows_per_split + WG_MC) * (ldy > ldx ? ldy : ldx) * 4 < 0x7FFFFFF0L, LIME_ERR_UNSUPPORTED,
                  "lime_linear_wgrad_f32: a row slice spans more than 2 GB (rows %d, ld %ld)", w.rows_per_split, (long)(ldy > ldx ? ldy : ldx));
-    const bool vec = N % 4 == 0 && K % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ((((uintptr_t)dy) | ((uintptr_t)x)) & 15) == 0;
     int st;
     const int ones_col = (db != nullptr && K < w.kp) ? 1 : 0;          // room for a ones column in the padded tile grid
-#define WGRAD(NKT) (vec ? launch_wgrad<NKT, true>(w, dy, ldy, x, ldx, workspace, M, N, K, ones_col, s) \
+#define WGRAD(NKT) (vec ? (no_dma ? launch_wgrad<NKT, true>(w, dy, ldy, x, ldx, workspace, M, N, K, ones_col, s)              \
+                                  : launch_wgrad_dma<NKT>(w, dy, ldy, x, ldx, workspace, M, N, K, ones_col, s))                \
                         : launch_wgrad<NKT, false>(w, dy, ldy, x, ldx, workspace, M, N, K, ones_col, s))
     if (w.nkt == 5) st = WGRAD(5); else if (w.nkt == 3) st = WGRAD(3); else st = WGRAD(4);
 #undef WGRAD
