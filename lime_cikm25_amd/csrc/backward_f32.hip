@@ -752,7 +752,7 @@ template <int SP>
 __global__ __launch_bounds__(512) void token_attn_fwd_dropout_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                       const float* __restrict__ v, long ld, float* __restrict__ out,
                                                                       long ldo, int n_seq, int S, int n_head, int head_dim,
-                                                                      int head_stride, float scale, LimeDropout drop) {
+                                                                      int head_stride, float scale, LimeDropout drop, int vec) {
     constexpr int NT = SP / 16, WPP = SP / 16, PPW = 8 / WPP, TPP = 64 * WPP, LDP = SP + 2;
     constexpr int PROB_FLOATS = 3 * SP * AB_LD + SP * LDP;
     extern __shared__ float smem[];
@@ -768,13 +768,25 @@ __global__ __launch_bounds__(512) void token_attn_fwd_dropout_kernel(const float
     float* Ps = Vs + SP * AB_LD;
     const int R0 = 16 * wr;
     const long row_base = (long)seq * S;
-    for (int e = lt; e < SP * 32; e += TPP) {
-        const int r = e >> 5, c = e & 31;
-        const bool ok = live && r < S && c < head_dim;
-        const long g = (row_base + r) * ld + (long)head * head_stride + c;
-        Qs[r * AB_LD + c] = ok ? q[g] : 0.f;
-        Ks[r * AB_LD + c] = ok ? k[g] : 0.f;
-        Vs[r * AB_LD + c] = ok ? v[g] : 0.f;
+    if (vec) {                  // 32-float head rows on 16-byte boundaries, zero padding columns
+        for (int e = lt; e < SP * 8; e += TPP) {
+            const int r = e >> 3, c = (e & 7) * 4;
+            const bool ok = live && r < S;
+            const long g = (row_base + (ok ? r : 0)) * ld + (long)head * head_stride + c;
+            const f32x4v z = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4v*>(&Qs[r * AB_LD + c]) = ok ? *reinterpret_cast<const f32x4v*>(q + g) : z;
+            *reinterpret_cast<f32x4v*>(&Ks[r * AB_LD + c]) = ok ? *reinterpret_cast<const f32x4v*>(k + g) : z;
+            *reinterpret_cast<f32x4v*>(&Vs[r * AB_LD + c]) = ok ? *reinterpret_cast<const f32x4v*>(v + g) : z;
+        }
+    } else {
+        for (int e = lt; e < SP * 32; e += TPP) {
+            const int r = e >> 5, c = e & 31;
+            const bool ok = live && r < S && c < head_dim;
+            const long g = (row_base + r) * ld + (long)head * head_stride + c;
+            Qs[r * AB_LD + c] = ok ? q[g] : 0.f;
+            Ks[r * AB_LD + c] = ok ? k[g] : 0.f;
+            Vs[r * AB_LD + c] = ok ? v[g] : 0.f;
+        }
     }
     __syncthreads();
     f32x4 p[NT];
@@ -1510,8 +1522,9 @@ int launch_attn_fwd_dropout(const float* q, const float* k, const float* v, long
         configured = true;
     }
     const long n_group = ((long)n_seq * n_head + PPW - 1) / PPW;
+    const bool vec = head_stride == 32 && ld % 4 == 0 && ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) == 0;
     token_attn_fwd_dropout_kernel<SP><<<(unsigned)n_group, 512, BYTES, s>>>(q, k, v, ld, out, ldo, n_seq, S, n_head, head_dim, head_stride,
-                                                                           scale, drop);
+                                                                           scale, drop, vec ? 1 : 0);
     return lime_check_launch("token_attn_fwd_dropout_kernel");
 }
 }  // namespace
