@@ -211,8 +211,7 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------------
 // wgrad with LDS-DMA staging (16-byte aligned operands): the same tiling as wgrad_kernel, but 32-row chunks go global -> LDS
 // directly (raw_ptr_buffer_load_lds, 1 KB per wave instruction, rows packed without padding), two stages, ONE barrier per
-// chunk: chunk c + 1 is in flight while chunk c is multiplied; no staging registers, no LDS stores.  116 VGPRs and 56 KB of
-// LDS: two workgroups (16 waves) per CU, one's barrier is the other's MFMA time.
+// chunk: chunk c + 1 is in flight while chunk c is multiplied; no staging registers, no LDS stores.
 // ---------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, float* lds_base, unsigned voff, int soff) {
@@ -221,10 +220,11 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, float* lds_base,
 #endif
 }
 
-constexpr int WD_MC = 16;          // rows per chunk: two stages of 16 rows = 56 KB (TK = 320), two workgroups per CU
+constexpr int WD_MC = 32;          // rows per chunk: two stages of 32 rows = 112 KB at TK = 320 (16-row chunks with two workgroups
+                                   // per CU measured the same kernel time and double the partial tiles to sum)
 
 template <int NKT>
-__global__ __launch_bounds__(WG_THREADS, 2) void wgrad_dma_kernel(const float* __restrict__ dy, long ldy, const float* __restrict__ x,
+__global__ __launch_bounds__(WG_THREADS) void wgrad_dma_kernel(const float* __restrict__ dy, long ldy, const float* __restrict__ x,
                                                                 long ldx, float* __restrict__ ws, int M, int N, int K, int n_tiles,
                                                                 int k_tiles, int rows_per_split, int ones_col) {
     constexpr int TK = 64 * NKT;
@@ -1296,7 +1296,7 @@ namespace {
 
 struct WgradPlan { int nkt, tk, n_tiles, k_tiles, splits, rows_per_split; long np, kp; };
 
-WgradPlan wgrad_plan(int M, int N, int K, int wg_per_cu = 2) {
+WgradPlan wgrad_plan(int M, int N, int K, int wg_per_cu = 1) {
     WgradPlan w;
     long best = -1;
     w.nkt = 4;
@@ -1310,7 +1310,7 @@ WgradPlan wgrad_plan(int M, int N, int K, int wg_per_cu = 2) {
     w.np = (long)w.n_tiles * WG_TN;
     w.kp = (long)w.k_tiles * w.tk;
     const int ntile = w.n_tiles * w.k_tiles;
-    int splits = 256 * wg_per_cu / ntile;                         // a single round of eight-wave workgroups (two per CU on the DMA kernel)
+    int splits = 256 * wg_per_cu / ntile;                         // a single round of eight-wave workgroups, one per CU
     const int max_splits = (M + 511) / 512;                       // at least 8 chunks of 64 rows per workgroup
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -1388,7 +1388,7 @@ extern "C" int lime_linear_wgrad_f32(const float* dy, int64_t ldy, const float* 
     LIME_REQUIRE(ldy >= N && ldx >= K && lddw >= K, LIME_ERR_BAD_ARG, "lime_linear_wgrad_f32: leading dimension smaller than the row");
     const bool vec = N % 4 == 0 && K % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 && ((((uintptr_t)dy) | ((uintptr_t)x)) & 15) == 0;
     static const bool no_dma = getenv("LIME_WGRAD_NO_DMA") != nullptr;        // A/B switch for tools/, not a product option
-    const WgradPlan w = wgrad_plan(M, N, K, (vec && !no_dma) ? 2 : 1);        // the DMA kernel fits two workgroups per CU
+    const WgradPlan w = wgrad_plan(M, N, K, 1);
     LIME_REQUIRE(workspace_floats >= lime_linear_wgrad_workspace(M, N, K), LIME_ERR_BAD_ARG,
                  "lime_linear_wgrad_f32: workspace holds %ld floats, lime_linear_wgrad_workspace() asks for %ld",
                  (long)workspace_floats, (long)lime_linear_wgrad_workspace(M, N, K));
