@@ -523,6 +523,8 @@ class TrainStep:
                 p.data = self.flat[off:off + n].view(p.shape)
                 p.grad = self.grad[off:off + n].view(p.shape)
                 off += align(n)
+        if hasattr(model, '_graphs'):
+            model._graphs = {}                  # captured scoring graphs hold the parameters' old addresses
         self.step_count = 0
         self.last_norm = None
 

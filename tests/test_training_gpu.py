@@ -174,3 +174,20 @@ def test_detached_bucket_is_detected():
     model.zero_grad()                      # set_to_none: the .grad views are gone
     with pytest.raises(RuntimeError, match='flat bucket'):
         step.step(*batch)
+
+
+def test_scoring_graph_captured_before_training_is_not_reused():
+    """A scoring HIP graph captured before TrainStep moved the parameters into its bucket must not be replayed afterwards
+    (it would read the old, now stale, parameter storage): scoring after training equals a fresh eager evaluation."""
+    cfg, model, batch = train_model('cfg1_crown')
+    with torch.no_grad():
+        before = model(*batch).clone()                     # captures the scoring graph
+    step = TrainStep(model, lr=1e-3)
+    for _ in range(2):
+        step.step(*batch)
+    with torch.no_grad():
+        after = model(*batch).clone()
+        model.use_graph = False
+        eager = model(*batch).clone()
+    assert rel_err(after.cpu().numpy(), eager.cpu().numpy()) < 1e-5
+    assert not torch.equal(after, before), 'two Adam steps at lr 1e-3 must change the scores'
