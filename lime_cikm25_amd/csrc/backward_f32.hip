@@ -409,21 +409,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
                                                                  const float* __restrict__ rstd, float* __restrict__ dz, long lddz,
                                                                  int M, int E, float* __restrict__ ws) {
     __shared__ float red[4][3][64 * V4];
+    __shared__ __attribute__((aligned(16))) float Gs[64 * V4], Bs[64 * V4], IGs[64 * V4];   // gamma, beta, 1 / gamma (registers are
+                                                                                          // for the column sums: occupancy)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane & 15, rg = lane >> 4;
     const f32x4v zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4v ga[V4], be[V4], iga[V4], sg[V4], sb[V4], sz[V4];
-    bool cin[V4];
-#pragma unroll
-    for (int j = 0; j < V4; ++j) {
-        const int c = 4 * (sub + 16 * j);
-        cin[j] = c < E;
-        ga[j] = cin[j] ? *reinterpret_cast<const f32x4v*>(gamma + c) : zero;
-        be[j] = cin[j] ? *reinterpret_cast<const f32x4v*>(beta + c) : zero;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) iga[j][e] = cin[j] ? 1.0f / ga[j][e] : 0.f;
-        sg[j] = sb[j] = sz[j] = zero;
+    for (int c = threadIdx.x; c < 64 * V4; c += 256) {
+        const float g = c < E ? gamma[c] : 0.f;
+        Gs[c] = g;
+        Bs[c] = c < E ? beta[c] : 0.f;
+        IGs[c] = c < E ? 1.0f / g : 0.f;
     }
+    __syncthreads();
+    f32x4v sg[V4], sb[V4], sz[V4];
+#pragma unroll
+    for (int j = 0; j < V4; ++j) sg[j] = sb[j] = sz[j] = zero;
     const float inv_e = 1.0f / (float)E;
     for (long r4 = ((long)blockIdx.x * 4 + wave) * 4; r4 < M; r4 += (long)gridDim.x * 16) {
         const long r = r4 + rg;
@@ -432,14 +432,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
         const float* py = y + (rin ? r : 0) * ldy;
         f32x4v d[V4], xh[V4];
         float s1 = 0.f, s2 = 0.f;
+        // the three vectors are re-read from LDS for every row: hidden from the optimiser, which would otherwise hoist the
+        // loop-invariant loads back into 60 registers
+        const float *gs = Gs, *bs = Bs, *igs = IGs;
+        asm volatile("" : "+v"(gs), "+v"(bs), "+v"(igs));
 #pragma unroll
         for (int j = 0; j < V4; ++j) {
             const int c = 4 * (sub + 16 * j);
-            const bool ok = rin && cin[j];
+            const bool ok = rin && c < E;
+            const f32x4v ga = *reinterpret_cast<const f32x4v*>(&gs[c]), be = *reinterpret_cast<const f32x4v*>(&bs[c]);
             d[j] = ok ? *reinterpret_cast<const f32x4v*>(pdy + c) * dy_scale : zero;
-            const f32x4v yv = ok ? *reinterpret_cast<const f32x4v*>(py + c) : be[j];
-            xh[j] = (yv - be[j]) * iga[j];
-            const f32x4v g = d[j] * ga[j];
+            const f32x4v yv = ok ? *reinterpret_cast<const f32x4v*>(py + c) : be;
+            xh[j] = (yv - be) * *reinterpret_cast<const f32x4v*>(&igs[c]);
+            const f32x4v g = d[j] * ga;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { s1 += g[e]; s2 += g[e] * xh[j][e]; }
         }
@@ -452,9 +457,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
 #pragma unroll
         for (int j = 0; j < V4; ++j) {
             const int c = 4 * (sub + 16 * j);
-            f32x4v v = (d[j] * ga[j] - s1 - xh[j] * s2) * rs;
-            if (!(rin && cin[j])) v = zero;
-            if (rin && cin[j]) *reinterpret_cast<f32x4v*>(dz + r * lddz + c) = v;
+            const bool ok = rin && c < E;
+            f32x4v v = (d[j] * *reinterpret_cast<const f32x4v*>(&gs[c]) - s1 - xh[j] * s2) * rs;
+            if (!ok) v = zero;
+            if (ok) *reinterpret_cast<f32x4v*>(dz + r * lddz + c) = v;
             sg[j] += d[j] * xh[j];
             sb[j] += d[j];
             sz[j] += v;
