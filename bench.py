@@ -50,6 +50,8 @@ WORKLOADS = {
     # one training step = forward + backward + gradient all-reduce (N > 1) + clip_grad_norm_ + Adam
     'train2b': (dict(), 32, 5, 'training step (forward + backward + gradient all-reduce + clip + Adam), LIME-CROWN-CROWN, '
                                'batch=32 per GPU, history=50, title 32 + body 128, K=1+4, fp32, dropout off'),
+    'train2a': (dict(content_encoder='MHSA'), 32, 5, 'training step, LIME-MHSA-CROWN (title only), batch=32 per GPU, history=50, '
+                                                     'title_len=32, K=1+4, fp32, dropout off'),
     'train2b_dropout': (dict(dropout_rate=0.2), 32, 5,
                         'training step as train2b with the dropout_rate = 0.2 of the reference (config.py:78) in every encoder dropout '
                         'site (model.train()), counter-based masks'),

@@ -351,12 +351,15 @@ int lime_relu_bwd_f32(float* dh, int64_t lddh, const float* h, int64_t ldh, int6
  * S <= 512, head_dim <= head_stride <= 32.  S <= 128: one pass per (sequence, head); `out` and `workspace` may be NULL.
  * 128 < S <= 512 (the 512-token bodies of BASELINE config 4): 128 x 128 blocks; needs the forward output `out` (packed like
  * dout) and lime_token_attention_bwd_workspace(n_seq, S, n_head) floats; the key blocks' shares of dq are added with float
- * atomics.  dropout_p > 0: the forward was lime_token_attention_dropout_f32 with the same (dropout_p, seed, site). */
+ * atomics.  dropout_p > 0: the forward was lime_token_attention_dropout_f32 with the same (dropout_p, seed, site).
+ * key_mask (uint8 [n_seq, S], 0 = masked, or NULL; S <= 128): the masked attention of layers.MultiHeadAttention
+ * (layers.py:227-232) -- masked scores are constants (-1e9) and receive no gradient. */
 int64_t lime_token_attention_bwd_workspace(int32_t n_seq, int32_t S, int32_t n_head);
 int lime_token_attention_bwd_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out, int64_t ld_out,
                                  const float* dout, int64_t ldo, float* dq, float* dk, float* dv, int64_t ld_dqkv, int32_t n_seq,
                                  int32_t S, int32_t n_head, int32_t head_dim, int32_t head_stride, float scale, float* workspace,
-                                 int64_t workspace_floats, float dropout_p, uint64_t seed, uint32_t site, void* stream);
+                                 int64_t workspace_floats, float dropout_p, uint64_t seed, uint32_t site, const uint8_t* key_mask,
+                                 void* stream);
 
 /* ---- dropout inside the token encoders in training mode --------------------------------------------------------------
  * Masks are a pure function of (seed, site, element index) (csrc/dropout.h): element e of site `site` is kept iff

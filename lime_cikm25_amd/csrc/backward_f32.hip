@@ -521,7 +521,7 @@ __global__ __launch_bounds__(512) void token_attn_bwd_kernel(const float* __rest
                                                               long ldo, float* __restrict__ dq, float* __restrict__ dk,
                                                               float* __restrict__ dv, long ldd, int n_seq, int S, int n_head,
                                                               int head_dim, int head_stride, float scale, int vec,
-                                                              LimeDropout drop) {
+                                                              LimeDropout drop, const unsigned char* __restrict__ key_mask) {
     constexpr int NT = SP / 16;                 // 16-column score tiles per row
     constexpr int WPP = SP / 16;                // waves per problem
     constexpr int PPW = 8 / WPP;                // problems per workgroup
@@ -652,6 +652,12 @@ __global__ __launch_bounds__(512) void token_attn_bwd_kernel(const float* __rest
                 p[ct] = s0; dp[ct] = d0; p[ct + 1] = s1; dp[ct + 1] = d1;
             }
         }
+        // key mask of layers.MultiHeadAttention (layers.py:227-232: masked_fill(mask == 0, -1e9) before the softmax): a masked
+        // score is a constant, its dS is zero
+        bool kmask[NT];
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+            kmask[ct] = key_mask != nullptr && live && 16 * ct + fi < S && key_mask[(long)seq * S + 16 * ct + fi] == 0;
         // softmax over the row (columns: tiles ct x the 16 lanes with the same kg), then delta and dS
 #pragma unroll
         for (int r = 0; r < ((LIME_ATTN_BWD_ABLATE & 4) ? 0 : 4); ++r) {
@@ -659,7 +665,7 @@ __global__ __launch_bounds__(512) void token_attn_bwd_kernel(const float* __rest
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
                 const bool col_ok = 16 * ct + fi < S;
-                const float sv = col_ok ? p[ct][r] * (scale * LOG2E) : -INFINITY;
+                const float sv = col_ok ? (kmask[ct] ? -1e9f * LOG2E : p[ct][r] * (scale * LOG2E)) : -INFINITY;
                 p[ct][r] = sv;
                 mx = fmaxf(mx, sv);
             }
@@ -690,7 +696,7 @@ __global__ __launch_bounds__(512) void token_attn_bwd_kernel(const float* __rest
             }
             dl += __shfl_xor(dl, 1); dl += __shfl_xor(dl, 2); dl += __shfl_xor(dl, 4); dl += __shfl_xor(dl, 8);
 #pragma unroll
-            for (int ct = 0; ct < NT; ++ct) dp[ct][r] = scale * p[ct][r] * (dp[ct][r] - dl);      // dS
+            for (int ct = 0; ct < NT; ++ct) dp[ct][r] = kmask[ct] ? 0.f : scale * p[ct][r] * (dp[ct][r] - dl);      // dS
         }
         // P (as the forward multiplied it into V) -> LDS
 #pragma unroll
@@ -1491,7 +1497,7 @@ namespace {
 template <int SP>
 int launch_attn_bwd(const float* q, const float* k, const float* v, long ld, const float* dout, long ldo, float* dq, float* dk,
                     float* dv, long ldd, int n_seq, int S, int n_head, int head_dim, int head_stride, float scale,
-                    const LimeDropout& drop, hipStream_t s) {
+                    const LimeDropout& drop, const unsigned char* key_mask, hipStream_t s) {
     constexpr int PPW = 8 / (SP / 16);
     constexpr int BYTES = PPW * (4 * SP * AB_LD + SP * (SP + 2)) * 4;
     static bool configured = false;
@@ -1511,7 +1517,7 @@ int launch_attn_bwd(const float* q, const float* k, const float* v, long ld, con
     const bool vec = head_stride == 32 && ld % 4 == 0 && ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) == 0 &&
                      head_dim % 2 == 0 && ldo % 2 == 0 && (((uintptr_t)dout) & 7) == 0;
     token_attn_bwd_kernel<SP><<<grid, 512, BYTES, s>>>(q, k, v, ld, dout, ldo, dq, dk, dv, ldd, n_seq, S, n_head, head_dim,
-                                                      head_stride, scale, vec ? 1 : 0, drop);
+                                                      head_stride, scale, vec ? 1 : 0, drop, key_mask);
     return lime_check_launch("token_attn_bwd_kernel");
 }
 
@@ -1543,7 +1549,7 @@ extern "C" int lime_token_attention_bwd_f32(const float* q, const float* k, cons
                                             int64_t ld_out, const float* dout, int64_t ldo, float* dq, float* dk, float* dv,
                                             int64_t ld_dqkv, int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim,
                                             int32_t head_stride, float scale, float* workspace, int64_t workspace_floats,
-                                            float dropout_p, uint64_t seed, uint32_t site, void* stream) {
+                                            float dropout_p, uint64_t seed, uint32_t site, const uint8_t* key_mask, void* stream) {
     LIME_REQUIRE(q && k && v && dout && dq && dk && dv, LIME_ERR_BAD_ARG, "lime_token_attention_bwd_f32: null pointer");
     LIME_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, LIME_ERR_BAD_ARG, "lime_token_attention_bwd_f32: dropout_p outside [0, 1)");
     const LimeDropout drop = lime_make_dropout(dropout_p, seed, site);
@@ -1555,10 +1561,11 @@ extern "C" int lime_token_attention_bwd_f32(const float* q, const float* k, cons
                  LIME_ERR_BAD_ARG, "lime_token_attention_bwd_f32: leading dimension smaller than the row");
     if (n_seq == 0) return LIME_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (S <= 32) return launch_attn_bwd<32>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, drop, s);
-    if (S <= 64) return launch_attn_bwd<64>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, drop, s);
-    if (S <= 128) return launch_attn_bwd<128>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, drop, s);
+    if (S <= 32) return launch_attn_bwd<32>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, drop, key_mask, s);
+    if (S <= 64) return launch_attn_bwd<64>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, drop, key_mask, s);
+    if (S <= 128) return launch_attn_bwd<128>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, drop, key_mask, s);
     // blocked path
+    LIME_REQUIRE(key_mask == nullptr, LIME_ERR_UNSUPPORTED, "lime_token_attention_bwd_f32: a key mask needs S <= 128");
     LIME_REQUIRE(out && ld_out >= (int64_t)n_head * head_dim, LIME_ERR_BAD_ARG,
                  "lime_token_attention_bwd_f32: S > 128 needs the forward output `out` (delta = dO . O)");
     LIME_REQUIRE(workspace && workspace_floats >= lime_token_attention_bwd_workspace(n_seq, S, n_head), LIME_ERR_BAD_ARG,

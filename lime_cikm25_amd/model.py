@@ -78,10 +78,10 @@ class Model(nn.Module):
                 news_content_entity, news_freshness, news_user_topic_lifetime, remaining_lifetime)
         if self.training and torch.is_grad_enabled():
             # trainer.py:131-145: model.train(); logits = model(...); loss.backward() -- the differentiable path
-            return training.forward_train(self, user_category, user_subCategory, user_title_text, user_content_text,
-                                          user_freshness, user_user_topic_lifetime, user_history_mask, news_category,
-                                          news_subCategory, news_title_text, news_content_text, news_freshness,
-                                          news_user_topic_lifetime, remaining_lifetime)
+            return training.forward_train(self, user_category, user_subCategory, user_title_text, user_title_mask,
+                                          user_content_text, user_freshness, user_user_topic_lifetime, user_history_mask,
+                                          news_category, news_subCategory, news_title_text, news_title_mask, news_content_text,
+                                          news_freshness, news_user_topic_lifetime, remaining_lifetime)
         if (self.use_graph and ops.PROFILE is None and user_category.is_cuda
                 and not torch.cuda.is_current_stream_capturing()):
             return self._forward_graphed(args)

@@ -652,7 +652,7 @@ def relu_bwd_(dh, h, scale=1.0):
 
 
 def token_attention_bwd(q, k, v, dout, n_seq, S, n_head, head_dim, scale, head_stride=None, dqkv=None, out=None,
-                        dropout=None):
+                        dropout=None, key_mask=None):
     """Backward of the unmasked ``token_attention``: q / k / v column views of one packed qkv buffer [tokens, 3 * n_head *
     head_stride]; returns dqkv in the same layout.  ``out``: the forward's result (needed for S > 128).  ``dropout``:
     (p, seed, site) of the ``token_attention_dropout`` forward."""
@@ -682,8 +682,8 @@ def token_attention_bwd(q, k, v, dout, n_seq, S, n_head, head_dim, scale, head_s
         ws = _workspace(q.device, need)
     check(lib.lime_token_attention_bwd_f32(_p(q), _p(k), _p(v), _ld(q), _p(out), _ld(out) if out is not None else 0, _p(dout),
                                            _ld(dout), _p(dq), _p(dk), _p(dv), _ld(dqkv), n_seq, S, n_head, head_dim, hs, scale,
-                                           _p(ws), ws.numel() if ws is not None else 0, *(dropout or (0.0, 0, 0)), _stream()),
-          'lime_token_attention_bwd_f32')
+                                           _p(ws), ws.numel() if ws is not None else 0, *(dropout or (0.0, 0, 0)),
+                                           _p(_mask_u8(key_mask, 'key_mask')), _stream()), 'lime_token_attention_bwd_f32')
     return dqkv
 
 

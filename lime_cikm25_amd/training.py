@@ -77,27 +77,29 @@ class _GatherRows(torch.autograd.Function):
     """table[idx] (nn.Embedding forward) on the gather kernel; backward = the scatter-add kernel."""
 
     @staticmethod
-    def forward(ctx, idx, table):
+    def forward(ctx, idx, table, hot_id):
         out = torch.empty((idx.numel(), table.shape[1]), dtype=torch.float32, device=table.device)
         ops.gather_rows(idx, table, out)
         ctx.save_for_backward(idx)
         ctx.shape = tuple(table.shape)
+        ctx.hot_id = hot_id
         return out
 
     @staticmethod
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
         dtable = torch.zeros(ctx.shape, dtype=torch.float32, device=dy.device)
-        ops.embed_bwd(idx, dy.contiguous(), dtable, hot_id=-1)
-        return None, dtable
+        ops.embed_bwd(idx, dy.contiguous(), dtable, hot_id=ctx.hot_id)
+        return None, dtable, None
 
 
-def embedding(table, idx):
-    """table[idx] for an integer tensor idx of any shape -> [*idx.shape, dim]."""
+def embedding(table, idx, hot_id=-1):
+    """table[idx] for an integer tensor idx of any shape -> [*idx.shape, dim].  ``hot_id``: a row that a large share of the
+    indices hit (the padding word), summed per wave before it reaches memory in the backward."""
     flat = idx.reshape(-1)
     flat = (flat if flat.dtype == torch.int32 else flat.to(torch.int32)).contiguous()
     if table.requires_grad and torch.is_grad_enabled():
-        out = _GatherRows.apply(flat, table)
+        out = _GatherRows.apply(flat, table, hot_id)
     else:
         out = torch.empty((flat.numel(), table.shape[1]), dtype=torch.float32, device=table.device)
         ops.gather_rows(flat, table, out)
@@ -163,6 +165,42 @@ class _CandAttnWeights(torch.autograd.Function):
         (B, N, H, D), n_head, p, seed = ctx.cfg
         dqp, dkp = ops.cand_attn_weights_bwd(qp.view(-1), kp.view(-1), mask, dagg, B, N, H, D, n_head, p, seed, 0)
         return dqp.view_as(qp), dkp.view_as(kp), None, None, None, None, None
+
+
+class _Dropout(torch.autograd.Function):
+    """nn.Dropout on the counter-based masks (csrc/dropout.h): the backward re-applies the mask of (seed, site)."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, site):
+        ctx.cfg = (p, seed, site)
+        return ops.dropout(x.contiguous(), p, seed, site)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, site = ctx.cfg
+        return ops.dropout(dy.contiguous(), p, seed, site), None, None, None
+
+
+class _MaskedAttention(torch.autograd.Function):
+    """The attention core of layers.MultiHeadAttention (layers.py:227-237): softmax(Q K^T / sqrt(d_k), key mask -1e9) V on the
+    packed [tokens, 3 h d_k] projections."""
+
+    @staticmethod
+    def forward(ctx, qkv, mask, n_seq, S, h, dk):
+        W = h * dk
+        out = ops.token_attention(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], n_seq, S, h, dk, 1.0 / math.sqrt(float(dk)), key_mask=mask)
+        ctx.dims = (n_seq, S, h, dk)
+        ctx.save_for_backward(qkv, mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, mask = ctx.saved_tensors
+        n_seq, S, h, dk = ctx.dims
+        W = h * dk
+        dqkv = ops.token_attention_bwd(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], dout.contiguous(), n_seq, S, h, dk,
+                                       1.0 / math.sqrt(float(dk)), key_mask=mask)
+        return dqkv, None, None, None, None, None
 
 
 class _InterestMatch(torch.autograd.Function):
@@ -348,10 +386,7 @@ def crown_tail(enc, title_p, body_p, category, subCategory):
 
 def pooled_tokens(ne, title_text, content_text):
     """The two token encoders of the CROWN content encoder (newsEncoders.py:311-321) on M flat news -> 2 x [M, 300]."""
-    from .newsEncoders import CROWN
     enc = ne.base_news_encoder
-    if not isinstance(enc, CROWN):
-        raise NotImplementedError('the training path covers the CROWN content encoder (LIME-CROWN-CROWN)')
     table = enc.word_embedding.weight
     p_emb = enc.dropout.p if enc.training else 0.0                                                              # :311-312
     title_p = encode_tokens(title_text, table, enc.title_pos_encoder, enc.title_transformer, enc.head_num, p_emb)   # :311-317
@@ -359,9 +394,35 @@ def pooled_tokens(ne, title_text, content_text):
     return title_p, body_p
 
 
-def lime_tail(ne, title_p, body_p, category, subCategory, freshness, lifetime):
-    """LIME.forward, fusion 'concat' (newsEncoders.py:140-153), after the token encoders -> [M, 400]."""
-    content = crown_tail(ne.base_news_encoder, title_p, body_p, category, subCategory)
+def mhsa_content(enc, title_text, title_mask, category, subCategory):
+    """newsEncoders.MHSA.forward (newsEncoders.py:582-595; title only) on M flat news -> [M, h d_k + 100]."""
+    M, T = title_text.shape
+    if T > 128:
+        raise NotImplementedError('the masked attention backward covers sequences of at most 128 tokens (got %d)' % T)
+    mha, att = enc.multiheadAttention, enc.attention
+    if mha.d_k != mha.d_v:
+        raise NotImplementedError('d_k != d_v')
+    p = float(enc.dropout.p) if enc.training else 0.0
+    seed = _draw_seed() if p > 0 else 0
+    x = embedding(enc.word_embedding.weight, title_text, hot_id=0).view(M * T, -1)                              # :588
+    if p > 0:
+        x = _Dropout.apply(x, p, seed, 0)
+    w = torch.cat([mha.W_Q.weight, mha.W_K.weight, mha.W_V.weight], dim=0)
+    b = torch.cat([mha.W_Q.bias, mha.W_K.bias, mha.W_V.bias], dim=0)
+    mask = title_mask.contiguous()
+    c = _MaskedAttention.apply(_Linear.apply(x, w, b, None), mask, M, T, mha.h, mha.d_k)                         # :590, layers.py:222-238
+    if p > 0:
+        c = _Dropout.apply(c, p, seed, 1)
+    hidden = linear(c, att.affine1, act='tanh')                                                                 # layers.py:288
+    score = (hidden * att.affine2.weight.view(1, -1)).sum(dim=-1).view(M, T).masked_fill(mask == 0, -1e9)
+    rep = (torch.softmax(score, dim=1).unsqueeze(-1) * c.view(M, T, -1)).sum(dim=1)                             # :592
+    cat_e = embedding(enc.category_embedding.weight, category)
+    sub_e = embedding(enc.subCategory_embedding.weight, subCategory)
+    return torch.cat([rep, enc.dropout(cat_e.clone()), enc.dropout(sub_e.clone())], dim=1)                      # :594
+
+
+def lime_tail(ne, content, freshness, lifetime):
+    """LIME.forward, fusion 'concat' (newsEncoders.py:140-153), from the content encoder's output -> [M, 400]."""
     fe = ne.freshness_encoder
     fb = ops.bucketize(freshness)
     lb = ops.bucketize(lifetime)
@@ -420,26 +481,16 @@ def user_logits(ue, weighting, hist, cand, category, subCategory, user_category,
                                 bool(w.use_remaining_lifetime_weighting), bool(w.use_expired_penalty))               # :163-168
 
 
-def tail_forward(model, title_p, body_p, category, subCategory, freshness, lifetime, news_category, news_subCategory, user_category,
-                 user_subCategory, user_history_mask, remaining_lifetime):
-    """Everything of Model.forward after the token encoders: intent disentanglement / fusion / freshness / project per news,
-    then the CROWN user encoder and the lifetime-weighted dot product.  3 % of the FLOPs in some 400 small launches forward +
-    backward (4 ms of kernel time at config 2b: the launches are short, not sparse -- capturing them into HIP graphs with
-    torch.cuda.make_graphed_callables was measured and changed nothing; fewer, fused kernels are what is missing)."""
-    B, N = news_category.shape
-    H = user_category.shape[1]
-    rep = lime_tail(model.news_encoder, title_p, body_p, category, subCategory, freshness, lifetime)
-    cand = rep[:B * N].view(B, N, -1)
-    hist = rep[B * N:].view(B, H, -1)
-    return user_logits(model.user_encoder, model.remaining_lifetime_weighting, hist, cand, news_category, news_subCategory,
-                       user_category, user_subCategory, user_history_mask, remaining_lifetime)
-
-
-def forward_train(model, user_category, user_subCategory, user_title_text, user_content_text, user_freshness,
-                  user_user_topic_lifetime, user_history_mask, news_category, news_subCategory, news_title_text,
+def forward_train(model, user_category, user_subCategory, user_title_text, user_title_mask, user_content_text, user_freshness,
+                  user_user_topic_lifetime, user_history_mask, news_category, news_subCategory, news_title_text, news_title_mask,
                   news_content_text, news_freshness, news_user_topic_lifetime, remaining_lifetime):
-    """Model.forward with [B, N] candidates (model.py:171-187), recording the autograd graph."""
-    ne = model.news_encoder
+    """Model.forward with [B, N] candidates (model.py:171-187), recording the autograd graph.  Candidates and history go
+    through the news encoder as one flat batch of B (N + H) news.  After the token encoders come the content tail, freshness
+    and project per news, then the CROWN user encoder and the lifetime-weighted dot product: 3 % of the FLOPs in some 300
+    short launches forward + backward (4 ms of kernel time at config 2b -- short kernels, not idle gaps: capturing them into
+    HIP graphs with torch.cuda.make_graphed_callables was measured and changed nothing)."""
+    from .newsEncoders import CROWN, MHSA
+    ne, enc = model.news_encoder, model.news_encoder.base_news_encoder
     B, N = news_category.shape
     H = user_category.shape[1]
     i32 = lambda t: t if t.dtype == torch.int32 else t.to(torch.int32)
@@ -449,13 +500,22 @@ def forward_train(model, user_category, user_subCategory, user_title_text, user_
         news_freshness = news_freshness.unsqueeze(1).expand(B, N)
     if news_user_topic_lifetime.dim() == 1:
         news_user_topic_lifetime = news_user_topic_lifetime.unsqueeze(1).expand(B, N)
-    title_p, body_p = pooled_tokens(ne, i32(flat2(news_title_text, user_title_text)), i32(flat2(news_content_text, user_content_text)))
-    args = (title_p, body_p, i32(flat1(news_category, user_category)), i32(flat1(news_subCategory, user_subCategory)),
-            flat1(news_freshness.float(), user_freshness.float()).contiguous(),
-            flat1(news_user_topic_lifetime.float(), user_user_topic_lifetime.float()).contiguous(),
-            i32(news_category).contiguous(), i32(news_subCategory).contiguous(), i32(user_category).contiguous(),
-            i32(user_subCategory).contiguous(), user_history_mask.contiguous(), remaining_lifetime.float().contiguous())
-    return tail_forward(model, *args)
+    category, subCategory = i32(flat1(news_category, user_category)), i32(flat1(news_subCategory, user_subCategory))
+    if isinstance(enc, CROWN):
+        title_p, body_p = pooled_tokens(ne, i32(flat2(news_title_text, user_title_text)), i32(flat2(news_content_text, user_content_text)))
+        content = crown_tail(enc, title_p, body_p, category, subCategory)
+    elif isinstance(enc, MHSA):
+        content = mhsa_content(enc, i32(flat2(news_title_text, user_title_text)), flat2(news_title_mask, user_title_mask), category,
+                               subCategory)
+    else:
+        raise NotImplementedError('the training path covers the CROWN and MHSA content encoders')
+    rep = lime_tail(ne, content, flat1(news_freshness.float(), user_freshness.float()).contiguous(),
+                    flat1(news_user_topic_lifetime.float(), user_user_topic_lifetime.float()).contiguous())
+    cand = rep[:B * N].view(B, N, -1)
+    hist = rep[B * N:].view(B, H, -1)
+    return user_logits(model.user_encoder, model.remaining_lifetime_weighting, hist, cand, i32(news_category).contiguous(),
+                       i32(news_subCategory).contiguous(), i32(user_category).contiguous(), i32(user_subCategory).contiguous(),
+                       user_history_mask.contiguous(), remaining_lifetime.float().contiguous())
 
 
 # ---------------------------------------------------------------------------------------------------------------------

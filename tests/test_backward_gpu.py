@@ -279,3 +279,26 @@ def test_cand_attn_weights_train_and_bwd(ops, B, N, H, nh, hd, p):
     dqp, dkp = ops.cand_attn_weights_bwd(qp.cuda().view(-1), kp.cuda().view(-1), mask.cuda(), dagg.cuda(), B, N, H, D, nh, p, seed, 0)
     close(dqp, qd.grad.float(), tol=2e-4, what='dqp')
     close(dkp, kd.grad.float(), tol=2e-4, what='dkp')
+
+
+@pytest.mark.parametrize('n_seq,S,nh,hd', [(6, 32, 10, 20), (3, 16, 10, 20), (2, 100, 4, 32)])
+def test_masked_token_attention_bwd(ops, n_seq, S, nh, hd):
+    """layers.MultiHeadAttention's attention core (key mask filled with -1e9, layers.py:227-237) forward and backward."""
+    tok, W = n_seq * S, nh * hd
+    scale = 1.0 / math.sqrt(hd)
+    vals = rnd(tok, 3, nh, hd, seed=1)
+    dout = rnd(tok, W, seed=2)
+    g = torch.Generator().manual_seed(4)
+    lens = torch.randint(1, S + 1, (n_seq,), generator=g)
+    lens[0] = 0                                                      # a sequence with every key masked
+    mask = torch.arange(S).unsqueeze(0) < lens.unsqueeze(1)
+    x = vals.double().requires_grad_()
+    q, k, v = (x[:, i].reshape(n_seq, S, nh, hd).permute(0, 2, 1, 3) for i in range(3))
+    a = (q @ k.transpose(-1, -2) * scale).masked_fill(mask.view(n_seq, 1, 1, S) == 0, -1e9)
+    o = (torch.softmax(a, dim=-1) @ v).permute(0, 2, 1, 3).reshape(tok, W)
+    o.backward(dout.double())
+    qkv = vals.reshape(tok, 3 * W).cuda()
+    out = ops.token_attention(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], n_seq, S, nh, hd, scale, key_mask=mask.cuda())
+    close(out, o.detach().float(), what='masked attention forward')
+    dqkv = ops.token_attention_bwd(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], dout.cuda(), n_seq, S, nh, hd, scale, key_mask=mask.cuda())
+    close(dqkv, x.grad.float().reshape(tok, 3 * W), tol=2e-4, what='masked dqkv')

@@ -119,10 +119,11 @@ def test_p_zero_is_the_fused_path(ops):
     assert rel_err(y.cpu().numpy(), want.numpy()) < 2e-5
 
 
-def test_model_trains_with_the_reference_dropout_rate():
-    """model.train() at dropout_rate = 0.2 (the reference's config.py:78): finite loss and gradients, repeatable under
-    torch.manual_seed, different under another seed; eval-mode scoring is untouched."""
-    cfg, batch, c = golden_cases.build_case('cfg1_crown')
+@pytest.mark.parametrize('case,probe', [('cfg1_crown', 'title_transformer.layers.0.linear1.weight'), ('cfg1_mhsa', 'multiheadAttention.W_V.weight')])
+def test_model_trains_with_the_reference_dropout_rate(case, probe):
+    """model.train() at dropout_rate = 0.2 (the reference's config.py:78), both content encoders: finite loss and gradients,
+    repeatable under torch.manual_seed, different under another seed."""
+    cfg, batch, c = golden_cases.build_case(case)
     cfg.dropout_rate = 0.2
     model = Model(cfg)
     model.initialize()
@@ -135,7 +136,7 @@ def test_model_trains_with_the_reference_dropout_rate():
         model.zero_grad()
         loss = T.negative_log_softmax(model(*b))
         loss.backward()
-        return float(loss.detach()), model.news_encoder.base_news_encoder.title_transformer.layers[0].linear1.weight.grad.clone()
+        return float(loss.detach()), dict(model.news_encoder.base_news_encoder.named_parameters())[probe].grad.clone()
 
     l1, g1 = run(11)
     l2, g2 = run(11)

@@ -16,7 +16,7 @@ from lime_cikm25_amd.training import TrainStep, negative_log_softmax
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
 LR = 1e-5
-GRAD_CASES = ['cfg1_crown', 'spill', 'empty_history', 'full_len', 'long_body']
+GRAD_CASES = ['cfg1_crown', 'cfg1_mhsa', 'spill', 'empty_history', 'full_len', 'long_body']
 
 
 def train_model(name):
@@ -48,10 +48,10 @@ def compare_grads(g, named):
         scale = float(g['norm:' + k]) / max(1.0, got.numel()) ** 0.5          # rms of the reference gradient
         if 'full:' + k in g.files_:
             want = g['full:' + k].reshape(-1)
-            e = rel_err(got.numpy(), want, floor=max(scale, 1e-6))
+            e = rel_err(got.numpy(), want, floor=max(scale, 1e-5))
         else:
             idx, want = g['idx:' + k], g['val:' + k]
-            e = rel_err(got.numpy()[idx], want, floor=max(scale, 1e-6))
+            e = rel_err(got.numpy()[idx], want, floor=max(scale, 1e-5))
             e = max(e, abs(float(got.norm()) - float(g['norm:' + k])) / (float(g['norm:' + k]) + 1e-6))
         if e > worst[1]:
             worst = (k, e)

@@ -36,7 +36,7 @@ def main():
         f.restype = ctypes.c_int32
         f.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64] + \
                      [ctypes.c_void_p] * 3 + [ctypes.c_int64] + [ctypes.c_int32] * 5 + [ctypes.c_float, ctypes.c_void_p, ctypes.c_int64,
-                                                                                      ctypes.c_float, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p]
+                                                                                      ctypes.c_float, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
         line = 'mask %2d' % mask
         for n_seq, S in ((1760, 128), (1760, 32)):
             tok = n_seq * S
@@ -47,7 +47,7 @@ def main():
 
             def run():
                 st = f(P(qkv), P(qkv, W), P(qkv, 2 * W), 3 * W, None, 0, P(dout), nh * hd, P(dqkv), P(dqkv, W), P(dqkv, 2 * W), 3 * W,
-                       n_seq, S, nh, hd, hs, 1.0 / hd ** 0.5, None, 0, 0.0, 0, 0, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                       n_seq, S, nh, hd, hs, 1.0 / hd ** 0.5, None, 0, 0.0, 0, 0, None, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
                 assert st == 0
             for _ in range(3):
                 run()
