@@ -3,10 +3,9 @@ lines, turned into the in-memory records ``device_data.DeviceBehaviors`` consume
 builds at corpus.py:478-552 (train) and :556-650 (dev / test).  Host-side text parsing; no tokenisation (vocabulary building,
 GloVe lookup and the knowledge-graph files of corpus.py:27-296 stay with the reference's preprocessing).
 
-Parity: restated from the cited lines and exercised on hand-written fixtures (tests/test_formats.py).  **Parity unpinned**: the
-reference's parser is one 350-line constructor that also needs the files its own preprocessing writes, so it was not run to
-produce goldens; the record layouts are the ones the batch-assembly goldens (tests/golden/dataset_*.npz, captured from the
-imported ``Train_Dataset`` / ``DevTest_Dataset``) consume.
+Parity: pinned by tests/golden/formats.json -- the records the IMPORTED reference's ``Corpus`` parsed out of a synthetic dataset
+directory (tools/make_format_goldens.py writes the tsv files in the reference's layout, runs corpus.py on them and stores its
+train / dev / test records next to the lines); tests/test_formats.py requires equality, record for record.
 
 Upstream defect kept visible: the dev / test loops look the candidate's topic up with ``news_idx`` -- the loop variable LEFT
 OVER from the train loop (corpus.py:582, :630) -- instead of the candidate's own ``news_index``, so every dev / test candidate

@@ -1,7 +1,6 @@
 """On-disk formats: the 6-column behaviors.tsv and 8-column news.tsv lines of the reference
-(corpus.py:384-400, :478-650) through lime_cikm25_amd.formats, on hand-written fixtures.  Parity unpinned at this boundary
-(the reference's parser was not run, see formats.py); what IS checked against the reference-derived goldens is that the
-records have the layout the batch assembly consumes (oracle.assemble_* is pinned by tests/golden/dataset_*.npz)."""
+(corpus.py:384-400, :478-650) through lime_cikm25_amd.formats: hand-written fixtures first (readable expectations), then
+equality with what the imported reference's Corpus parsed out of a synthetic dataset (tests/golden/formats.json)."""
 import json
 from types import SimpleNamespace
 
@@ -101,3 +100,49 @@ def test_records_feed_the_batch_assembly():
     out = O.assemble_devtest(c, 'dev', [0, 1, 2])
     assert out[0].tolist() == [0, 0, 2]                              # user ids
     assert np.asarray(out[15]).tolist() == [1, 3, 2]                 # news_category of candidates N1, N4, N2
+
+
+# ---- pinned against the reference: tests/golden/formats.json holds what the imported reference's Corpus (corpus.py) parsed out
+# ---- of a synthetic dataset directory (tools/make_format_goldens.py); the tsv lines are stored beside its records
+def _golden():
+    import os
+    from helpers import GOLDEN_DIR
+    return json.load(open(os.path.join(GOLDEN_DIR, 'formats.json')))
+
+
+def _norm(records):
+    return [[x.tolist() if isinstance(x, np.ndarray) else x for x in r] for r in records]
+
+
+def test_train_records_equal_the_reference_corpus():
+    g = _golden()
+    names = {int(k): v for k, v in g['category_index_to_name'].items()}
+    recs, left_over = formats.train_records(g['lines']['train_behaviors'], g['news_ID_dict'], g['user_ID_dict'], g['news_category'],
+                                            names, g['max_history_num'])
+    assert _norm(recs) == g['train_behaviors']
+    assert left_over is not None
+
+
+@pytest.mark.parametrize('split', ['dev', 'test'])
+def test_devtest_records_equal_the_reference_corpus(split):
+    """With the stale index the reference's loops reuse (corpus.py:582, :630) the records are the reference's, bit for bit; the
+    per-candidate lookup (the default) differs exactly in the user-topic lifetime column."""
+    g = _golden()
+    names = {int(k): v for k, v in g['category_index_to_name'].items()}
+    _, left_over = formats.train_records(g['lines']['train_behaviors'], g['news_ID_dict'], g['user_ID_dict'], g['news_category'],
+                                         names, g['max_history_num'])
+    args = (g['lines'][split + '_behaviors'], g['news_ID_dict'], g['user_ID_dict'], g['news_category'], names, g['max_history_num'])
+    recs, idx = formats.devtest_records(*args, stale_news_index=left_over)
+    assert _norm(recs) == g[split + '_behaviors'] and idx == g[split + '_indices']
+    fixed, idx2 = formats.devtest_records(*args)
+    assert idx2 == idx
+    diff_cols = {j for a, b in zip(_norm(fixed), g[split + '_behaviors']) for j, (x, y) in enumerate(zip(a, b)) if x != y}
+    assert diff_cols <= {6}
+
+
+def test_news_lines_of_the_golden_dataset_parse():
+    g = _golden()
+    for split in ('train', 'dev', 'test'):
+        for line in g['lines'][split + '_news']:
+            rec = formats.parse_news_line(line, strip=split != 'train')
+            assert rec['news_ID'] in g['news_ID_dict'] and rec['category'] in g['category_dict']
