@@ -1,7 +1,8 @@
 """On-disk formats of the reference: the lifetime-augmented ``behaviors.tsv`` and ``news.tsv``
 lines, turned into the in-memory records ``device_data.DeviceBehaviors`` consumes -- the lists the reference's ``Corpus``
-builds at corpus.py:478-552 (train) and :556-650 (dev / test).  Host-side text parsing; no tokenisation (vocabulary building,
-GloVe lookup and the knowledge-graph files of corpus.py:27-296 stay with the reference's preprocessing).
+builds at corpus.py:478-552 (train) and :556-650 (dev / test) -- and the per-news arrays of corpus.py:360-367, :407-477 from the
+news lines and the vocabulary / category dictionaries the reference's preprocessing wrote.  Host-side text work; building the
+vocabulary, the GloVe table and the knowledge-graph files (corpus.py:27-296) stays with the reference's preprocessing.
 
 Parity: pinned by tests/golden/formats.json -- the records the IMPORTED reference's ``Corpus`` parsed out of a synthetic dataset
 directory (tools/make_format_goldens.py writes the tsv files in the reference's layout, runs corpus.py on them and stores its
@@ -14,6 +15,7 @@ by default and reproduces the reference when ``stale_news_index`` is given.
 """
 import ast
 import json
+import re
 
 import numpy as np
 
@@ -116,3 +118,53 @@ def devtest_records(lines, news_ID_dict, user_ID_dict, news_category, category_i
 def truth_labels(lines):
     """Per impression the 0 / 1 click labels in candidate order: what the truth file of config.py:262-276 holds."""
     return [[int(label) for _nid, label in parse_behavior_line(line)['impressions']] for line in lines]
+
+
+# ---- news.tsv -> the per-news arrays of corpus.py:360-367 (what DeviceCorpus keeps in HBM) ----------------------------------
+_MIND_TOKENS = re.compile(r"[\w]+|[.,!?;|]")            # the 'MIND' tokenizer (corpus.py:23); 'NLTK' needs nltk and is not offered
+
+
+def _is_number(s):
+    try:
+        float(s)
+        return True
+    except ValueError:
+        return False
+
+
+def _encode(text, length, word_dict, ids, mask):
+    for i, word in enumerate(_MIND_TOKENS.findall(text.lower())):
+        if i == length:
+            break
+        ids[i] = word_dict['<NUM>'] if _is_number(word) else word_dict.get(word, 1)      # 1 = <UNK> (corpus.py:421-426)
+        mask[i] = True
+
+
+def news_arrays(news_lines_by_split, news_ID_dict, category_dict, subCategory_dict, word_dict, max_title_length, max_abstract_length,
+                dataset='mind'):
+    """``Corpus.news_category / news_subCategory / news_title_text / news_title_mask / news_abstract_text / news_abstract_mask``
+    (corpus.py:360-367, :380-477) from the news.tsv lines of the train, dev and test splits (in that order; a news keeps its
+    FIRST line), the 'MIND' regex tokenizer and the dictionaries of the reference's preprocessing.  Row 0 is the <PAD> news
+    (its masks have position 0 set, :476-477).  The entity arrays (unused by LIME-{CROWN,MHSA}-CROWN) are not produced."""
+    n = len(news_ID_dict)
+    out = {'news_category': np.zeros(n, np.int32), 'news_subCategory': np.zeros(n, np.int32),
+           'news_title_text': np.zeros((n, max_title_length), np.int32), 'news_title_mask': np.zeros((n, max_title_length), bool),
+           'news_abstract_text': np.zeros((n, max_abstract_length), np.int32),
+           'news_abstract_mask': np.zeros((n, max_abstract_length), bool)}
+    seen = {'<PAD>'}
+    for split, lines in enumerate(news_lines_by_split):
+        for line in lines:
+            rec = parse_news_line(line, strip=(split > 0 and dataset == 'mind'))
+            if rec['news_ID'] in seen:
+                continue
+            seen.add(rec['news_ID'])
+            index = news_ID_dict[rec['news_ID']]
+            out['news_category'][index] = category_dict.get(rec['category'], 0)
+            out['news_subCategory'][index] = subCategory_dict.get(rec['subCategory'], 0)
+            _encode(rec['title'], max_title_length, word_dict, out['news_title_text'][index], out['news_title_mask'][index])
+            _encode(rec['abstract'], max_abstract_length, word_dict, out['news_abstract_text'][index], out['news_abstract_mask'][index])
+    if len(seen) != n:
+        raise ValueError('news_ID_dict has %d entries, the files hold %d news' % (n, len(seen)))
+    out['news_title_mask'][0][0] = True
+    out['news_abstract_mask'][0][0] = True
+    return out

@@ -146,3 +146,17 @@ def test_news_lines_of_the_golden_dataset_parse():
         for line in g['lines'][split + '_news']:
             rec = formats.parse_news_line(line, strip=split != 'train')
             assert rec['news_ID'] in g['news_ID_dict'] and rec['category'] in g['category_dict']
+
+
+def test_news_arrays_equal_the_reference_corpus():
+    """Token ids (vocabulary, <NUM>, <UNK>, truncation), masks and category ids as the reference's Corpus built them."""
+    g = _golden()
+    L = g['lines']
+    got = formats.news_arrays([L['train_news'], L['dev_news'], L['test_news']], g['news_ID_dict'], g['category_dict'],
+                              g['subCategory_dict'], g['word_dict'], g['max_title_length'], g['max_abstract_length'], dataset='adressa')
+    for k in ('news_category', 'news_subCategory', 'news_title_text', 'news_abstract_text'):
+        assert got[k].tolist() == g[k], k
+    for k in ('news_title_mask', 'news_abstract_mask'):
+        assert got[k].astype(int).tolist() == g[k], k
+    words = {w for row in g['news_title_text'] + g['news_abstract_text'] for w in row}
+    assert 1 in words and g['word_dict']['<NUM>'] in words and 0 in words          # <UNK>, <NUM> and padding all occur

@@ -23,7 +23,8 @@ sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import ref_harness  # noqa: E402
 
 TOPICS = ['sports', 'news', 'finance', 'travel']
-WORDS = ['alpha', 'beta', 'gamma', 'delta', 'epsilon', 'zeta', 'eta', 'theta', 'iota', 'kappa']
+WORDS = ['alpha', 'beta', 'gamma', 'delta', 'epsilon', 'zeta', 'eta', 'theta', 'iota', 'kappa', '42', '3.5', 'Rare1', 'rare2', ',', '!',
+         'MiXed', 'x_y']
 
 
 def news_lines(ids, rng):
@@ -91,7 +92,7 @@ def main():
         open(os.path.join(roots[split], 'news.tsv'), 'w', encoding='utf-8').writelines(files[split + '_news'])
         open(os.path.join(roots[split], 'behaviors.tsv'), 'w', encoding='utf-8').writelines(files[split + '_behaviors'])
     cfg = types.SimpleNamespace(
-        dataset='adressa', tokenizer='MIND', word_threshold=1, word_embedding_dim=50, max_title_length=6, max_abstract_length=10,
+        dataset='adressa', tokenizer='MIND', word_threshold=12, word_embedding_dim=50, max_title_length=6, max_abstract_length=10,
         max_history_num=4, negative_sample_num=2, user_encoder='CROWN', no_self_connection=False, no_adjacent_normalization=False,
         gcn_normalization_type='symmetric', train_root=roots['train'], dev_root=roots['dev'], test_root=roots['test'],
         entity_embedding_dim=100, context_embedding_dim=100)
@@ -109,7 +110,11 @@ def main():
         'max_history_num': cfg.max_history_num,
         'lines': files,
         'news_ID_dict': c.news_ID_dict, 'user_ID_dict': c.user_ID_dict, 'category_dict': c.category_dict,
-        'news_category': c.news_category.tolist(),
+        'news_category': c.news_category.tolist(), 'news_subCategory': c.news_subCategory.tolist(),
+        'subCategory_dict': c.subCategory_dict, 'word_dict': c.word_dict,
+        'max_title_length': cfg.max_title_length, 'max_abstract_length': cfg.max_abstract_length,
+        'news_title_text': c.news_title_text.tolist(), 'news_title_mask': c.news_title_mask.astype(int).tolist(),
+        'news_abstract_text': c.news_abstract_text.tolist(), 'news_abstract_mask': c.news_abstract_mask.astype(int).tolist(),
         'category_index_to_name': {str(k): v for k, v in c.category_index_to_name.items()},
         'train_behaviors': [rec(r) for r in c.train_behaviors],
         'dev_behaviors': [rec(r) for r in c.dev_behaviors], 'dev_indices': list(c.dev_indices),
