@@ -168,3 +168,30 @@ def news_arrays(news_lines_by_split, news_ID_dict, category_dict, subCategory_di
     out['news_title_mask'][0][0] = True
     out['news_abstract_mask'][0][0] = True
     return out
+
+
+def build_corpus(config, news_lines_by_split, behavior_lines_by_split, news_ID_dict, user_ID_dict, category_dict, subCategory_dict,
+                 word_dict, dataset='mind', reference_stale_lookup=False):
+    """The ``Corpus`` attributes ``DeviceCorpus`` / ``DeviceBehaviors`` (and the reference's datasets) read, from the raw tsv
+    lines of the (train, dev, test) splits and the dictionaries of the reference's preprocessing (its ``*-<dataset>.json`` files).
+    ``reference_stale_lookup``: reproduce the dev / test topic lookup of corpus.py:582,:630 (module docstring)."""
+    from types import SimpleNamespace
+    c = SimpleNamespace(config=config, max_history_num=config.max_history_num, max_title_length=config.max_title_length,
+                        max_abstract_length=config.max_abstract_length, negative_sample_num=config.negative_sample_num,
+                        news_ID_dict=news_ID_dict, user_ID_dict=user_ID_dict, category_dict=category_dict,
+                        subCategory_dict=subCategory_dict, word_dict=word_dict)
+    for k, v in news_arrays(news_lines_by_split, news_ID_dict, category_dict, subCategory_dict, word_dict, config.max_title_length,
+                            config.max_abstract_length, dataset).items():
+        setattr(c, k, v)
+    c.news_title_entity = np.zeros_like(c.news_title_text)                  # unused by LIME-{CROWN,MHSA}-CROWN
+    c.news_abstract_entity = np.zeros_like(c.news_abstract_text)
+    c.category_index_to_name = {v: k for k, v in category_dict.items()}
+    args = (news_ID_dict, user_ID_dict, c.news_category, c.category_index_to_name, config.max_history_num)
+    c.train_behaviors, left_over = train_records(behavior_lines_by_split[0], *args)
+    stale = left_over if reference_stale_lookup else None
+    c.dev_behaviors, c.dev_indices = devtest_records(behavior_lines_by_split[1], *args, stale_news_index=stale)
+    c.test_behaviors, c.test_indices = devtest_records(behavior_lines_by_split[2], *args, stale_news_index=stale)
+    for split in ('train', 'dev', 'test'):                                  # SUE-only tables (dataset.py:21-28)
+        for name in ('user_history_graph', 'user_history_category_mask', 'user_history_category_indices'):
+            setattr(c, '%s_%s' % (split, name), None)
+    return c

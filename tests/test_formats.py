@@ -160,3 +160,22 @@ def test_news_arrays_equal_the_reference_corpus():
         assert got[k].astype(int).tolist() == g[k], k
     words = {w for row in g['news_title_text'] + g['news_abstract_text'] for w in row}
     assert 1 in words and g['word_dict']['<NUM>'] in words and 0 in words          # <UNK>, <NUM> and padding all occur
+
+
+def test_build_corpus_from_the_golden_files_feeds_the_batch_assembly():
+    """Raw lines + the preprocessing's dictionaries -> a corpus object whose dev batch (through the oracle's assembly, pinned by
+    the dataset goldens) carries the token rows and lifetimes of the reference's Corpus."""
+    g = _golden()
+    L = g['lines']
+    cfg = make_config(max_history_num=g['max_history_num'], max_title_length=g['max_title_length'],
+                      max_abstract_length=g['max_abstract_length'], vocabulary_size=len(g['word_dict']), negative_sample_num=2,
+                      category_num=len(g['category_dict']) + 1)
+    c = formats.build_corpus(cfg, [L['train_news'], L['dev_news'], L['test_news']],
+                             [L['train_behaviors'], L['dev_behaviors'], L['test_behaviors']], g['news_ID_dict'], g['user_ID_dict'],
+                             g['category_dict'], g['subCategory_dict'], g['word_dict'], dataset='adressa', reference_stale_lookup=True)
+    assert _norm(c.dev_behaviors) == g['dev_behaviors'] and c.test_indices == g['test_indices']
+    rows = list(range(len(c.dev_behaviors)))
+    batch = O.assemble_devtest(c, 'dev', rows)
+    cand = [r[3] for r in g['dev_behaviors']]
+    assert np.asarray(batch[17]).tolist() == [g['news_title_text'][i] for i in cand]          # news_title_text of the candidates
+    assert np.allclose(np.asarray(batch[24]), [r[6] for r in g['dev_behaviors']])              # news_user_topic_lifetime
