@@ -23,6 +23,39 @@ def _pad_history_list(values, H):
     return values[-H:] + [0] * max(0, H - len(values))
 
 
+def negative_sampling(train_behaviors, negative_sample_num, randint=None):
+    """Train_Dataset.negative_sampling (dataset.py:42-77) on the host: per train record [positive, negatives ...] news indices,
+    the candidate freshness repeated, and [positive lifetime, negative lifetimes ...].  A record with at most
+    ``negative_sample_num`` non-clicked news cycles through them; otherwise distinct ones are drawn with ``randint(0, n - 1)``.
+    The reference imports ``randint`` from numpy.random (dataset.py:6), whose upper bound is EXCLUSIVE: the last non-clicked
+    news of such an impression is never drawn.  That is the default here too (same ``np.random.seed`` -> same samples, pinned
+    by tests/golden/dataset_train.npz); pass ``randint=lambda lo, hi: random.randint(lo, hi)`` for the inclusive draw."""
+    if randint is None:
+        from numpy.random import randint
+    samples, freshness, lifetime = [], [], []
+    for rec in train_behaviors:
+        neg_indices, fresh, neg_lifetimes = rec[4], rec[6], rec[8]
+        s, f, l = [rec[3]], [fresh], [rec[7]]
+        n = len(neg_indices)
+        used = set()
+        for j in range(negative_sample_num):
+            if n <= negative_sample_num:
+                k = j % n
+            else:
+                while True:
+                    k = randint(0, n - 1)
+                    if k not in used:
+                        used.add(k)
+                        break
+            s.append(neg_indices[k])
+            f.append(fresh)
+            l.append(neg_lifetimes[k])
+        samples.append(s)
+        freshness.append(f)
+        lifetime.append(l)
+    return samples, freshness, lifetime
+
+
 class DeviceCorpus:
     """The eight per-news arrays of the reference's Corpus (corpus.py:360-367) on the device."""
 

@@ -37,3 +37,18 @@ def test_devtest_assembly_matches_reference_dataset(mode, rows):
     assert len(out) == 25
     for k, arr in enumerate(out):
         _same(arr, g['out%02d' % k], '%s output %d' % (mode, k))
+
+
+def test_negative_sampling_reproduces_the_reference_draws():
+    """device_data.negative_sampling under the seed the goldens were drawn with (tools/make_dataset_goldens.py) gives the
+    reference's sampled candidate tables, including numpy's exclusive upper bound in randint (dataset.py:6,64)."""
+    from lime_cikm25_amd.device_data import negative_sampling
+    cfg, corpus = dataset_cases.build()
+    g = np.load(os.path.join(GOLD, 'dataset_train.npz'))
+    np.random.seed(dataset_cases.SAMPLING_SEED)
+    samples, fresh, life = negative_sampling(corpus.train_behaviors, cfg.negative_sample_num)
+    assert np.array_equal(np.asarray(samples, dtype=np.int64), g['train_samples'])
+    assert np.array_equal(np.asarray(fresh, dtype=np.float64), g['train_freshness'])
+    assert np.array_equal(np.asarray(life, dtype=np.float64), g['train_user_topic_lifetime'])
+    many = [r for r in corpus.train_behaviors if len(r[4]) > cfg.negative_sample_num]
+    assert many, 'the fixture must exercise the random branch'

@@ -46,7 +46,7 @@ def behavior_lines(n, users, pool, rng, start_id):
         life = [float(x) for x in np.round(rng.uniform(600, 1e6, size=k), 3)]
         cands = list(rng.choice(pool, size=rng.integers(2, 6), replace=False))
         labels = ['0'] * len(cands)
-        for j in rng.choice(len(cands), size=rng.integers(1, 3), replace=False):
+        for j in rng.choice(len(cands), size=min(len(cands) - 1, rng.integers(1, 3)), replace=False):      # both classes present
             labels[j] = '1'
         seen = {t: float(np.round(rng.uniform(1e3, 1e5), 2)) for t in rng.choice(TOPICS, size=rng.integers(0, 3), replace=False)}
         unseen = {t: float(np.round(rng.uniform(1e3, 1e5), 2)) for t in rng.choice(TOPICS, size=rng.integers(0, 3), replace=False)}
