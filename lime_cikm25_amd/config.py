@@ -52,6 +52,18 @@ _DEFAULTS = dict(
     subCategory_embedding_dim=50,         # config.py:92
     user_embedding_dim=50,                # config.py:90
     click_predictor='dot_product',        # config.py:109
+    # training loop (trainer.py:17-69)
+    seed=0,                               # config.py:33
+    epoch=16,                             # config.py:44
+    lr=1e-4,                              # config.py:46
+    weight_decay=0.0,                     # config.py:47
+    gradient_clip_norm=4.0,               # config.py:48
+    dev_criterion='auc',                  # config.py:51
+    early_stopping_epoch=5,               # config.py:52
+    model_dir='models',                   # config.py:249-253 derive these four from the dataset and model name
+    best_model_dir='best_model',
+    dev_res_dir='dev/res',
+    result_dir='results',
     # normally filled in by corpus.py:309-326
     vocabulary_size=50000,
     category_num=18,

@@ -55,3 +55,40 @@ def test_files_to_metrics(tmp_path):
         assert 0.0 <= m <= 1.0
     ranks = [json.loads(line.split(' ', 1)[1]) for line in open(tmp_path / 'rank.txt')]
     assert [sorted(r) for r in ranks] == [list(range(1, len(lab) + 1)) for lab in formats.truth_labels(L['dev_behaviors'])]
+
+
+def test_trainer_loop_selects_and_saves_the_best_epoch(tmp_path):
+    """trainer.Trainer (the reference's Trainer.train, trainer.py:84-244) for three epochs on the toy dataset: dev metrics per
+    epoch, the improving epochs checkpointed in the reference's file layout, the best one copied to best_model_dir."""
+    from lime_cikm25_amd.trainer import Trainer
+    from lime_cikm25_amd.training import load_checkpoint
+    g = json.load(open(os.path.join(GOLDEN_DIR, 'formats.json')))
+    L = g['lines']
+    d = str(tmp_path)
+    cfg = make_config(max_history_num=g['max_history_num'], max_title_length=g['max_title_length'],
+                      max_abstract_length=g['max_abstract_length'], vocabulary_size=len(g['word_dict']), negative_sample_num=2,
+                      category_num=len(g['category_dict']) + 1, subCategory_num=len(g['subCategory_dict']) + 1,
+                      user_num=len(g['user_ID_dict']), batch_size=4, epoch=3, lr=1e-3, dataset='adressa',
+                      model_dir=d + '/models', best_model_dir=d + '/best', dev_res_dir=d + '/dev', result_dir=d + '/results')
+    corpus = formats.build_corpus(cfg, [L['train_news'], L['dev_news'], L['test_news']],
+                                  [L['train_behaviors'], L['dev_behaviors'], L['test_behaviors']], g['news_ID_dict'],
+                                  g['user_ID_dict'], g['category_dict'], g['subCategory_dict'], g['word_dict'], dataset='adressa')
+    truth = tmp_path / 'truth.txt'
+    with open(truth, 'w') as f:
+        for i, labels in enumerate(formats.truth_labels(L['dev_behaviors'])):
+            f.write('%d %s\n' % (i + 1, json.dumps(labels).replace(' ', '')))
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = Model(cfg)
+    model.initialize()
+    torch.nn.init.normal_(model.news_encoder.base_news_encoder.word_embedding.weight, std=0.1)
+    trainer = Trainer(model.cuda(), cfg, corpus, run_index=1, truth_file=str(truth))
+    best = trainer.train()
+    assert 1 <= best <= 3 and len(trainer.results['auc']) == 3 and all(0.0 <= v <= 1.0 for v in trainer.results['auc'])
+    best_file = os.path.join(d, 'best', '#1', model.model_name)
+    assert os.path.exists(best_file) and os.path.exists(os.path.join(d, 'results', '#1-dev'))
+    log = open(os.path.join(d, 'dev', '#1', '%s-adressa-dev_log.txt' % model.model_name)).read().splitlines()
+    assert log[0] == 'Epoch\tAUC\tMRR\tnDCG@5\tnDCG@10' and len(log) == 4
+    fresh = Model(cfg).cuda()
+    payload = load_checkpoint(best_file, fresh)                      # the reference's main.py:45 reads the same key
+    assert model.model_name in payload
