@@ -66,6 +66,14 @@ def allreduce_mean_(flat, group=None):
     return flat.mul_(1.0 / world)
 
 
+def broadcast_(flat, src=0, group=None):
+    """Every rank takes rank ``src``'s values (what DistributedDataParallel does with the parameters at construction, so
+    that replicas start identical whatever their local initialisation was); a no-op for one process."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat, src=src, group=group)
+    return flat
+
+
 def sampler_rows(n_rows, rank, world, epoch_perm=None):
     """Row indices of rank `rank` for one training epoch: rows rank, rank + world, ... of the (optionally permuted) order,
     padded by wrapping around so every rank takes the same number of steps -- torch's DistributedSampler rule

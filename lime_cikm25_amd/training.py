@@ -583,6 +583,7 @@ class TrainStep:
                 p.data = self.flat[off:off + n].view(p.shape)
                 p.grad = self.grad[off:off + n].view(p.shape)
                 off += align(n)
+        distributed.broadcast_(self.flat, 0, process_group)      # replicas start from rank 0's parameters (as under DDP)
         if hasattr(model, '_graphs'):
             model._graphs = {}                  # captured scoring graphs hold the parameters' old addresses
         self.step_count = 0

@@ -82,8 +82,9 @@ def _worker(rank, world, port, out_dir):
     _, names, sd, loss = oracle_grads('spill', rows=rows)
     local = _flat(names, sd)
     reduced = D.allreduce_mean_(local.clone())
+    start = D.broadcast_(torch.full((5,), float(rank + 1)))              # replicas start from rank 0's values
     dist.barrier()
-    torch.save({'local': local, 'reduced': reduced, 'rows': rows, 'loss': loss}, os.path.join(out_dir, 'g%d.pt' % rank))
+    torch.save({'local': local, 'reduced': reduced, 'rows': rows, 'loss': loss, 'start': start}, os.path.join(out_dir, 'g%d.pt' % rank))
     dist.destroy_process_group()
 
 
@@ -97,3 +98,4 @@ def test_two_gloo_ranks_average_their_gradient_buckets(tmp_path):
     want = (r0['local'].double() + r1['local'].double()) / 2
     assert rel_err(r0['reduced'].numpy(), want.numpy()) < 1e-6
     assert not torch.equal(r0['local'], r1['local'])
+    assert torch.equal(r0['start'], torch.ones(5)) and torch.equal(r1['start'], torch.ones(5))
