@@ -757,16 +757,19 @@ __global__ __launch_bounds__(512) void token_attn_bwd_kernel(const float* __rest
 
 // ---------------------------------------------------------------------------------------------------
 // Training-mode forward of the encoder attention WITH probability dropout: out = (keep * softmax(scale Q K^T) / (1 - p)) V.
-// Same layout as token_attn_bwd_kernel (eight waves, 16 query rows each, S <= 128); the scoring kernel in token_attn_f32.hip
-// stays free of the mask arithmetic.
+// Eight waves, 16 query rows each, S <= 128; the scoring kernel in token_attn_f32.hip stays free of the mask arithmetic.
+// The scores are computed TRANSPOSED (S^T = K Q^T): the MFMA result layout then holds, per lane, P^T[j = 4 kg + r][i = lane's
+// query] -- exactly the B operand of the second product O^T = V^T P^T -- so the probabilities never leave the registers (no
+// P image in LDS, 55 KB per workgroup, two workgroups per CU); the softmax of a query is a reduction over the lane's own
+// registers and its three kg partners; and the four r of an accumulator are four consecutive keys: one mask hash each.
 // ---------------------------------------------------------------------------------------------------
 template <int SP>
-__global__ __launch_bounds__(512) void token_attn_fwd_dropout_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                                      const float* __restrict__ v, long ld, float* __restrict__ out,
-                                                                      long ldo, int n_seq, int S, int n_head, int head_dim,
-                                                                      int head_stride, float scale, LimeDropout drop, int vec) {
-    constexpr int NT = SP / 16, WPP = SP / 16, PPW = 8 / WPP, TPP = 64 * WPP, LDP = SP + 2;
-    constexpr int PROB_FLOATS = 3 * SP * AB_LD + SP * LDP;
+__global__ __launch_bounds__(512, 2) void token_attn_fwd_dropout_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                         const float* __restrict__ v, long ld, float* __restrict__ out,
+                                                                         long ldo, int n_seq, int S, int n_head, int head_dim,
+                                                                         int head_stride, float scale, LimeDropout drop, int vec) {
+    constexpr int NT = SP / 16, WPP = SP / 16, PPW = 8 / WPP, TPP = 64 * WPP;
+    constexpr int PROB_FLOATS = 3 * SP * AB_LD;
     extern __shared__ float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, kg = lane >> 4;
     const int pw = wave / WPP, wr = wave % WPP, lt = tid - pw * TPP;
@@ -777,7 +780,6 @@ __global__ __launch_bounds__(512) void token_attn_fwd_dropout_kernel(const float
     float* Qs = smem + pw * PROB_FLOATS;
     float* Ks = Qs + SP * AB_LD;
     float* Vs = Ks + SP * AB_LD;
-    float* Ps = Vs + SP * AB_LD;
     const int R0 = 16 * wr;
     const long row_base = (long)seq * S;
     if (vec) {                  // 32-float head rows on 16-byte boundaries, zero padding columns
@@ -801,65 +803,79 @@ __global__ __launch_bounds__(512) void token_attn_fwd_dropout_kernel(const float
         }
     }
     __syncthreads();
+    // S^T tiles: rows = keys 16 ct + 4 kg + r, column = this lane's query R0 + fi
     f32x4 p[NT];
     {
-        f32x4v qa[2];
+        f32x4v qf[2];                           // B operand: Q[i = R0 + fi][d = 8 kg .. 8 kg + 7] (k-permuted, two b128)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) qa[h] = *reinterpret_cast<const f32x4v*>(&Qs[(R0 + fi) * AB_LD + 8 * kg + 4 * h]);
+        for (int h = 0; h < 2; ++h) qf[h] = *reinterpret_cast<const f32x4v*>(&Qs[(R0 + fi) * AB_LD + 8 * kg + 4 * h]);
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            f32x4v kf[2];
+            f32x4v kf[2];                       // A operand: K[j = 16 ct + fi][d = 8 kg ..]
 #pragma unroll
             for (int h = 0; h < 2; ++h) kf[h] = *reinterpret_cast<const f32x4v*>(&Ks[(16 * ct + fi) * AB_LD + 8 * kg + 4 * h]);
 #pragma unroll
-            for (int t = 0; t < 8; ++t) a = mfma16(qa[t >> 2][t & 3], kf[t >> 2][t & 3], a);
+            for (int t = 0; t < 8; ++t) a = mfma16(kf[t >> 2][t & 3], qf[t >> 2][t & 3], a);
             p[ct] = a;
         }
     }
+    // softmax over the keys of this lane's query: the lane's registers, then the kg partners (lanes +-16, +-32)
+    float mx = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float mx = -INFINITY;
+    for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
-        for (int ct = 0; ct < NT; ++ct) {
-            const float sv = (16 * ct + fi < S) ? p[ct][r] * (scale * LOG2E) : -INFINITY;
+        for (int r = 0; r < 4; ++r) {
+            const float sv = (16 * ct + 4 * kg + r < S) ? p[ct][r] * (scale * LOG2E) : -INFINITY;
             p[ct][r] = sv;
             mx = fmaxf(mx, sv);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
-        mx = fmaxf(mx, __shfl_xor(mx, 4)); mx = fmaxf(mx, __shfl_xor(mx, 8));
-        float sum = 0.f;
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
 #pragma unroll
-        for (int ct = 0; ct < NT; ++ct) {
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
             const float e = __builtin_amdgcn_exp2f(p[ct][r] - mx);
             p[ct][r] = e;
             sum += e;
         }
-        sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4); sum += __shfl_xor(sum, 8);
-        const float inv = 1.0f / sum;
-        const uint64_t mrow = ((uint64_t)prob * S + (uint64_t)(R0 + 4 * kg + r)) * (uint64_t)S;
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = drop.scale / sum;
+    // mask element ((prob S + i) S + j): the four r of an accumulator are keys 16 ct + 4 kg .. + 3 -- one hash
+    const uint64_t mrow = ((uint64_t)prob * S + (uint64_t)(R0 + fi)) * (uint64_t)S;
 #pragma unroll
-        for (int ct = 0; ct < NT; ++ct) {
-            const float f = (drop.thresh == 0 || lime_keep(drop, mrow + (uint64_t)(16 * ct + fi))) ? drop.scale * inv : 0.f;
-            Ps[(R0 + 4 * kg + r) * LDP + 16 * ct + fi] = p[ct][r] * f;
+    for (int ct = 0; ct < NT; ++ct) {
+        unsigned m = 0xFu;
+        if (drop.thresh != 0) {
+            const uint64_t idx = mrow + (uint64_t)(16 * ct + 4 * kg);
+            if ((idx & 3) == 0) m = lime_keep4(drop, idx >> 2);
+            else
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = (m & ~(1u << r)) | ((lime_keep(drop, idx + r) ? 1u : 0u) << r);
         }
-    }
-    __syncthreads();
-    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
-#pragma unroll 8
-    for (int t = 0; t < SP / 4; ++t) {          // O[i, d] = sum_j P[i, j] V[j, d] for the wave's own rows
-        const int j = 4 * t + kg;
-        const float a = Ps[(R0 + fi) * LDP + j];
-        o0 = mfma16(a, Vs[j * AB_LD + fi], o0);
-        o1 = mfma16(a, Vs[j * AB_LD + 16 + fi], o1);
-    }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = R0 + 4 * kg + r;
-        if (live && row < S) {
-            float* o = out + (row_base + row) * ldo + (long)head * head_dim;
-            if (fi < head_dim) o[fi] = o0[r];
-            if (16 + fi < head_dim) o[16 + fi] = o1[r];
+        for (int r = 0; r < 4; ++r) p[ct][r] = (m >> r) & 1u ? p[ct][r] * inv : 0.f;
+    }
+    // O^T[d][i] = sum_j V^T[d][j] P^T[j][i]: A = V[j = 16 ct + 4 kg + t][d = 16 dt + fi] from LDS, B = p[ct][t] from registers
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = 16 * ct + 4 * kg + t;
+            o0 = mfma16(Vs[j * AB_LD + fi], p[ct][t], o0);
+            o1 = mfma16(Vs[j * AB_LD + 16 + fi], p[ct][t], o1);
+        }
+    // the lane holds O[i = R0 + fi][d = 4 kg + r] (o0) and [16 + 4 kg + r] (o1)
+    if (live && R0 + fi < S) {
+        float* o = out + (row_base + R0 + fi) * ldo + (long)head * head_dim;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (4 * kg + r < head_dim) o[4 * kg + r] = o0[r];
+            if (16 + 4 * kg + r < head_dim) o[16 + 4 * kg + r] = o1[r];
         }
     }
 }
@@ -1525,7 +1541,7 @@ template <int SP>
 int launch_attn_fwd_dropout(const float* q, const float* k, const float* v, long ld, float* out, long ldo, int n_seq, int S,
                             int n_head, int head_dim, int head_stride, float scale, const LimeDropout& drop, hipStream_t s) {
     constexpr int PPW = 8 / (SP / 16);
-    constexpr int BYTES = PPW * (3 * SP * AB_LD + SP * (SP + 2)) * 4;
+    constexpr int BYTES = PPW * (3 * SP * AB_LD) * 4;
     static bool configured = false;
     if (!configured) {
         const hipError_t e = hipFuncSetAttribute((const void*)token_attn_fwd_dropout_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
