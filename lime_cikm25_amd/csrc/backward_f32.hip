@@ -760,7 +760,7 @@ __global__ __launch_bounds__(512) void token_attn_bwd_kernel(const float* __rest
 // Eight waves, 16 query rows each, S <= 128; the scoring kernel in token_attn_f32.hip stays free of the mask arithmetic.
 // The scores are computed TRANSPOSED (S^T = K Q^T): the MFMA result layout then holds, per lane, P^T[j = 4 kg + r][i = lane's
 // query] -- exactly the B operand of the second product O^T = V^T P^T -- so the probabilities never leave the registers (no
-// P image in LDS, 55 KB per workgroup, two workgroups per CU); the softmax of a query is a reduction over the lane's own
+// P image in LDS; K and V images only, 37 KB per workgroup); the softmax of a query is a reduction over the lane's own
 // registers and its three kg partners; and the four r of an accumulator are four consecutive keys: one mask hash each.
 // ---------------------------------------------------------------------------------------------------
 template <int SP>
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(512, 2) void token_attn_fwd_dropout_kernel(const fl
                                                                          long ldo, int n_seq, int S, int n_head, int head_dim,
                                                                          int head_stride, float scale, LimeDropout drop, int vec) {
     constexpr int NT = SP / 16, WPP = SP / 16, PPW = 8 / WPP, TPP = 64 * WPP;
-    constexpr int PROB_FLOATS = 3 * SP * AB_LD;
+    constexpr int PROB_FLOATS = 2 * SP * AB_LD;            // K and V images; a lane's Q operand comes straight from global
     extern __shared__ float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, kg = lane >> 4;
     const int pw = wave / WPP, wr = wave % WPP, lt = tid - pw * TPP;
@@ -777,18 +777,30 @@ __global__ __launch_bounds__(512, 2) void token_attn_fwd_dropout_kernel(const fl
     const long prob = (long)blockIdx.x * PPW + pw;
     const bool live = prob < n_prob;
     const int seq = live ? (int)(prob / n_head) : 0, head = live ? (int)(prob % n_head) : 0;
-    float* Qs = smem + pw * PROB_FLOATS;
-    float* Ks = Qs + SP * AB_LD;
+    float* Ks = smem + pw * PROB_FLOATS;
     float* Vs = Ks + SP * AB_LD;
     const int R0 = 16 * wr;
     const long row_base = (long)seq * S;
+    // B operand of S^T = K Q^T: Q[i = R0 + fi][d = 8 kg .. 8 kg + 7] (k-permuted: 32 consecutive bytes of the lane's row)
+    f32x4v qf[2];
+    {
+        const bool ok = live && R0 + fi < S;
+        const float* qrow = q + (row_base + (ok ? R0 + fi : 0)) * ld + (long)head * head_stride + 8 * kg;
+        if (vec) {
+            const f32x4v z = {0.f, 0.f, 0.f, 0.f};
+            qf[0] = ok ? *reinterpret_cast<const f32x4v*>(qrow) : z;
+            qf[1] = ok ? *reinterpret_cast<const f32x4v*>(qrow + 4) : z;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) qf[t >> 2][t & 3] = (ok && 8 * kg + t < head_dim) ? qrow[t] : 0.f;
+        }
+    }
     if (vec) {                  // 32-float head rows on 16-byte boundaries, zero padding columns
         for (int e = lt; e < SP * 8; e += TPP) {
             const int r = e >> 3, c = (e & 7) * 4;
             const bool ok = live && r < S;
             const long g = (row_base + (ok ? r : 0)) * ld + (long)head * head_stride + c;
             const f32x4v z = {0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4v*>(&Qs[r * AB_LD + c]) = ok ? *reinterpret_cast<const f32x4v*>(q + g) : z;
             *reinterpret_cast<f32x4v*>(&Ks[r * AB_LD + c]) = ok ? *reinterpret_cast<const f32x4v*>(k + g) : z;
             *reinterpret_cast<f32x4v*>(&Vs[r * AB_LD + c]) = ok ? *reinterpret_cast<const f32x4v*>(v + g) : z;
         }
@@ -797,7 +809,6 @@ __global__ __launch_bounds__(512, 2) void token_attn_fwd_dropout_kernel(const fl
             const int r = e >> 5, c = e & 31;
             const bool ok = live && r < S && c < head_dim;
             const long g = (row_base + r) * ld + (long)head * head_stride + c;
-            Qs[r * AB_LD + c] = ok ? q[g] : 0.f;
             Ks[r * AB_LD + c] = ok ? k[g] : 0.f;
             Vs[r * AB_LD + c] = ok ? v[g] : 0.f;
         }
@@ -806,9 +817,6 @@ __global__ __launch_bounds__(512, 2) void token_attn_fwd_dropout_kernel(const fl
     // S^T tiles: rows = keys 16 ct + 4 kg + r, column = this lane's query R0 + fi
     f32x4 p[NT];
     {
-        f32x4v qf[2];                           // B operand: Q[i = R0 + fi][d = 8 kg .. 8 kg + 7] (k-permuted, two b128)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) qf[h] = *reinterpret_cast<const f32x4v*>(&Qs[(R0 + fi) * AB_LD + 8 * kg + 4 * h]);
 #pragma unroll
         for (int ct = 0; ct < NT; ++ct) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
@@ -1541,7 +1549,7 @@ template <int SP>
 int launch_attn_fwd_dropout(const float* q, const float* k, const float* v, long ld, float* out, long ldo, int n_seq, int S,
                             int n_head, int head_dim, int head_stride, float scale, const LimeDropout& drop, hipStream_t s) {
     constexpr int PPW = 8 / (SP / 16);
-    constexpr int BYTES = PPW * (3 * SP * AB_LD) * 4;
+    constexpr int BYTES = PPW * (2 * SP * AB_LD) * 4;
     static bool configured = false;
     if (!configured) {
         const hipError_t e = hipFuncSetAttribute((const void*)token_attn_fwd_dropout_kernel<SP>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
