@@ -3,6 +3,7 @@
 the native clip + Adam step against torch.optim.Adam / clip_grad_norm_ driven by the same gradients.  Tolerance 1e-3
 relative (north star); observed errors are printed."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -191,3 +192,41 @@ def test_scoring_graph_captured_before_training_is_not_reused():
         eager = model(*batch).clone()
     assert rel_err(after.cpu().numpy(), eager.cpu().numpy()) < 1e-5
     assert not torch.equal(after, before), 'two Adam steps at lr 1e-3 must change the scores'
+
+
+def test_full_size_step_against_the_oracle_autograd():
+    """BASELINE config 2b at full size (batch 32, history 50, title 32 + body 128, K = 1+4; 281,600 tokens): loss and gradients of
+    the HIP training forward + backward against the CPU oracle's autograd (one forward + backward of the same batch)."""
+    from lime_cikm25_amd import make_config
+    from oracle import lime_oracle as O
+    cfg = make_config()
+    model = Model(cfg)
+    model.initialize()
+    synth.fill_state_dict(model, seed=1)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    batch = synth.make_batch(cfg, 32, 5, seed=100)
+    probes = ['news_encoder.base_news_encoder.body_transformer.layers.0.self_attn.in_proj_weight',
+              'news_encoder.base_news_encoder.title_transformer.layers.0.linear2.weight',
+              'news_encoder.base_news_encoder.body_transformer.layers.0.norm1.weight',
+              'news_encoder.base_news_encoder.intent_layers.1.weight', 'news_encoder.project.weight',
+              'user_encoder.graph_sage.convs.0.lin_r.weight', 'user_encoder.candidate_aware_attn.gate_proj.weight']
+    for k in probes:
+        sd[k].requires_grad_(True)
+    for k in list(sd):
+        if k.startswith('user_encoder.news_encoder.'):
+            sd[k] = sd[k[len('user_encoder.'):]]
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref = (-torch.log_softmax(O.model_forward(sd, cfg, batch, grad=True), dim=1).select(dim=1, index=0)).mean()
+    ref.backward()
+    model = model.cuda()
+    model.eval()
+    model.training = True
+    loss = negative_log_softmax(model(*[v.cuda() for v in batch.values()]))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) < TOL * max(1.0, abs(float(ref.detach())))
+    named = dict(model.named_parameters())
+    for k in probes:
+        want, got = sd[k].grad, named[k].grad.cpu()
+        floor = max(float(want.norm()) / want.numel() ** 0.5, 1e-5)
+        e = rel_err(got.numpy(), want.numpy(), floor=floor)
+        assert e < TOL, '%s: %.3e' % (k, e)
