@@ -501,6 +501,9 @@ def forward_train(model, user_category, user_subCategory, user_title_text, user_
     if news_user_topic_lifetime.dim() == 1:
         news_user_topic_lifetime = news_user_topic_lifetime.unsqueeze(1).expand(B, N)
     category, subCategory = i32(flat1(news_category, user_category)), i32(flat1(news_subCategory, user_subCategory))
+    if getattr(enc, 'compute_dtype', 'fp32') != 'fp32':
+        raise NotImplementedError("compute_dtype %r is a scoring option (BASELINE config 3); the training step is fp32: build the "
+                                  "model with compute_dtype='fp32' to train" % enc.compute_dtype)
     if isinstance(enc, CROWN):
         title_p, body_p = pooled_tokens(ne, i32(flat2(news_title_text, user_title_text)), i32(flat2(news_content_text, user_content_text)))
         content = crown_tail(enc, title_p, body_p, category, subCategory)

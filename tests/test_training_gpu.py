@@ -230,3 +230,14 @@ def test_full_size_step_against_the_oracle_autograd():
         floor = max(float(want.norm()) / want.numel() ** 0.5, 1e-5)
         e = rel_err(got.numpy(), want.numpy(), floor=floor)
         assert e < TOL, '%s: %.3e' % (k, e)
+
+
+def test_bf16_scoring_models_do_not_train_silently_in_fp32():
+    cfg, batch, c = golden_cases.build_case('cfg1_crown')
+    cfg.compute_dtype = 'bf16'
+    model = Model(cfg)
+    model.initialize()
+    model = model.cuda()
+    model.training = True
+    with pytest.raises(NotImplementedError, match='compute_dtype'):
+        model(*[v.cuda() for v in batch.values()])
