@@ -345,7 +345,7 @@ int lime_layernorm_bwd_f32(const float* dy, int64_t lddy, int32_t dy_div, float 
  * ReLU + the dropout that follows it when h is the dropped-out activation (scale = 1 / (1 - p)) */
 int lime_relu_bwd_f32(float* dh, int64_t lddh, const float* h, int64_t ldh, int64_t rows, int32_t cols, float scale, void* stream);
 
-/* Backward of lime_token_attention_f32 without a key mask (the encoder layers): given q / k / v as the forward read them
+/* Backward of lime_token_attention_f32 (the encoder layers; optionally the key mask of MHSA): given q / k / v as the forward read them
  * and dout [tokens, n_head * head_dim] (packed), writes dq / dk / dv in the layout of q / k / v (row stride ld_dqkv, head
  * h at column h * head_stride; columns head_dim .. head_stride - 1 come out as zeros).  The probabilities are recomputed.
  * S <= 512, head_dim <= head_stride <= 32.  S <= 128: one pass per (sequence, head); `out` and `workspace` may be NULL.
