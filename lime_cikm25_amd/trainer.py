@@ -26,9 +26,10 @@ def _mkdir(path):
 
 
 class Trainer:
-    def __init__(self, model, config, corpus, run_index=0, truth_file=None, device_corpus=None):
+    def __init__(self, model, config, corpus, run_index=0, truth_file=None, device_corpus=None, cached_eval=True):
         """``truth_file``: the dev truth file of config.py:262-276 ("<impression> [labels]" lines); written from the corpus's
-        own dev labels when a ``dev_labels`` list is attached to the corpus and no file is given."""
+        own dev labels when a ``dev_labels`` list is attached to the corpus and no file is given.  ``cached_eval``: the dev pass
+        encodes every news once (util.compute_scores_cached) instead of once per row and slot; same scores."""
         self.model, self.config, self.corpus, self.run_index = model, config, corpus, run_index
         self.epoch, self.batch_size = config.epoch, config.batch_size
         self.dev_criterion, self.early_stopping_epoch = config.dev_criterion, config.early_stopping_epoch
@@ -37,6 +38,7 @@ class Trainer:
         self.dev_res_dir = _mkdir(os.path.join(config.dev_res_dir, '#%d' % run_index))
         self.result_dir = _mkdir(config.result_dir)
         self.truth_file = truth_file
+        self.cached_eval = cached_eval and config.lifetime_type == 'user_topic'
         self.dc = device_corpus if device_corpus is not None else DeviceCorpus(corpus)
         self.dev = DeviceBehaviors.from_devtest(self.dc, corpus, 'dev')
         self.step = TrainStep(model, lr=config.lr, weight_decay=config.weight_decay, gradient_clip_norm=config.gradient_clip_norm)
@@ -72,6 +74,8 @@ class Trainer:
 
     def evaluate(self, e):
         out = os.path.join(self.dev_res_dir, '%s-%d.txt' % (self.model.model_name, e))
+        if self.cached_eval:
+            return util.compute_scores_cached(self.model, self.dev, self.corpus.dev_indices, out, self.truth_file, 2 * self.batch_size)
         rows = list(range(self.dev.num))
         batches = (self.dev.assemble(rows[i:i + 2 * self.batch_size]) for i in range(0, len(rows), 2 * self.batch_size))
         return util.compute_scores(self.model, batches, self.corpus.dev_indices, out, self.truth_file)

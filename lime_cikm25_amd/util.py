@@ -80,3 +80,30 @@ def compute_scores(model, batches, indices, result_file, truth_file=None):
         return None, None, None, None
     with open(truth_file, 'r', encoding='utf-8') as truth_f, open(result_file, 'r', encoding='utf-8') as result_f:
         return scoring(truth_f, result_f)
+
+
+def compute_scores_cached(model, behaviors, indices, result_file, truth_file=None, rows_per_forward=None):
+    """The same dev / test pass from a per-news content cache (Model.build_news_cache + Model.score_behaviors): every news goes
+    through the token encoders ONCE instead of once per (row, slot) -- the reference re-encodes all 51 news of every row
+    (util.py:86-111).  ``behaviors``: a dev / test ``DeviceBehaviors``.  Rows are scored in chunks of ``rows_per_forward`` (default:
+    twice the training batch size, as main.py:50 calls compute_scores) with the chunk's row count as the GraphSAGE source count,
+    so the scores are those of ``compute_scores`` over the same batches; lifetime_type 'user_topic' (config.py:62)."""
+    config = model.config
+    if config.lifetime_type != 'user_topic':
+        raise NotImplementedError("the cached pass derives the remaining lifetime as lifetime_type 'user_topic' does")
+    per = rows_per_forward or 2 * config.batch_size
+    was_training = model.training
+    model.eval()
+    cache = model.build_news_cache(behaviors.corpus)
+    scores = []
+    for r0 in range(0, behaviors.num, per):
+        rows = list(range(r0, min(behaviors.num, r0 + per)))
+        scores.append(model.score_behaviors(behaviors, rows, cache, n_src=len(rows)).float().cpu())
+    model.train(was_training)
+    scores = torch.cat(scores).tolist() if scores else []
+    assert len(scores) == len(indices), 'one score per (impression, candidate) row'
+    write_rank_file(result_file, rank_impressions(scores, indices))
+    if truth_file is None:
+        return None, None, None, None
+    with open(truth_file, 'r', encoding='utf-8') as truth_f, open(result_file, 'r', encoding='utf-8') as result_f:
+        return scoring(truth_f, result_f)

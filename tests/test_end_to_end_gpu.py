@@ -53,6 +53,10 @@ def test_files_to_metrics(tmp_path):
     auc, mrr, ndcg5, ndcg10 = util.compute_scores(model, batches, corpus.dev_indices, str(tmp_path / 'rank.txt'), str(truth))
     for m in (auc, mrr, ndcg5, ndcg10):
         assert 0.0 <= m <= 1.0
+    # the cached dev pass (every news through the token encoders once) over the same single batch: the same rank file
+    cached = util.compute_scores_cached(model, dev, corpus.dev_indices, str(tmp_path / 'rank_cached.txt'), str(truth), rows_per_forward=dev.num)
+    assert open(tmp_path / 'rank_cached.txt').read() == open(tmp_path / 'rank.txt').read()
+    assert cached == (auc, mrr, ndcg5, ndcg10)
     ranks = [json.loads(line.split(' ', 1)[1]) for line in open(tmp_path / 'rank.txt')]
     assert [sorted(r) for r in ranks] == [list(range(1, len(lab) + 1)) for lab in formats.truth_labels(L['dev_behaviors'])]
 
