@@ -60,7 +60,9 @@ class Trainer:
         cfg, model = self.config, self.model
         samples = negative_sampling(self.corpus.train_behaviors, cfg.negative_sample_num)     # dataset.py:42-77
         train = DeviceBehaviors.from_train(self.dc, self.corpus, *samples)
-        order = np.random.permutation(train.num)                             # DataLoader(shuffle=True), trainer.py:86
+        # shuffle (DataLoader(shuffle=True), trainer.py:86) with a generator every rank seeds alike, as DistributedSampler
+        # does with (seed, epoch): the ranks' row sets must partition ONE permutation
+        order = np.random.RandomState(getattr(cfg, 'seed', 0) + e).permutation(train.num)
         rows = distributed.sampler_rows(train.num, self.rank, self.world, order)
         model.train()
         total, seen = 0.0, 0
