@@ -1,33 +1,46 @@
 """bench.py -- impressions scored / sec on MI355X for LIME's candidate-scoring path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2b|cfg2a|cfg1|cfg3shape]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2b|cfg2a|cfg1|cfg3|cfg5|train2b|...]
 
-A step = one ``Model.forward`` (news encoder over the K candidates and H history news of every row,
-CROWN user encoder, dot product x remaining-lifetime weight) over one synthetic MIND-shaped batch
-that is already resident in HBM.  Default workload = BASELINE.json configs[1] with the reference's
-default body length: LIME-CROWN-CROWN, batch 32, history 50, title 32 + body 128, K = 1+4, 300-d, fp32.
-Impression rows are independent, so N GPUs score N batches with no data-path collective (weak scaling).
+With ``--gpus N`` (N > 1) from a plain shell the script launches its N ranks itself: N fresh child processes, spawned
+BEFORE this process makes any GPU call, each with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what the reference does
+with ``mp.spawn`` in main.py:28 and ``init_process_group(backend='nccl', init_method='env://')`` in trainer.py:246-256).
+Under ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` the ranks already exist and are used as
+they are.  One process per GPU, backend "nccl" (= RCCL over xGMI on ROCm).
 
-Rank 0 prints ONE JSON line: metric/value/unit ..., plus
-  "roofline"     the dominant kernel (the 128x128 fp32-MFMA GEMM behind in_proj / linear1), algorithmic FLOPs per
-                 launch / average launch duration from HIP events recorded in the timed region on the launch stream,
-                 against the 157.3 TFLOP/s fp32 matrix peak of MI355X_MICROARCH.md;
-  "cpu_baseline" the CPU oracle (oracle/lime_oracle.py, a torch-CPU port of the reference forward) timed on this
-                 host's cores on the same workload (rank 0, N=1 only).
+A step = one ``Model.forward`` (news encoder over the K candidates and H history news of every row, CROWN user encoder,
+dot product x remaining-lifetime weight) over one synthetic MIND-shaped batch that is already resident in HBM.  Default
+workload = BASELINE.json configs[1] with the reference's default body length: LIME-CROWN-CROWN, batch 32, history 50,
+title 32 + body 128, K = 1+4, 300-d, fp32.  Impression rows are independent, so N GPUs score N batches with no data-path
+collective (weak scaling); the training workloads add the one exchange step of the path, the all-reduce of the flat
+gradient bucket.
+
+Rank 0 prints ONE JSON line: metric / value / unit ... (value = exactly K timed steps between two barriers), plus
+  "roofline"        the dominant kernel: ALGORITHMIC FLOPs per launch (2 m n k on the unpadded problem: in_proj counts its
+                    900 useful columns, not the 960 the kernel computes) / average launch duration from HIP events recorded
+                    on the launch stream, against the 157.3 TFLOP/s fp32-matrix peak of MI355X_MICROARCH.md; "frac_padded"
+                    counts the padded columns as well; "traffic" is NOT measured in this run -- it is the PMC figure of the
+                    rocprofv3 pass named in "traffic_source";
+  "sustained"       the same step over a >= 2 s region (>= 100 steps), batches rotating;
+  "value_with_h2d"  the same K steps with the 26 input tensors copied from pinned host memory inside every step
+                    (trainer.py:93-118, util.py:94);
+  "cpu_baseline"    the CPU oracle (oracle/lime_oracle.py, a torch-CPU port of the reference forward) timed on this
+                    host's cores on the same workload (rank 0, N = 1 only): 3 warm-ups + 5 forwards;
+  "also"            (default workload, N = 1) the other BASELINE.json configurations in the same run: cfg2a (configs[1]
+                    read literally: title only), cfg3 (configs[2]: batch 256, bf16), cfg5 (configs[4]: 1024 x 100 scoring),
+                    train2b (one training step at the configs[1] shape), train4 (configs[3] per-GPU shape).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 (the 5 PF headline figure includes 2:1 sparsity)
@@ -38,7 +51,7 @@ WORKLOADS = {
     'cfg2b': (dict(), 32, 5, 'MIND-shape synthetic, LIME-CROWN-CROWN, batch=32, history=50, title_len=32, body_len=128, '
                              'K=1+4, 300-d, fp32 (BASELINE.json configs[1], reference default body length)'),
     'cfg2a': (dict(content_encoder='MHSA'), 32, 5, 'MIND-shape synthetic, LIME-MHSA-CROWN (title only), batch=32, history=50, '
-                                                   'title_len=32, K=1+4, 300-d, fp32'),
+                                                   'title_len=32, K=1+4, 300-d, fp32 (BASELINE.json configs[1] read literally)'),
     'cfg1': (dict(max_history_num=10, max_title_length=16, max_abstract_length=32, batch_size=8), 8, 2,
              'MIND-small synthetic, batch=8, history=10, title_len=16, K=1+1 (BASELINE.json configs[0])'),
     'cfg3shape': (dict(batch_size=256), 256, 5, 'MIND-shape synthetic, batch=256, history=50, title 32 + body 128, K=1+4, '
@@ -59,10 +72,15 @@ WORKLOADS = {
                'training step at the BASELINE.json configs[3] shape per GPU (Adressa-shape: batch=32 per GPU, history=50, '
                'title 32 + body 512, K=1+4, config.batch_size=256), forward + backward + gradient all-reduce + clip + Adam, fp32, '
                'dropout off'),
+    'cfg4fwd': (dict(max_abstract_length=512, batch_size=256), 32, 5,
+                'scoring forward at the BASELINE.json configs[3] shape per GPU (batch=32, history=50, title 32 + body 512, K=1+4), fp32'),
     'cfg5': (dict(batch_size=1024), 1024, 100,
              'MIND-shape inference, 1024 impressions x K=100 candidates, history=50, title 32 + body 128, scoring only, '
              'eval-mode (per-candidate) semantics with every history encoded once (BASELINE.json configs[4]), fp32'),
 }
+# (workload, steps, warmup) run beside the default line so that the driver's own run times them
+ALSO = (('cfg2a', 100, 10), ('cfg3', 30, 5), ('cfg5', 3, 1), ('train2b', 30, 5), ('train4', 8, 2))
+N_BATCHES = 4           # distinct resident batches a scoring run rotates through
 
 
 def flops_per_impression(cfg, N, per_candidate_user_side=False):
@@ -82,64 +100,210 @@ def flops_per_impression(cfg, N, per_candidate_user_side=False):
     return (H + N) * news + user(N)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', default='cfg2b', choices=sorted(WORKLOADS))
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--overlap-streams', action='store_true',
-                    help='fork the title / body / freshness / attention-weight branches onto side streams in the timed region')
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher: N fresh ranks, spawned before this process touches the GPU
+# ---------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
-        args.gpus = world
-    assert torch.cuda.is_available(), 'bench.py needs the MI355X (the product path has no CPU fallback)'
-    local_rank %= max(1, torch.cuda.device_count())      # (a 2-rank rehearsal on a 1-GPU box shares the device)
-    torch.cuda.set_device(local_rank)
-    from lime_cikm25_amd import distributed as D
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        backend = os.environ.get('LIME_BENCH_BACKEND', 'nccl')                  # "nccl" is RCCL on ROCm; gloo only to rehearse
-        D.init(backend=backend, device_id=torch.device('cuda', local_rank) if backend == 'nccl' else None)
 
-    from lime_cikm25_amd import Model, make_config, newsEncoders, ops, synth
-    if args.overlap_streams:
-        newsEncoders.OVERLAP_BRANCHES = frozenset((0, 1, 2))
-    overrides, B, N, desc = WORKLOADS[args.workload]
-    cfg = make_config(**overrides)
-    model = Model(cfg)
-    model.initialize()
-    synth.fill_state_dict(model, seed=1)
-    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
-    model = model.cuda()
-    model.eval()
-    model.training = True                        # [B, K] candidates; every child in eval mode
-    batch_cpu = synth.make_batch(cfg, B, N, seed=100 + rank)
-    batch = [v.cuda() for v in batch_cpu.values()]
-    step = torch.no_grad()(lambda: model(*batch))      # scoring: no autograd graph (grad mode on would take the training path)
-    train = args.workload.startswith('train')
-    if train:                                    # trainer.py:131-148 on the native step (flat buckets, one all-reduce)
-        from lime_cikm25_amd.training import TrainStep
-        if cfg.dropout_rate > 0:
-            model.train()                        # every dropout active, as under trainer.py:87
-        ts = TrainStep(model, lr=1e-5, gradient_clip_norm=4.0)
-        step = lambda: ts.step(*batch)
-    if args.workload == 'cfg5':                  # Model.score_impressions: eval semantics, histories encoded once (eager)
-        model.training = False
-        c = {k: v.cuda() for k, v in batch_cpu.items()}
-        sargs = [c[k] for k in ('user_category', 'user_subCategory', 'user_title_text', 'user_title_mask', 'user_content_text',
-                                'user_freshness', 'user_user_topic_lifetime', 'user_history_mask', 'news_category',
-                                'news_subCategory', 'news_title_text', 'news_title_mask', 'news_content_text', 'news_freshness',
-                                'news_user_topic_lifetime', 'remaining_lifetime')]
-        step = lambda: model.score_impressions(*sargs)
+def launch_ranks(n, argv):
+    """Spawn ``n`` child processes of this script (rank r on GPU r) and return the worst exit code.  The parent never
+    initialises the GPU (no torch import even): children are plain ``subprocess`` spawns, nothing is exec'ed over a process
+    that holds the device.  Rank 0's stdout (the JSON line) is passed through; every rank shares stderr."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), LIME_BENCH_SPAWNED='1')
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one workload on this rank
+# ---------------------------------------------------------------------------------------------------------------------
+class Run:
+    """Model + resident batches + the step closure of one workload."""
+
+    def __init__(self, name, rank, world, overlap_streams=False):
+        import torch
+        from lime_cikm25_amd import Model, make_config, newsEncoders, synth
+        self.name, self.rank, self.world = name, rank, world
+        overrides, self.B, self.N, self.desc = WORKLOADS[name]
+        if overlap_streams:
+            newsEncoders.OVERLAP_BRANCHES = frozenset((0, 1, 2))
+        self.cfg = cfg = make_config(**overrides)
+        self.train = name.startswith('train')
+        model = Model(cfg)
+        model.initialize()
+        synth.fill_state_dict(model, seed=1)
+        self.sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if rank == 0 else None
+        self.model = model = model.cuda()
+        model.eval()
+        model.training = True                        # [B, K] candidates; every child in eval mode
+        nb = 1 if (self.train or name == 'cfg5') else N_BATCHES
+        self.batches_cpu = [synth.make_batch(cfg, self.B, self.N, seed=100 + rank + 1000 * i) for i in range(nb)]
+        self.batches = [[v.cuda() for v in b.values()] for b in self.batches_cpu]
+        self.i = 0
+        self.ts = None
+        if self.train:                                # trainer.py:131-148 on the native step (flat buckets, one all-reduce)
+            from lime_cikm25_amd.training import TrainStep
+            if cfg.dropout_rate > 0:
+                model.train()                         # every dropout active, as under trainer.py:87
+            self.ts = TrainStep(model, lr=1e-5, gradient_clip_norm=4.0)
+            self._step = lambda b: self.ts.step(*b)
+        elif name == 'cfg5':                          # Model.score_impressions: eval semantics, histories encoded once (eager)
+            model.training = False
+            keys = ('user_category', 'user_subCategory', 'user_title_text', 'user_title_mask', 'user_content_text',
+                    'user_freshness', 'user_user_topic_lifetime', 'user_history_mask', 'news_category', 'news_subCategory',
+                    'news_title_text', 'news_title_mask', 'news_content_text', 'news_freshness', 'news_user_topic_lifetime',
+                    'remaining_lifetime')
+            c = {k: v.cuda() for k, v in self.batches_cpu[0].items()}
+            sargs = [c[k] for k in keys]
+            self._step = lambda b: model.score_impressions(*sargs)
+        else:
+            nograd = torch.no_grad()
+            self._step = nograd(lambda b: model(*b))  # scoring: no autograd graph (grad mode on would take the training path)
+
+    def step(self):
+        b = self.batches[self.i % len(self.batches)]
+        self.i += 1
+        return self._step(b)
+
+    def step_h2d(self, pinned):
+        """The step with the host->device copy of the batch inside it (all 26 tensors, as trainer.py:93-118 moves them)."""
+        p = pinned[self.i % len(pinned)]
+        self.i += 1
+        return self._step([t.cuda(non_blocking=True) for t in p])
+
+
+def timed(run, steps, warmup, barrier, step=None):
+    step = step or run.step
+    out = None
+    for _ in range(warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    barrier()
+    return time.perf_counter() - t0, out
+
+
+def kernel_profile(run, steps):
+    """Per-kernel durations: ``steps`` more steps launched eagerly with a HIP event pair recorded on the launch stream around
+    every lime_linear_f32 launch (events cannot be recorded inside a graph replay).  Every branch of the forward runs on ONE
+    stream here (in the timed region only the two small head branches are forked; the token-encoder GEMMs are alone on the
+    device there as well), so these durations are what rocprofv3 --kernel-trace reports for the same command (profiles/)."""
+    import torch
+    from lime_cikm25_amd import newsEncoders, ops
+    prof = []
+    ops.PROFILE = prof
+    newsEncoders.SERIAL_STREAMS = True
+    try:
+        if run.train:                                  # rank 0 alone: the same step without the collective
+            from lime_cikm25_amd.training import negative_log_softmax
+            ts, model, b = run.ts, run.model, run.batches[0]
+            for _ in range(steps):
+                ts.grad.zero_()
+                negative_log_softmax(model(*b)).backward()
+                ts.update()
+        else:
+            for _ in range(steps):
+                run.step()
+        torch.cuda.synchronize()
+    finally:
+        newsEncoders.SERIAL_STREAMS = False
+        ops.PROFILE = None
+    by_kernel = {}
+    for (name, m, n, k, n_alg, e0, e1) in prof:
+        d = by_kernel.setdefault(name, [0.0, 0.0, 0.0, 0])
+        d[0] += 2.0 * m * n_alg * k                    # algorithmic: the useful output columns
+        d[1] += 2.0 * m * n * k                        # what the kernel computes (head padding included)
+        d[2] += e0.elapsed_time(e1) * 1e-3
+        d[3] += 1
+    return by_kernel
+
+
+def roofline(by_kernel, workload, steps):
+    if not by_kernel:
+        return None
+    name, (fl, flp, sec, cnt) = max(by_kernel.items(), key=lambda kv: kv[1][2])
+    ach = fl / sec / 1e12
+    traffic, source = None, None
+    tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tfile) and workload == 'cfg2b':       # the PMC passes were taken on this workload's launches
+        tj = json.load(open(tfile))
+        traffic = tj.get(name, {}).get('hbm_bytes_per_launch')
+        source = tj.get('_source', 'profiles/traffic.json')
+    is_bf16 = name.startswith('gemm_pp_kernel<') and name.split(', ')[4].startswith('true')   # <NTL, LN, RELU, RES, BF, ...>
+    peak = PEAK_BF16_MFMA_TFLOPS if is_bf16 else PEAK_F32_MFMA_TFLOPS
+    return {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+            'frac': round(ach / peak, 4), 'frac_padded': round(flp / sec / 1e12 / peak, 4),
+            'traffic': traffic, 'traffic_source': (source + ' -- a rocprofv3 --pmc pass of an earlier run of this command, NOT measured '
+                                                   'in this run') if traffic is not None else None,
+            'launches': cnt, 'avg_launch_us': round(sec / cnt * 1e6, 1), 'flops_per_launch': fl / cnt,
+            'flops_per_launch_padded': flp / cnt,
+            'measured': 'HIP events on the launch stream, eager pass of %d steps, branches on one stream' % steps,
+            'all_gemm_kernels': {k: {'tflops': round(v[0] / v[2] / 1e12, 2), 'avg_launch_us': round(v[2] / v[3] * 1e6, 1),
+                                     'launches': v[3]} for k, v in by_kernel.items()}}
+
+
+def cpu_baseline(run, logits, first_loss):
+    """The oracle on this host's cores: 3 warm-ups + 5 timed forwards of the workload's batches (training: one forward +
+    backward, no warm-up -- a step takes ~6 s)."""
+    import torch
+    from oracle import lime_oracle
+    cfg, B = run.cfg, run.B
+    ncore = min(len(os.sched_getaffinity(0)), 16)         # the GPU box gives one GPU's share of the host: 16 cores
+    torch.set_num_threads(ncore)
+    if run.train:
+        sd_g = {k: v.clone() for k, v in run.sd_cpu.items()}
+        for k in run.ts.names:
+            sd_g[k].requires_grad_(True)
+        for k in list(sd_g):
+            if k.startswith('user_encoder.news_encoder.'):
+                sd_g[k] = sd_g[k[len('user_encoder.'):]]
+        c0 = time.perf_counter()
+        lg = lime_oracle.model_forward(sd_g, cfg, run.batches_cpu[0], grad=True)
+        closs = (-torch.log_softmax(lg, dim=1).select(dim=1, index=0)).mean()
+        closs.backward()
+        cdt = time.perf_counter() - c0
+        return {'value': round(B / cdt, 2), 'unit': 'impressions/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                'sample': '1 forward + backward of the same %d-impression batch (torch CPU fp32 oracle with autograd, no optimizer '
+                          'step, no warm-up)' % B, 'first_step_loss_cpu': float(closs), 'first_step_loss_gpu': first_loss}
+    n_warm, n_timed = 3, 5
+    nb = len(run.batches_cpu)
+    for i in range(n_warm):
+        lime_oracle.model_forward(run.sd_cpu, cfg, run.batches_cpu[i % nb])
+    c0 = time.perf_counter()
+    for i in range(n_timed):
+        want = lime_oracle.model_forward(run.sd_cpu, cfg, run.batches_cpu[i % nb])
+    cdt = time.perf_counter() - c0
+    with torch.no_grad():
+        got = run.model(*run.batches[(n_timed - 1) % nb]).cpu()
+    err = float(((got - want).abs() / (want.abs() + want.abs()[want != 0].mean())).max())
+    return {'value': round(B * n_timed / cdt, 2), 'unit': 'impressions/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d forwards over %d distinct %d-impression batches of the workload (torch CPU fp32 oracle, %d warm-ups)'
+                      % (n_timed, nb, B, n_warm), 'max_rel_err_gpu_vs_cpu': err}
+
+
+def bench_workload(name, steps, warmup, rank, world, dist, D, args, full=True):
+    """Time one workload; returns the result dict on rank 0 (None elsewhere)."""
+    import torch
+    run = Run(name, rank, world, overlap_streams=args.overlap_streams)
+    cfg, B, N, train = run.cfg, run.B, run.N, run.train
 
     def barrier():
         torch.cuda.synchronize()
@@ -147,127 +311,117 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The forward's ~75 launches are replayed from a HIP graph captured on the first call (Model.use_graph).
-    first_loss = None
-    for i in range(args.warmup):
-        logits = step()
-        if i == 0 and train:
-            first_loss = float(logits)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        logits = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    dt = D.max_over_ranks(dt, device='cuda')                     # the slowest rank's time
+    first = run.step()                                   # captures the HIP graph / builds the buckets
+    first_loss = float(first) if train else None
+    dt, logits = timed(run, steps, max(0, warmup - 1), barrier)
+    dt = D.max_over_ranks(dt, device='cuda')             # the slowest rank's time
     assert torch.isfinite(logits).all()
-    # Per-kernel durations: the same K steps again, launched eagerly with a HIP event pair recorded on the launch
-    # stream around every lime_linear_f32 launch (events cannot be recorded inside a graph replay).  Every branch of the
-    # forward runs on ONE stream here (in the timed region only the two small head branches are forked, the token-encoder
-    # GEMMs are alone on the device there as well), so these durations are the quantity rocprofv3 --kernel-trace reports
-    # for the same command (profiles/).
-    prof = []
-    if rank == 0:
-        ops.PROFILE = prof
-        newsEncoders.SERIAL_STREAMS = True
-        if train:                                  # rank 0 alone: the same step without the collective
-            from lime_cikm25_amd.training import negative_log_softmax
-
-            def local_step():
-                ts.grad.zero_()
-                negative_log_softmax(model(*batch)).backward()
-                ts.update()
-            prof_step = local_step
-        else:
-            prof_step = step
-        for _ in range(args.steps):
-            prof_step()
-        torch.cuda.synchronize()
-        newsEncoders.SERIAL_STREAMS = False
-        ops.PROFILE = None
+    sustained = h2d = None
+    if full and name != 'cfg5':
+        # >= 2 s and >= 100 steps, batches rotating (the K-step region above is what `value` reports)
+        n_sus = int(min(2000, max(100, 2.2 / (dt / steps))))
+        sdt, _ = timed(run, n_sus, 0, barrier)
+        sdt = D.max_over_ranks(sdt, device='cuda')
+        sustained = {'steps': n_sus, 'seconds': round(sdt, 3), 'ms_per_step': round(sdt / n_sus * 1e3, 4),
+                     'value': round(world * B * n_sus / sdt, 2)}
+        pinned = [[t.pin_memory() for t in b.values()] for b in run.batches_cpu]
+        hdt, _ = timed(run, steps, 2, barrier, step=lambda: run.step_h2d(pinned))
+        hdt = D.max_over_ranks(hdt, device='cuda')
+        nbytes = sum(t.numel() * t.element_size() for t in pinned[0])
+        h2d = {'value_with_h2d': round(world * B * steps / hdt, 2), 'ms_per_step_with_h2d': round(hdt / steps * 1e3, 4),
+               'h2d_bytes_per_step': nbytes,
+               'h2d_note': 'all 26 input tensors copied from pinned host memory with .cuda(non_blocking=True) inside every step'}
+    by_kernel = kernel_profile(run, min(steps, 20) if full else min(steps, 5)) if rank == 0 else {}
     if dist is not None:
         dist.barrier()
+    if rank != 0:
+        return None
+    value = world * B * steps / dt
+    fimp = flops_per_impression(cfg, N, per_candidate_user_side=name == 'cfg5')
+    if train:
+        fimp *= 3                                       # backward = input gradients + weight gradients: 2 x the forward GEMMs
+    bf16 = getattr(cfg, 'compute_dtype', 'fp32') == 'bf16'
+    out = {
+        'metric': 'impressions trained/sec' if train else 'impressions scored/sec', 'value': round(value, 2), 'unit': 'impressions/s',
+        'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': round(dt / steps * 1e3, 4),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
+        'config': {'workload': run.desc, 'batch_per_gpu': B, 'history': cfg.max_history_num, 'candidates': N,
+                   'title_len': cfg.max_title_length, 'body_len': cfg.max_abstract_length,
+                   'parallelism': ('data parallel over %d GPU(s), one all-reduce of the flat gradient bucket per step' % world) if train
+                   else 'rows sharded over %d GPU(s), no data-path collective' % world,
+                   'backend': (dist.get_backend() if dist is not None else None), 'world_size': world,
+                   'distinct_batches': len(run.batches),
+                   'streams': 'title / body / freshness / attention-weight branches forked' if args.overlap_streams else
+                   'token encoders on one stream; freshness and attention-weight branches forked beside the head'},
+        'roofline': roofline(by_kernel, name, min(steps, 20) if full else min(steps, 5)),
+        'end_to_end': {'flops_per_impression': fimp, 'achieved_tflops': round(value * fimp / 1e12, 2),
+                       'frac_of_f32_mfma_peak': round(value * fimp / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4)},
+    }
+    if sustained:
+        out['sustained'] = sustained
+    if h2d:
+        out.update(h2d)
+    if full and world == 1 and not args.no_cpu_baseline and name != 'cfg5' and (not train or cfg.dropout_rate == 0):
+        out['cpu_baseline'] = cpu_baseline(run, logits, first_loss)
+    return out
 
+
+def brief(res):
+    """The part of a workload's result kept under "also"."""
+    r = res['roofline'] or {}
+    return {'metric': res['metric'], 'value': res['value'], 'unit': res['unit'], 'steps': res['steps'], 'warmup': res['warmup'],
+            'ms_per_step': res['ms_per_step'], 'dtype': res['dtype'], 'workload': res['config']['workload'],
+            'end_to_end_tflops': res['end_to_end']['achieved_tflops'],
+            'dominant_kernel': {k: r.get(k) for k in ('kernel', 'achieved', 'peak', 'frac', 'frac_padded', 'avg_launch_us', 'launches')}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=500)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', default='cfg2b', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-also', action='store_true', help='skip the other BASELINE configurations beside the default line')
+    ap.add_argument('--overlap-streams', action='store_true',
+                    help='fork the title / body / freshness / attention-weight branches onto side streams in the timed region')
+    args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # a plain `python bench.py --gpus N`: become the launcher.  Nothing above imported torch or touched the GPU.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    args.gpus = world
+    assert torch.cuda.is_available(), 'bench.py needs the MI355X (the product path has no CPU fallback)'
+    ndev = torch.cuda.device_count()
+    shared = world > ndev                                 # a rehearsal of N ranks on fewer devices (1-GPU box)
+    torch.cuda.set_device(local_rank % max(1, ndev))
+    from lime_cikm25_amd import distributed as D
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        # "nccl" is RCCL on ROCm.  RCCL refuses two ranks on one device, so a rehearsal on a 1-GPU box falls back to gloo
+        # (and says so in config.backend); a real N-GPU node always takes nccl.
+        backend = os.environ.get('LIME_BENCH_BACKEND', 'gloo' if shared else 'nccl')
+        D.init(backend=backend, device_id=torch.device('cuda', local_rank % ndev) if backend == 'nccl' else None)
+
+    res = bench_workload(args.workload, args.steps, args.warmup, rank, world, dist, D, args, full=True)
+    if rank == 0 and world == 1 and args.workload == 'cfg2b' and not args.no_also:
+        also = {}
+        for name, steps, warmup in ALSO:
+            try:
+                torch.cuda.empty_cache()
+                also[name] = brief(bench_workload(name, steps, warmup, 0, 1, None, D, args, full=False))
+            except Exception as e:                         # the headline line must survive a failing side workload
+                also[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+        res['also'] = also
     if rank == 0:
-        value = world * B * args.steps / dt
-        fimp = flops_per_impression(cfg, N, per_candidate_user_side=args.workload == 'cfg5')
-        if train:
-            fimp *= 3                                   # backward = input gradients + weight gradients: 2 x the forward GEMMs
-        # dominant kernel = the gemm_f32_kernel instantiation with the largest total time (out_proj + linear2 of both
-        # encoders: 128x320 tiles, residual in the accumulators, LayerNorm epilogue)
-        by_kernel = {}
-        for (name, m, n, k, e0, e1) in prof:
-            d = by_kernel.setdefault(name, [0.0, 0.0, 0])
-            d[0] += 2.0 * m * n * k
-            d[1] += e0.elapsed_time(e1) * 1e-3
-            d[2] += 1
-        roof = None
-        if by_kernel:
-            name, (fl, sec, cnt) = max(by_kernel.items(), key=lambda kv: kv[1][1])
-            ach = fl / sec / 1e12
-            traffic = None
-            tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-            if os.path.exists(tfile) and args.workload == 'cfg2b':      # the PMC passes were taken on this workload's launches
-                traffic = json.load(open(tfile)).get(name, {}).get('hbm_bytes_per_launch')
-            is_bf16 = name.startswith('gemm_pp_kernel<') and name.split(', ')[4].startswith('true')   # gemm_pp_kernel<NTL, LN, RELU, RES, BF, PING>
-            peak = PEAK_BF16_MFMA_TFLOPS if is_bf16 else PEAK_F32_MFMA_TFLOPS
-            roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak,
-                    'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': traffic,
-                    'launches': cnt, 'avg_launch_us': round(sec / cnt * 1e6, 1), 'flops_per_launch': fl / cnt,
-                    'measured': 'HIP events on the launch stream, eager pass of the same %d steps, branches on one stream' % args.steps,
-                    'all_gemm_kernels': {k: {'tflops': round(v[0] / v[1] / 1e12, 2), 'avg_launch_us': round(v[1] / v[2] * 1e6, 1),
-                                             'launches': v[2]} for k, v in by_kernel.items()}}
-        out = {
-            'metric': 'impressions trained/sec' if train else 'impressions scored/sec', 'value': round(value, 2), 'unit': 'impressions/s', 'n_gpus': world,
-            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16' if getattr(cfg, 'compute_dtype', 'fp32') == 'bf16' else 'f32', 'data': 'synthetic',
-            'config': {'workload': desc, 'batch_per_gpu': B, 'history': cfg.max_history_num, 'candidates': N,
-                       'title_len': cfg.max_title_length, 'body_len': cfg.max_abstract_length,
-                       'parallelism': ('data parallel over %d GPU(s), one all-reduce of the flat gradient bucket per step' % world) if train
-                       else 'rows sharded over %d GPU(s), no data-path collective' % world,
-                       'streams': 'title / body / freshness / attention-weight branches forked' if args.overlap_streams else
-                       'token encoders on one stream; freshness and attention-weight branches forked beside the head'},
-            'roofline': roof,
-            'end_to_end': {'flops_per_impression': fimp, 'achieved_tflops': round(value * fimp / 1e12, 2),
-                           'frac_of_f32_mfma_peak': round(value * fimp / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4)},
-        }
-        if world == 1 and not args.no_cpu_baseline and train and cfg.dropout_rate == 0:
-            from oracle import lime_oracle
-            ncore = min(len(os.sched_getaffinity(0)), 16)
-            torch.set_num_threads(ncore)
-            sd_g = {k: v.clone() for k, v in sd_cpu.items()}
-            for k in ts.names:
-                sd_g[k].requires_grad_(True)
-            for k in list(sd_g):
-                if k.startswith('user_encoder.news_encoder.'):
-                    sd_g[k] = sd_g[k[len('user_encoder.'):]]
-            c0 = time.perf_counter()
-            lg = lime_oracle.model_forward(sd_g, cfg, batch_cpu, grad=True)
-            closs = (-torch.log_softmax(lg, dim=1).select(dim=1, index=0)).mean()
-            closs.backward()
-            cdt = time.perf_counter() - c0
-            out['cpu_baseline'] = {'value': round(B / cdt, 2), 'unit': 'impressions/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-                                   'sample': '1 forward + backward of the same %d-impression batch (torch CPU fp32 oracle with '
-                                             'autograd, no optimizer step, no warm-up)' % B,
-                                   'first_step_loss_cpu': float(closs), 'first_step_loss_gpu': first_loss}
-        elif world == 1 and not args.no_cpu_baseline and args.workload != 'cfg5' and not train:
-            from oracle import lime_oracle
-            # the GPU box gives one GPU's share of the host: 16 cores (more threads only oversubscribe)
-            ncore = min(len(os.sched_getaffinity(0)), 16)
-            torch.set_num_threads(ncore)
-            n_warm, n_timed = 1, 3
-            for _ in range(n_warm):
-                lime_oracle.model_forward(sd_cpu, cfg, batch_cpu)
-            c0 = time.perf_counter()
-            for _ in range(n_timed):
-                want = lime_oracle.model_forward(sd_cpu, cfg, batch_cpu)
-            cdt = time.perf_counter() - c0
-            err = float(((logits.cpu() - want).abs() / (want.abs() + want.abs()[want != 0].mean())).max())
-            out['cpu_baseline'] = {'value': round(B * n_timed / cdt, 2), 'unit': 'impressions/s', 'cores': torch.get_num_threads(),
-                                   'kind': 'port', 'sample': '%d forwards of the same %d-impression batch (torch CPU fp32 oracle, '
-                                   '%d warm-up)' % (n_timed, B, n_warm), 'max_rel_err_gpu_vs_cpu': err}
-        print(json.dumps(out))
+        print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

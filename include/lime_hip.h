@@ -44,7 +44,9 @@ const char* lime_last_error_string(void);
 enum { LIME_ACT_NONE = 0, LIME_ACT_RELU = 1, LIME_ACT_TANH = 2, LIME_ACT_SIGMOID = 3 };
 
 /*
- * lime_linear_f32: C = epilogue(A . W^T + bias), exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * lime_linear_f32: C = epilogue(A . W^T + bias), exact-fp32 MFMA: v_mfma_f32_16x16x4_f32 in the LDS-DMA kernel that takes the
+ * large 16-byte-aligned problems (gemm_pp_kernel: the four GEMMs of an encoder layer), v_mfma_f32_32x32x2_f32 in the general
+ * kernel behind every other shape (gemm_f32_kernel).
  *
  * Replaces every nn.Linear on the path, with the surrounding element-wise work fused:
  *   in_proj / out_proj / linear1 / linear2 of the two TransformerEncoderLayers (newsEncoders.py:244-247,316,320),

@@ -12,16 +12,28 @@ import torch
 import torch.distributed as dist
 
 
+def default_backend():
+    """"nccl" (= RCCL over xGMI on ROCm) when every local rank has a GPU of its own; "gloo" on CPU and when ranks share a device
+    (RCCL refuses two ranks on one GPU: the 2-rank rehearsal on a 1-GPU box)."""
+    if not torch.cuda.is_available():
+        return 'gloo'
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1')))
+    return 'nccl' if torch.cuda.device_count() >= local_world else 'gloo'
+
+
 def init(backend=None, device_id=None):
     """Initialise from the torchrun environment (RANK / WORLD_SIZE / MASTER_*); returns (rank, world)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        backend = backend or default_backend()
         kw = {}
-        if device_id is not None:
+        if device_id is None and backend == 'nccl':
+            device_id = torch.device('cuda', torch.cuda.current_device())
+        if device_id is not None and backend == 'nccl':
             kw['device_id'] = device_id
-        dist.init_process_group(backend=backend or ('nccl' if torch.cuda.is_available() else 'gloo'), **kw)
+        dist.init_process_group(backend=backend, **kw)
     return rank, world
 
 

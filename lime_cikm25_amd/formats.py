@@ -15,6 +15,7 @@ by default and reproduces the reference when ``stale_news_index`` is given.
 """
 import ast
 import json
+import os
 import re
 
 import numpy as np
@@ -120,6 +121,15 @@ def truth_labels(lines):
     return [[int(label) for _nid, label in parse_behavior_line(line)['impressions']] for line in lines]
 
 
+def write_truth_file(path, labels):
+    """The truth file of config.py:262-276: ``<impression> [l1,l2,...]`` lines, 1-based ids, no spaces, no trailing newline."""
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, 'w', encoding='utf-8') as f:
+        for i, lab in enumerate(labels):
+            f.write(('' if i == 0 else '\n') + str(i + 1) + ' ' + str([int(v) for v in lab]).replace(' ', ''))
+    return path
+
+
 # ---- news.tsv -> the per-news arrays of corpus.py:360-367 (what DeviceCorpus keeps in HBM) ----------------------------------
 _MIND_TOKENS = re.compile(r"[\w]+|[.,!?;|]")            # the 'MIND' tokenizer (corpus.py:23); 'NLTK' needs nltk and is not offered
 
@@ -191,6 +201,8 @@ def build_corpus(config, news_lines_by_split, behavior_lines_by_split, news_ID_d
     stale = left_over if reference_stale_lookup else None
     c.dev_behaviors, c.dev_indices = devtest_records(behavior_lines_by_split[1], *args, stale_news_index=stale)
     c.test_behaviors, c.test_indices = devtest_records(behavior_lines_by_split[2], *args, stale_news_index=stale)
+    c.dev_labels = truth_labels(behavior_lines_by_split[1])                 # what config.py:262-276 writes to dev/ref/truth-*.txt
+    c.test_labels = truth_labels(behavior_lines_by_split[2])
     for split in ('train', 'dev', 'test'):                                  # SUE-only tables (dataset.py:21-28)
         for name in ('user_history_graph', 'user_history_category_mask', 'user_history_category_indices'):
             setattr(c, '%s_%s' % (split, name), None)

@@ -66,8 +66,12 @@ class CandidateAware_ClickedNewsAttention(nn.Module):
         return out.view(B, H, D)
 
     def forward(self, clicked_news_embeddings, clicked_news_topic_embeddings, candidate_topic_embeddings, mask=None):
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError('training-mode dropout (p=0.2, layers.py:36,74) is not part of the scoring path yet')
+        """-> (refined history [B, H, D], attn_weights_agg [B, H]).  In training mode (autograd recording, or the layer's own
+        p = 0.2 dropout active, layers.py:36,74) the call takes the differentiable kernels of ``training.candidate_aware``."""
+        from . import training
+        if training.wants_train_path(self, self.dropout.p):
+            return training.candidate_aware(self, clicked_news_embeddings.float(), clicked_news_topic_embeddings.float(),
+                                            candidate_topic_embeddings.float(), mask)
         agg = self.attention_weights(clicked_news_topic_embeddings, candidate_topic_embeddings, mask)
         return self.refine(clicked_news_embeddings, agg), agg
 

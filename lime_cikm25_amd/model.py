@@ -76,8 +76,11 @@ class Model(nn.Module):
                 user_history_mask, user_history_graph, user_history_category_mask, user_history_category_indices, news_category,
                 news_subCategory, news_title_text, news_title_mask, news_title_entity, news_content_text, news_content_mask,
                 news_content_entity, news_freshness, news_user_topic_lifetime, remaining_lifetime)
-        if self.training and torch.is_grad_enabled():
-            # trainer.py:131-145: model.train(); logits = model(...); loss.backward() -- the differentiable path
+        if self.training and (torch.is_grad_enabled() or self.news_encoder.training or self.user_encoder.training):
+            # trainer.py:131-145: model.train(); logits = model(...); loss.backward() -- the differentiable path.  It is also the
+            # path with the training-mode dropouts (model.train() under no_grad: the layer's p = 0.2 dropout of layers.py:74 is
+            # active whatever config.dropout_rate says); `model.eval(); model.training = True` keeps the [B, K] shape on the
+            # fused scoring kernels (children in eval mode)
             return training.forward_train(self, user_category, user_subCategory, user_title_text, user_title_mask,
                                           user_content_text, user_freshness, user_user_topic_lifetime, user_history_mask,
                                           news_category, news_subCategory, news_title_text, news_title_mask, news_content_text,

@@ -28,8 +28,16 @@ MAX_TOKENS_PER_PASS = 4 * 1024 * 1024
 
 def _no_train_dropout(module, p):
     if module.training and p > 0:
-        raise NotImplementedError('training-mode dropout is not implemented: the HIP path covers scoring '
-                                  '(eval-mode children, or dropout_rate = 0); see SURVEY.md section 8f row 2')
+        raise NotImplementedError('encode_flat() is the fused scoring kernel chain (eval-mode children, or dropout_rate = 0): with '
+                                  'training-mode dropout active call the module (forward) or Model.forward, which take the '
+                                  'differentiable path of lime_cikm25_amd.training')
+
+
+def _flat_inputs(title_text, title_mask, content_text, category, subCategory):
+    B, n = title_text.shape[0], title_text.shape[1]
+    return (_i32(title_text).reshape(B * n, -1).contiguous(), title_mask.reshape(B * n, -1).contiguous(),
+            _i32(content_text).reshape(B * n, -1).contiguous(), _i32(category).reshape(-1).contiguous(),
+            _i32(subCategory).reshape(-1).contiguous())
 
 
 _SIDE = {}
@@ -241,7 +249,19 @@ class LIME(nn.Module):
         return res
 
     def forward(self, title_text, title_mask, title_entity, content_text, content_mask, content_entity, category, subCategory,
-                user_embedding, news_freshness, news_user_topic_lifetime):
+                user_embedding, news_freshness=None, news_user_topic_lifetime=None):
+        """newsEncoders.py:140-161 -> [B, n, output_dim].  In training mode (autograd recording or dropout active) the call takes
+        the differentiable path (``training.news_flat``): gradients reach every parameter the reference's do."""
+        from . import training
+        if training.wants_train_path(self, getattr(self.base_news_encoder, 'dropout_rate', 0.0)):
+            B, n = title_text.shape[0], title_text.shape[1]
+            fr, lt = news_freshness, news_user_topic_lifetime
+            fr = fr.unsqueeze(1) if fr.dim() == 1 else fr
+            lt = lt.unsqueeze(1) if lt.dim() == 1 else lt
+            lt = lt.expand_as(fr) if lt.shape != fr.shape else lt
+            rep = training.news_flat(self, *_flat_inputs(title_text, title_mask, content_text, category, subCategory),
+                                     fr.float().reshape(-1).contiguous(), lt.float().reshape(-1).contiguous())
+            return rep.view(B, n, -1)
         return self.encode_many([(title_text, title_mask, content_text, category, subCategory, news_freshness,
                                   news_user_topic_lifetime)])[0]
 
@@ -274,12 +294,14 @@ class NewsEncoder(nn.Module):
         nn.init.zeros_(self.affine.bias)
 
     def forward(self, title_text, title_mask, title_entity, content_text, content_mask, content_entity, category, subCategory,
-                user_embedding, news_freshness, news_user_topic_lifetime):
+                user_embedding, news_freshness=None, news_user_topic_lifetime=None):
         B, n = title_text.shape[0], title_text.shape[1]
+        flat = _flat_inputs(title_text, title_mask, content_text, category, subCategory)
+        from . import training
+        if training.wants_train_path(self, self.dropout_rate):
+            return training.content_flat(self, *flat).view(B, n, -1)
         out = torch.empty((B * n, self.news_embedding_dim), dtype=torch.float32, device=title_text.device)
-        self.encode_flat(_i32(title_text).reshape(B * n, -1).contiguous(), title_mask.reshape(B * n, -1).contiguous(),
-                         _i32(content_text).reshape(B * n, -1).contiguous(), _i32(category).reshape(-1).contiguous(),
-                         _i32(subCategory).reshape(-1).contiguous(), out)
+        self.encode_flat(*flat, out)
         return out.view(B, n, -1)
 
 
@@ -358,9 +380,9 @@ def encode_tokens(ids, table, pe, transformer, nhead, pooled_out=None):
             # (E[ids] + PE) W^T + b = E[ids] W^T + (PE W^T + b)[t]: the positional term is an [S, 3W] table added as a
             # periodic residual, so the A operand is a pure row gather (which the LDS-DMA GEMM can stage directly)
             pew = ops.linear(pe[:S], w_in, b_in)
-            qkv = ops.linear(table, w_in, None, a_ids=flat, res=pew, res_mod=S)
+            qkv = ops.linear(table, w_in, None, a_ids=flat, res=pew, res_mod=S, n_alg=3 * E)
         else:
-            qkv = ops.linear(x, w_in, b_in)
+            qkv = ops.linear(x, w_in, b_in, n_alg=3 * E)
         attn = ops.token_attention(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, 1.0 / math.sqrt(hd),
                                    head_stride=hs)
         ln1 = (layer.norm1.weight, layer.norm1.bias)
@@ -412,28 +434,28 @@ def encode_tokens_bf16(ids, table_bf16, pe, transformer, nhead, pooled_out):
         w_in_b = ops.to_bf16(w_in, cols_out=EP)
         if li == 0:
             pew = ops.linear(pe[:S], w_in, b_in)                                     # fp32 [S, 3W]: positional term + bias
-            qkv = ops.linear_bf16(table_bf16, w_in_b, None, a_ids=flat, res=pew, res_kind=1, res_mod=S)
+            qkv = ops.linear_bf16(table_bf16, w_in_b, None, a_ids=flat, res=pew, res_kind=1, res_mod=S, n_alg=3 * E, k_alg=E)
         else:
-            qkv = ops.linear_bf16(x, w_in_b, b_in)
+            qkv = ops.linear_bf16(x, w_in_b, b_in, n_alg=3 * E, k_alg=E)
         attn = ops.token_attention_bf16(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, 1.0 / math.sqrt(hd), out_cols=EP)
         w_o = ops.to_bf16(sa.out_proj.weight, rows_out=EP, cols_out=EP)
         ln1 = (padv(layer.norm1.weight), padv(layer.norm1.bias))
         if li == 0:
             pe_p = torch.cat([pe[:S], pe.new_zeros(S, EP - E)], dim=1)
             x1 = ops.linear_bf16(attn, w_o, padv(sa.out_proj.bias), res=table_bf16, res_kind=2, res_ids=flat, res_pe=pe_p,
-                                 res_period=S, ln=ln1, ln_eps=layer.norm1.eps, ln_count=E)
+                                 res_period=S, ln=ln1, ln_eps=layer.norm1.eps, ln_count=E, n_alg=E, k_alg=E)
         else:
-            x1 = ops.linear_bf16(attn, w_o, padv(sa.out_proj.bias), res=x, res_kind=3, ln=ln1, ln_eps=layer.norm1.eps, ln_count=E)
-        h = ops.linear_bf16(x1, ops.to_bf16(layer.linear1.weight, cols_out=EP), layer.linear1.bias, act='relu')
+            x1 = ops.linear_bf16(attn, w_o, padv(sa.out_proj.bias), res=x, res_kind=3, ln=ln1, ln_eps=layer.norm1.eps, ln_count=E, n_alg=E, k_alg=E)
+        h = ops.linear_bf16(x1, ops.to_bf16(layer.linear1.weight, cols_out=EP), layer.linear1.bias, act='relu', k_alg=E)
         last = li == len(transformer.layers) - 1
         if last and transformer.norm is None:
             # token mean pooling in the epilogue: fp32 means over 32-token blocks, [M * S / 32, EP]
             blocks = ops.linear_bf16(h, ops.to_bf16(layer.linear2.weight, rows_out=EP), padv(layer.linear2.bias), res=x1, res_kind=3,
                                      ln=(padv(layer.norm2.weight), padv(layer.norm2.bias)), ln_eps=layer.norm2.eps, ln_count=E,
-                                     pool32=True)
+                                     pool32=True, n_alg=E)
             return ops.mean_pool(blocks[:, :E], M, S // 32, out=pooled_out)
         x = ops.linear_bf16(h, ops.to_bf16(layer.linear2.weight, rows_out=EP), padv(layer.linear2.bias), res=x1, res_kind=3,
-                            ln=(padv(layer.norm2.weight), padv(layer.norm2.bias)), ln_eps=layer.norm2.eps, ln_count=E)
+                            ln=(padv(layer.norm2.weight), padv(layer.norm2.bias)), ln_eps=layer.norm2.eps, ln_count=E, n_alg=E)
     if transformer.norm is not None:
         raise NotImplementedError('a final encoder norm is not used by the reference (newsEncoders.py:245,247)')
     return ops.mean_pool_bf16(x, M, S, E, out=pooled_out)

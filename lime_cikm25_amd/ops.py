@@ -61,8 +61,11 @@ def _mask_u8(mask, name):
 
 
 def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=0, res=None, res_div=1, res_ids=None,
-           res_pe=None, res_period=0, ln=None, ln_eps=1e-5, res_mod=0, pool32=False, ln_rstd=None):
+           res_pe=None, res_period=0, ln=None, ln_eps=1e-5, res_mod=0, pool32=False, ln_rstd=None, n_alg=None):
     """C = epilogue(A . W^T + bias) -- see ``lime_linear_f32`` in include/lime_hip.h.
+
+    n_alg: the number of USEFUL output columns when w carries zero padding rows (in_proj with heads padded to 32 columns:
+    900 of 960); only bench.py's per-kernel FLOP accounting reads it.
 
     a: [M, K] (or the [V, K] table when a_ids is given, M = len(a_ids)); w: [N, K]; out: [M, N] (may be a view).
     ln: (gamma, beta) for the fused LayerNorm (N <= 320); ln_rstd: optional [M] output of the rows' 1 / sqrt(var + eps).
@@ -130,7 +133,7 @@ def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=
         e0.record()
         check(lib.lime_linear_f32(ctypes.byref(args), _stream()), 'lime_linear_f32')
         e1.record()
-        PROFILE.append((lib.lime_last_linear_kernel().decode(), M, N, K, e0, e1))
+        PROFILE.append((lib.lime_last_linear_kernel().decode(), M, N, K, n_alg or N, e0, e1))
         return out
     check(lib.lime_linear_f32(ctypes.byref(args), _stream()), 'lime_linear_f32')
     return out
@@ -416,7 +419,7 @@ def to_bf16(src, rows_out=None, cols_out=None, out=None):
 
 
 def linear_bf16(a, w, bias=None, act=None, out=None, a_ids=None, res=None, res_kind=0, res_mod=0, res_ids=None, res_pe=None,
-                res_period=0, ln=None, ln_eps=1e-5, ln_count=None, pool32=False):
+                res_period=0, ln=None, ln_eps=1e-5, ln_count=None, pool32=False, n_alg=None, k_alg=None):
     """``lime_linear_bf16``: a / w / out (and residual kinds 2, 3) bfloat16, bias / LayerNorm / residual kind 1 fp32."""
     lib = _lib.load()
     _mat(a, 'a', dtype=torch.bfloat16)
@@ -469,7 +472,7 @@ def linear_bf16(a, w, bias=None, act=None, out=None, a_ids=None, res=None, res_k
         e0.record()
         check(lib.lime_linear_bf16(ctypes.byref(args), _stream()), 'lime_linear_bf16')
         e1.record()
-        PROFILE.append((lib.lime_last_linear_kernel().decode(), M, N, K, e0, e1))
+        PROFILE.append((lib.lime_last_linear_kernel().decode(), M, N, k_alg or K, n_alg or N, e0, e1))
         return out
     check(lib.lime_linear_bf16(ctypes.byref(args), _stream()), 'lime_linear_bf16')
     return out
@@ -596,7 +599,7 @@ def linear_wgrad(dy, x, out=None, accumulate=False, bias_out=None, want_bias=Fal
                                         1 if accumulate else 0, _p(ws), ws.numel(), _stream()), 'lime_linear_wgrad_f32')
         if PROFILE is not None:
             e1.record()
-            PROFILE.append(('wgrad_kernel + reduce_partials_kernel (dW = dY^T X)', M, N, K, e0, e1))
+            PROFILE.append(('wgrad_kernel + reduce_partials_kernel (dW = dY^T X)', M, N, K, N, e0, e1))
     return out if bias_out is None else (out, bias_out)
 
 

@@ -13,7 +13,7 @@ import shutil
 import numpy as np
 import torch
 
-from . import distributed, util
+from . import distributed, formats, util
 from .device_data import DeviceBehaviors, DeviceCorpus, negative_sampling
 from .training import TrainStep, save_checkpoint
 
@@ -27,24 +27,52 @@ def _mkdir(path):
 
 class Trainer:
     def __init__(self, model, config, corpus, run_index=0, truth_file=None, device_corpus=None, cached_eval=True):
-        """``truth_file``: the dev truth file of config.py:262-276 ("<impression> [labels]" lines); written from the corpus's
-        own dev labels when a ``dev_labels`` list is attached to the corpus and no file is given.  ``cached_eval``: the dev pass
-        encodes every news once (util.compute_scores_cached) instead of once per row and slot; same scores."""
+        """``truth_file``: the dev truth file of config.py:262-276 ("<impression> [labels]" lines).  Without one it is written
+        (as the reference's Config does at start-up) to ``<dev_res_dir>/../ref/truth-<dataset>.txt`` from ``corpus.dev_labels``
+        (formats.build_corpus attaches them); a corpus without labels and no file is refused here, before any training.
+        ``cached_eval``: the dev pass encodes every news once (util.compute_scores_cached) instead of once per row and slot; same
+        scores.
+
+        Under torch.distributed (WORLD_SIZE in the environment) the process group is initialised and the device selected
+        FIRST, so that TrainStep's broadcast of rank 0's parameters really runs (DistributedDataParallel does that at
+        construction, trainer.py:256), and each rank steps on ``config.batch_size // world`` rows (trainer.py:254-255)."""
         self.model, self.config, self.corpus, self.run_index = model, config, corpus, run_index
-        self.epoch, self.batch_size = config.epoch, config.batch_size
+        self.rank, self.world = 0, 1
+        if 'WORLD_SIZE' in os.environ and int(os.environ['WORLD_SIZE']) > 1:
+            dev = next(model.parameters()).device
+            if dev.type == 'cuda':
+                local = int(os.environ.get('LOCAL_RANK', '0')) % max(1, torch.cuda.device_count())
+                torch.cuda.set_device(local)
+                if dev.index not in (None, local):
+                    raise ValueError('rank with LOCAL_RANK %d was handed a model on %s: move it to cuda:%d' % (local, dev, local))
+            self.rank, self.world = distributed.init()
+        if config.batch_size % self.world:
+            raise ValueError('config.batch_size (%d) must be divisible by the world size (%d) (config.py:205)' % (config.batch_size, self.world))
+        self.epoch = config.epoch
+        self.batch_size = config.batch_size // self.world                      # rows per rank and step (trainer.py:254)
+        self.eval_batch_size = config.batch_size                               # the dev pass of trainer.py:153 (rank 0 alone)
         self.dev_criterion, self.early_stopping_epoch = config.dev_criterion, config.early_stopping_epoch
         self.model_dir = _mkdir(os.path.join(config.model_dir, '#%d' % run_index))
         self.best_model_dir = _mkdir(os.path.join(config.best_model_dir, '#%d' % run_index))
         self.dev_res_dir = _mkdir(os.path.join(config.dev_res_dir, '#%d' % run_index))
         self.result_dir = _mkdir(config.result_dir)
+        if truth_file is None:
+            labels = getattr(corpus, 'dev_labels', None)
+            if labels is None:
+                raise ValueError('Trainer needs the dev truth file (config.py:262-276): pass truth_file=... or a corpus that carries '
+                                 'dev_labels (formats.build_corpus attaches them)')
+            truth_file = os.path.join(os.path.dirname(os.path.normpath(config.dev_res_dir)) or '.', 'ref', 'truth-%s.txt' % config.dataset)
+            if self.rank == 0:
+                formats.write_truth_file(truth_file, labels)
         self.truth_file = truth_file
+        if getattr(config, 'dropout_rate', 0.0) == 0.0 and self.rank == 0:
+            print('Trainer: config.dropout_rate is 0 -- the reference trains with 0.2 (config.py:78); pass dropout_rate=0.2 for its recipe')
         self.cached_eval = cached_eval and config.lifetime_type == 'user_topic'
         self.dc = device_corpus if device_corpus is not None else DeviceCorpus(corpus)
         self.dev = DeviceBehaviors.from_devtest(self.dc, corpus, 'dev')
         self.step = TrainStep(model, lr=config.lr, weight_decay=config.weight_decay, gradient_clip_norm=config.gradient_clip_norm)
         self.results = {k: [] for k in _CRITERIA}
         self.best_dev_epoch, self.best, self.epoch_not_increase = 0, -1.0, 0
-        self.rank, self.world = distributed.init() if 'WORLD_SIZE' in os.environ else (0, 1)
 
     def _remaining(self, batch):
         cfg = self.config                                                    # trainer.py:121-129
@@ -75,11 +103,16 @@ class Trainer:
         return total / max(1, seen)
 
     def evaluate(self, e):
+        """The dev pass of trainer.py:153: ``compute_scores(model, corpus, self.batch_size, 'dev', ...)`` -- config.batch_size rows per
+        forward.  The row count of a forward is the GraphSAGE source count, so it decides the scores, and it must
+        not exceed the H + config.batch_size node slots (the 2 x batch size of main.py:50 does, at the reference's own
+        batch_size = 64 / max_history_num = 50)."""
         out = os.path.join(self.dev_res_dir, '%s-%d.txt' % (self.model.model_name, e))
+        per = self.eval_batch_size
         if self.cached_eval:
-            return util.compute_scores_cached(self.model, self.dev, self.corpus.dev_indices, out, self.truth_file, 2 * self.batch_size)
+            return util.compute_scores_cached(self.model, self.dev, self.corpus.dev_indices, out, self.truth_file, per)
         rows = list(range(self.dev.num))
-        batches = (self.dev.assemble(rows[i:i + 2 * self.batch_size]) for i in range(0, len(rows), 2 * self.batch_size))
+        batches = (self.dev.assemble(rows[i:i + per]) for i in range(0, len(rows), per))
         return util.compute_scores(self.model, batches, self.corpus.dev_indices, out, self.truth_file)
 
     def train(self):
@@ -102,9 +135,9 @@ class Trainer:
                 else:
                     self.epoch_not_increase += 1
             if self.world > 1:                                               # every rank follows rank 0's stopping decision
-                flag = torch.tensor([self.epoch_not_increase], device=next(self.model.parameters()).device)
+                flag = torch.tensor([self.epoch_not_increase, self.best_dev_epoch], device=next(self.model.parameters()).device)
                 torch.distributed.broadcast(flag, 0)
-                self.epoch_not_increase = int(flag.item())
+                self.epoch_not_increase, self.best_dev_epoch = int(flag[0].item()), int(flag[1].item())
             if self.epoch_not_increase == self.early_stopping_epoch:
                 break
         if self.rank == 0:

@@ -265,7 +265,7 @@ class _TokenEncoder(torch.autograd.Function):
         x0 = None
         if p > 0:
             x0 = ops.embed_pe_dropout(flat, table, pe, S, p, seed, _SITE_EMB, _SITE_PE)
-            qkv = ops.linear(x0, w_in, b_in)
+            qkv = ops.linear(x0, w_in, b_in, n_alg=3 * E)
             ao = ops.token_attention_dropout(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, scale, p, seed, _SITE_ATTN,
                                              head_stride=hs)
             x1, rstd1 = ops.dropout_add_layernorm(ops.linear(ao, out_w, out_b), x0, n1_w, n1_b, eps1, p, seed, _SITE_DROP1)
@@ -274,7 +274,7 @@ class _TokenEncoder(torch.autograd.Function):
             y, rstd2 = ops.dropout_add_layernorm(ops.linear(h, l2_w, l2_b), x1, n2_w, n2_b, eps2, p, seed, _SITE_DROP2)
         else:
             pew = ops.linear(pe[:S], w_in, b_in)
-            qkv = ops.linear(table, w_in, None, a_ids=flat, res=pew, res_mod=S)
+            qkv = ops.linear(table, w_in, None, a_ids=flat, res=pew, res_mod=S, n_alg=3 * E)
             ao = ops.token_attention(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, scale, head_stride=hs)
             rstd1 = torch.empty(tok, dtype=torch.float32, device=dev)
             x1 = ops.linear(ao, out_w, out_b, res=table, res_ids=flat, res_pe=pe, res_period=S, ln=(n1_w, n1_b), ln_eps=eps1,
@@ -384,9 +384,8 @@ def crown_tail(enc, title_p, body_p, category, subCategory):
     return torch.cat([fused, enc.dropout(cat_e.clone()), enc.dropout(sub_e.clone())], dim=1)                    # :221-225
 
 
-def pooled_tokens(ne, title_text, content_text):
-    """The two token encoders of the CROWN content encoder (newsEncoders.py:311-321) on M flat news -> 2 x [M, 300]."""
-    enc = ne.base_news_encoder
+def pooled_tokens(enc, title_text, content_text):
+    """The two token encoders of the CROWN content encoder ``enc`` (newsEncoders.py:311-321) on M flat news -> 2 x [M, 300]."""
     table = enc.word_embedding.weight
     p_emb = enc.dropout.p if enc.training else 0.0                                                              # :311-312
     title_p = encode_tokens(title_text, table, enc.title_pos_encoder, enc.title_transformer, enc.head_num, p_emb)   # :311-317
@@ -439,7 +438,8 @@ def _topic(ne, category, subCategory):
 
 
 def candidate_aware(att, hist, hist_topic, cand_topic, mask):
-    """CandidateAware_ClickedNewsAttention.forward (layers.py:52-93); the value_proj branch is dead there."""
+    """CandidateAware_ClickedNewsAttention.forward (layers.py:52-93) -> (refined history [B, H, D], attn_weights_agg [B, H]); the
+    value_proj branch is dead there."""
     B, H, D = hist.shape
     N = cand_topic.shape[1]
     if mask is None:
@@ -448,11 +448,35 @@ def candidate_aware(att, hist, hist_topic, cand_topic, mask):
     agg = _CandAttnWeights.apply(linear(cand_topic, att.query_proj).reshape(B * N, D), linear(hist_topic, att.key_proj).reshape(B * H, D),
                                  mask, (B, N, H, D), att.num_heads, p, _draw_seed() if p > 0 else 0)           # :66-81
     if not att.use_residual_connection:
-        return agg.unsqueeze(-1) * hist
+        return agg.unsqueeze(-1) * hist, agg
     ln = att.layernorm
     flat = hist.reshape(B * H, D)
     y = _Linear.apply(flat, att.gate_proj.weight, None, None)                       # W_g x; the row scale agg commutes (:87)
-    return _GateLN.apply(y, flat, agg.reshape(-1), att.gate_proj.bias, ln.weight, ln.bias, ln.eps).view(B, H, D)
+    return _GateLN.apply(y, flat, agg.reshape(-1), att.gate_proj.bias, ln.weight, ln.bias, ln.eps).view(B, H, D), agg
+
+
+def wants_train_path(module, p=0.0):
+    """A sub-module called on its own (``news_encoder(...)``, ``user_encoder(...)``, ``candidate_aware_attn(...)``) takes the
+    differentiable path of this file when it is in training mode and either autograd is recording or a dropout is active;
+    otherwise the fused scoring kernels compute the same function."""
+    return module.training and (torch.is_grad_enabled() or p > 0)
+
+
+def _interest_inputs(ue, hist, cand, category, subCategory, user_category, user_subCategory, user_history_mask, n_src=None):
+    """userEncoders.py:103-105, :114-162: candidate-aware refinement, user nodes + GraphSAGE closed form, K / Q projections."""
+    B, H, D = hist.shape
+    ne = ue.news_encoder
+    if ue.use_candidate_aware_attn:
+        hist, _ = candidate_aware(ue.candidate_aware_attn, hist, _topic(ne, user_category, user_subCategory),
+                                  _topic(ne, category, subCategory), user_history_mask)
+    nodes = ue.dropout_(ue.user_node_embedding.unsqueeze(0).expand(B, -1, -1))                                    # :121
+    n_src = B if n_src is None else n_src
+    if n_src > H + nodes.shape[1]:
+        raise IndexError('rows per forward (%d) exceed the node slots H + config.batch_size (SURVEY Q7)' % n_src)
+    X = torch.cat([hist, nodes], dim=1)
+    conv = ue.graph_sage.convs[0]
+    g = linear(X[:, :n_src].mean(dim=1), conv.lin_l).unsqueeze(1) + linear(hist, conv.lin_r)                      # :151-157
+    return g, linear(g, ue.K), linear(cand, ue.Q)                                                                 # :161-162
 
 
 def user_logits(ue, weighting, hist, cand, category, subCategory, user_category, user_subCategory, user_history_mask,
@@ -461,24 +485,53 @@ def user_logits(ue, weighting, hist, cand, category, subCategory, user_category,
     product of model.py:181 / util.py:23-49 -> logits [B, N]."""
     B, H, D = hist.shape
     N = cand.shape[1]
-    ne = ue.news_encoder
-    if ue.use_candidate_aware_attn:
-        hist = candidate_aware(ue.candidate_aware_attn, hist, _topic(ne, user_category, user_subCategory),
-                               _topic(ne, category, subCategory), user_history_mask)
-    nodes = ue.dropout_(ue.user_node_embedding.unsqueeze(0).expand(B, -1, -1))                                    # :121
-    n_src = B if n_src is None else n_src
-    if n_src > H + nodes.shape[1]:
-        raise IndexError('rows per forward (%d) exceed the node slots H + config.batch_size (SURVEY Q7)' % n_src)
-    X = torch.cat([hist, nodes], dim=1)
-    conv = ue.graph_sage.convs[0]
-    g = linear(X[:, :n_src].mean(dim=1), conv.lin_l).unsqueeze(1) + linear(hist, conv.lin_r)                      # :151-157
-    kp = linear(g, ue.K)                                                                                         # :161
-    qp = linear(cand, ue.Q)                                                                                      # :162
+    g, kp, qp = _interest_inputs(ue, hist, cand, category, subCategory, user_category, user_subCategory, user_history_mask, n_src)
     A = kp.shape[-1]
     w = weighting
     return _InterestMatch.apply(kp.reshape(B * H, A), qp.reshape(B * N, A), g.reshape(B * H, D), cand.reshape(B * N, D),
                                 remaining_lifetime, (B, N, H, A, D), 1.0 / ue.attention_scalar, float(w.alpha), float(w.beta),
                                 bool(w.use_remaining_lifetime_weighting), bool(w.use_expired_penalty))               # :163-168
+
+
+def user_representation(ue, hist, cand, category, subCategory, user_category, user_subCategory, user_history_mask, n_src=None):
+    """``user_encoder(...)`` called on its own in training mode (userEncoders.py:101-175) -> user_representation [B, N, D] with
+    autograd.  The model's own forward never materialises this tensor (``user_logits`` fuses the attention with the dot product);
+    the last two steps (:163-168: softmax over the history, weighted sum) are two batched torch matmuls here."""
+    g, kp, qp = _interest_inputs(ue, hist, cand, category, subCategory, user_category, user_subCategory, user_history_mask, n_src)
+    a = torch.softmax(torch.bmm(qp, kp.transpose(1, 2)) / ue.attention_scalar, dim=2)                             # [B, N, H]
+    return torch.bmm(a, g)
+
+
+def lifetime_weighted_logits(w, user, news, remaining_lifetime):
+    """RemainingLifetimeWeighting.forward (util.py:23-49) as torch ops with autograd (the module called on its own)."""
+    base = (user * news).sum(dim=-1)
+    if not w.use_remaining_lifetime_weighting:
+        return base
+    r = remaining_lifetime.float()
+    weight = torch.sigmoid(w.alpha * r)
+    if w.use_expired_penalty:
+        weight = torch.where(r < 0, w.beta * weight, weight)
+    return base * weight
+
+
+def content_flat(enc, title_text, title_mask, content_text, category, subCategory):
+    """The base content encoder (CROWN: newsEncoders.py:302-373, MHSA: :582-595) on M flat news with autograd -> [M, dim]."""
+    from .newsEncoders import CROWN, MHSA
+    if getattr(enc, 'compute_dtype', 'fp32') != 'fp32':
+        raise NotImplementedError("compute_dtype %r is a scoring option (BASELINE config 3); the training step is fp32: build the "
+                                  "model with compute_dtype='fp32' to train" % enc.compute_dtype)
+    if isinstance(enc, CROWN):
+        title_p, body_p = pooled_tokens(enc, title_text, content_text)
+        return crown_tail(enc, title_p, body_p, category, subCategory)
+    if isinstance(enc, MHSA):
+        return mhsa_content(enc, title_text, title_mask, category, subCategory)
+    raise NotImplementedError('the training path covers the CROWN and MHSA content encoders')
+
+
+def news_flat(ne, title_text, title_mask, content_text, category, subCategory, freshness, lifetime):
+    """LIME.forward (newsEncoders.py:140-161) on M flat news with autograd -> [M, 400]."""
+    content = content_flat(ne.base_news_encoder, title_text, title_mask, content_text, category, subCategory)
+    return lime_tail(ne, content, freshness, lifetime)
 
 
 def forward_train(model, user_category, user_subCategory, user_title_text, user_title_mask, user_content_text, user_freshness,
@@ -489,8 +542,7 @@ def forward_train(model, user_category, user_subCategory, user_title_text, user_
     and project per news, then the CROWN user encoder and the lifetime-weighted dot product: 3 % of the FLOPs in some 300
     short launches forward + backward (4 ms of kernel time at config 2b -- short kernels, not idle gaps: capturing them into
     HIP graphs with torch.cuda.make_graphed_callables was measured and changed nothing)."""
-    from .newsEncoders import CROWN, MHSA
-    ne, enc = model.news_encoder, model.news_encoder.base_news_encoder
+    ne = model.news_encoder
     B, N = news_category.shape
     H = user_category.shape[1]
     i32 = lambda t: t if t.dtype == torch.int32 else t.to(torch.int32)
@@ -501,18 +553,9 @@ def forward_train(model, user_category, user_subCategory, user_title_text, user_
     if news_user_topic_lifetime.dim() == 1:
         news_user_topic_lifetime = news_user_topic_lifetime.unsqueeze(1).expand(B, N)
     category, subCategory = i32(flat1(news_category, user_category)), i32(flat1(news_subCategory, user_subCategory))
-    if getattr(enc, 'compute_dtype', 'fp32') != 'fp32':
-        raise NotImplementedError("compute_dtype %r is a scoring option (BASELINE config 3); the training step is fp32: build the "
-                                  "model with compute_dtype='fp32' to train" % enc.compute_dtype)
-    if isinstance(enc, CROWN):
-        title_p, body_p = pooled_tokens(ne, i32(flat2(news_title_text, user_title_text)), i32(flat2(news_content_text, user_content_text)))
-        content = crown_tail(enc, title_p, body_p, category, subCategory)
-    elif isinstance(enc, MHSA):
-        content = mhsa_content(enc, i32(flat2(news_title_text, user_title_text)), flat2(news_title_mask, user_title_mask), category,
-                               subCategory)
-    else:
-        raise NotImplementedError('the training path covers the CROWN and MHSA content encoders')
-    rep = lime_tail(ne, content, flat1(news_freshness.float(), user_freshness.float()).contiguous(),
+    rep = news_flat(ne, i32(flat2(news_title_text, user_title_text)), flat2(news_title_mask, user_title_mask),
+                    i32(flat2(news_content_text, user_content_text)), category, subCategory,
+                    flat1(news_freshness.float(), user_freshness.float()).contiguous(),
                     flat1(news_user_topic_lifetime.float(), user_user_topic_lifetime.float()).contiguous())
     cand = rep[:B * N].view(B, N, -1)
     hist = rep[B * N:].view(B, H, -1)
@@ -554,6 +597,10 @@ class TrainStep:
 
     Parameters are re-pointed into one flat fp32 buffer (``p.data`` becomes a view, values preserved) and their ``.grad``
     into a second one, so zeroing, the norm, the all-reduce and the Adam update are one launch each.
+
+    One difference from torch's Adam, visible only with ``weight_decay > 0`` (the reference trains with 0, config.py:47): every
+    bucket parameter is decayed every step, including one whose gradient happened to be all zero in that step; torch skips a
+    parameter whose ``.grad`` is None (the never-used parameters of SURVEY Q20 are outside the bucket and skipped here too).
     """
 
     def __init__(self, model, lr=1e-4, weight_decay=0.0, gradient_clip_norm=4.0, betas=(0.9, 0.999), eps=1e-8,

@@ -113,7 +113,8 @@ class CROWN(UserEncoder):
         if not self.use_candidate_aware_attn:
             return None
         if self.training and self.candidate_aware_attn.dropout.p > 0:
-            raise NotImplementedError('training-mode dropout (p=0.2, layers.py:36,74) is not part of the scoring path yet')
+            raise NotImplementedError('attention_weights() is the scoring kernel: in training mode the layer\'s p = 0.2 dropout '
+                                      '(layers.py:36,74) runs on the differentiable path (user_encoder(...) / Model.forward)')
         cand_topic = self._topic(category, subCategory)
         hist_topic = self._topic(user_category, user_subCategory)
         return self.candidate_aware_attn.attention_weights(hist_topic, cand_topic, user_history_mask)
@@ -127,8 +128,9 @@ class CROWN(UserEncoder):
         ``agg``: precomputed ``attention_weights(...)``.  ``n_src``: how many node slots the GraphSAGE mean runs over
         (Q7: the reference uses the number of rows of the forward; default B).
         """
-        if self.training and self.dropout_rate > 0:
-            raise NotImplementedError('training-mode dropout on user_node_embedding (userEncoders.py:121) is not implemented')
+        if self.training and (self.dropout_rate > 0 or (self.use_candidate_aware_attn and self.candidate_aware_attn.dropout.p > 0)):
+            raise NotImplementedError('match() is the fused scoring kernel chain: with training-mode dropouts active (userEncoders.py:121, '
+                                      'layers.py:74) call user_encoder(...) or Model.forward, which take the differentiable path')
         B, H, D = history_embedding.shape
         N = candidate_news_representation.shape[1]
         cand = candidate_news_representation.contiguous()
@@ -157,6 +159,14 @@ class CROWN(UserEncoder):
         history_embedding = self.news_encoder(user_title_text, user_title_mask, user_title_entity, user_content_text,
                                               user_content_mask, user_content_entity, user_category, user_subCategory,
                                               user_embedding, user_freshness, user_user_topic_lifetime)        # :110-112
+        from . import training
+        p_any = max(self.dropout_rate, self.candidate_aware_attn.dropout.p if self.use_candidate_aware_attn else 0.0)
+        if training.wants_train_path(self, p_any):
+            # training mode (trainer.py:87): the differentiable path; the candidate representation may carry a graph
+            i32 = lambda t: (t if t.dtype == torch.int32 else t.to(torch.int32)).contiguous()
+            return training.user_representation(self, history_embedding, candidate_news_representation.float(), i32(category),
+                                                i32(subCategory), i32(user_category), i32(user_subCategory),
+                                                user_history_mask.contiguous())
         user, _ = self.match(history_embedding, category, subCategory, user_category, user_subCategory, user_history_mask,
                              candidate_news_representation)
         return user

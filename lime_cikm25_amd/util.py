@@ -19,6 +19,9 @@ class RemainingLifetimeWeighting(nn.Module):
         self.use_remaining_lifetime_weighting = config.use_remaining_lifetime_weighting
 
     def forward(self, user_embedding, news_embedding, remaining_lifetime):
+        if torch.is_grad_enabled() and (user_embedding.requires_grad or news_embedding.requires_grad):
+            from . import training
+            return training.lifetime_weighted_logits(self, user_embedding, news_embedding, remaining_lifetime)
         return ops.lifetime_score(user_embedding, news_embedding, remaining_lifetime, self.alpha, self.beta,
                                   self.use_remaining_lifetime_weighting, self.use_expired_penalty)
 
@@ -86,12 +89,17 @@ def compute_scores_cached(model, behaviors, indices, result_file, truth_file=Non
     """The same dev / test pass from a per-news content cache (Model.build_news_cache + Model.score_behaviors): every news goes
     through the token encoders ONCE instead of once per (row, slot) -- the reference re-encodes all 51 news of every row
     (util.py:86-111).  ``behaviors``: a dev / test ``DeviceBehaviors``.  Rows are scored in chunks of ``rows_per_forward`` (default:
-    twice the training batch size, as main.py:50 calls compute_scores) with the chunk's row count as the GraphSAGE source count,
-    so the scores are those of ``compute_scores`` over the same batches; lifetime_type 'user_topic' (config.py:62)."""
+    config.batch_size, as trainer.py:153 calls compute_scores; main.py:50,67 pass twice that, which only fits while
+    2 x batch_size <= H + config.batch_size node slots) with the chunk's row count as the GraphSAGE source count, so the scores
+    are those of ``compute_scores`` over the same batches; lifetime_type 'user_topic' (config.py:62)."""
     config = model.config
     if config.lifetime_type != 'user_topic':
         raise NotImplementedError("the cached pass derives the remaining lifetime as lifetime_type 'user_topic' does")
-    per = rows_per_forward or 2 * config.batch_size
+    per = rows_per_forward or config.batch_size
+    slots = behaviors.hist_index.shape[1] + model.user_encoder.user_node_embedding.shape[0]
+    if per > slots:
+        raise ValueError('rows_per_forward = %d exceeds the H + config.batch_size = %d GraphSAGE node slots (SURVEY Q7): the '
+                         'reference raises an index error there' % (per, slots))
     was_training = model.training
     model.eval()
     cache = model.build_news_cache(behaviors.corpus)

@@ -25,10 +25,10 @@ def synth_state_dict(keys_and_shapes, seed=golden_cases.WEIGHT_SEED):
 
 
 def rel_err(a, b, floor=None):
-    """max |a-b| / (|b| + floor).  ``floor`` defaults to the mean magnitude of the non-zero reference
-    entries: elements at the tensor's typical scale or above are judged relatively, elements far
-    below it (and the exact zeros the saturated lifetime weight produces, SURVEY.md section 7
-    'Exact zeros and ties') against that absolute floor."""
+    """max |a-b| / max(|b|, floor).  ``floor`` defaults to the mean magnitude of the non-zero reference
+    entries: an element at or above the tensor's typical scale is judged by its TRUE relative error, an
+    element below it (and the exact zeros the saturated lifetime weight produces, SURVEY.md section 7
+    'Exact zeros and ties') by its absolute error against that floor."""
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     if a.size == 0:
@@ -36,4 +36,4 @@ def rel_err(a, b, floor=None):
     if floor is None:
         nz = np.abs(b[b != 0])
         floor = float(nz.mean()) if nz.size else 1.0
-    return float(np.max(np.abs(a - b) / (np.abs(b) + floor)))
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))

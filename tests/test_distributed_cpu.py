@@ -59,3 +59,34 @@ def test_two_gloo_ranks_score_disjoint_shards(tmp_path):
     assert torch.equal(r0['full'], r1['full'])                               # both ranks hold the gathered scores
     assert torch.equal(r0['full'], torch.cat([r0['local'], r1['local']]))    # in row order
     assert r0['t'] == r1['t'] == 2.0                                         # MAX over ranks
+
+
+def _bucket_worker(rank, world, port, out_dir):
+    """Two ranks build the model from DIFFERENT seeds; TrainStep's constructor must leave both with rank 0's parameters
+    (what DistributedDataParallel does at construction, trainer.py:256)."""
+    from lime_cikm25_amd import Model, make_config
+    from lime_cikm25_amd.training import TrainStep
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    D.init(backend='gloo')
+    cfg = make_config(max_history_num=4, max_title_length=8, max_abstract_length=8, batch_size=4, vocabulary_size=50)
+    torch.manual_seed(100 + rank)
+    model = Model(cfg)
+    model.initialize()
+    before = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+    ts = TrainStep(model)
+    dist.barrier()
+    named = dict(model.named_parameters())
+    torch.save({'before': before, 'flat': ts.flat.clone(), 'probe': named['news_encoder.project.weight'].detach().clone()},
+               os.path.join(out_dir, 'b%d.pt' % rank))
+    dist.destroy_process_group()
+
+
+def test_trainstep_starts_every_rank_from_rank0_parameters(tmp_path):
+    port = _free_port()
+    mp.spawn(_bucket_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / 'b0.pt', weights_only=True)
+    r1 = torch.load(tmp_path / 'b1.pt', weights_only=True)
+    assert not torch.equal(r0['before'], r1['before'])                       # the local initialisations differed
+    assert torch.equal(r0['flat'], r1['flat'])                               # ... the buckets do not
+    assert torch.equal(r0['probe'], r1['probe'])                             # and the parameters are views of them

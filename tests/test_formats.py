@@ -179,3 +179,20 @@ def test_build_corpus_from_the_golden_files_feeds_the_batch_assembly():
     cand = [r[3] for r in g['dev_behaviors']]
     assert np.asarray(batch[17]).tolist() == [g['news_title_text'][i] for i in cand]          # news_title_text of the candidates
     assert np.allclose(np.asarray(batch[24]), [r[6] for r in g['dev_behaviors']])              # news_user_topic_lifetime
+
+
+def test_truth_file_is_the_reference_preprocessing_format(tmp_path):
+    """config.py:262-276: '<impression> [l1,l2,...]' lines, 1-based, no spaces, no trailing newline; build_corpus attaches the
+    labels the Trainer writes it from."""
+    lines = _golden()['lines']['dev_behaviors']
+    labels = formats.truth_labels(lines)
+    path = formats.write_truth_file(str(tmp_path / 'dev' / 'ref' / 'truth-mind.txt'), labels)
+    text = open(path).read()
+    want = []
+    for i, line in enumerate(lines):                                        # the reference's own loop body, restated
+        impressions = line.split('\t')[4]
+        lab = [int(imp[-1]) for imp in impressions.strip().split(' ')]
+        want.append(('' if i == 0 else '\n') + str(i + 1) + ' ' + str(lab).replace(' ', ''))
+    assert text == ''.join(want) and not text.endswith('\n')
+    from lime_cikm25_amd.evaluate import parse_line
+    assert [parse_line(l)[1] for l in text.split('\n')] == labels

@@ -193,8 +193,9 @@ def test_auc_matches_oracle(full_size):
 def test_bf16_path_against_oracle(full_size):
     """BASELINE config 3's arithmetic (bf16 MFMA operands / activations in the token encoders, fp32 accumulate, softmax,
     LayerNorm) on the config-2 batch, against the fp32 oracle.  bf16 keeps 8 mantissa bits (2^-9 = 2e-3 per rounding);
-    through one encoder layer + pooling the logits land ~1e-2 from the fp32 ones: tolerance 5e-2 relative to the mean
-    logit magnitude, and the ranking-quality gate of the north star (|dAUC| <= 0.001 is an fp32 statement; here 0.02)."""
+    through one encoder layer + pooling the logits land ~4e-3 (observed) from the fp32 ones: tolerance 1e-2 relative to the
+    mean logit magnitude, and |dAUC| <= 0.01 (the north star's 0.001 is an fp32 statement).  The configs[2] batch size (256)
+    is covered by tests/test_fullsize_gpu.py."""
     from sklearn.metrics import roc_auc_score
     cfg, model32, sd, batch, logits32 = full_size
     cfg16 = make_config(vocabulary_size=50000, compute_dtype='bf16')
@@ -206,14 +207,14 @@ def test_bf16_path_against_oracle(full_size):
     scale = float(want.abs().mean())
     err = float((got - want).abs().max()) / scale
     print('bf16 path: max |dlogit| / mean |logit| = %.3e (fp32 path: %.3e)' % (err, float((logits32 - want).abs().max()) / scale))
-    assert torch.isfinite(got).all() and err < 5e-2
+    assert torch.isfinite(got).all() and err < 1e-2
     assert torch.equal(run(model, batch, False), got)                       # still bitwise reproducible
     labels = np.zeros_like(want.numpy())
     labels[:, 0] = 1
     aucs = []
     for s_ in (got.numpy(), want.numpy()):
         aucs.append(float(np.mean([roc_auc_score(labels[r], s_[r]) for r in range(s_.shape[0])])))
-    assert abs(aucs[0] - aucs[1]) <= 0.02
+    assert abs(aucs[0] - aucs[1]) <= 0.01
 
 
 def test_score_impressions_equals_eval_forward_on_expanded_rows():

@@ -89,3 +89,25 @@ def test_eval_path_equals_single_candidate_training_shape():
     b2 = type(batch)((k, (v.unsqueeze(1) if i >= 15 else v)) for i, (k, v) in enumerate(batch.items()))
     b = O.model_forward(sd, cfg, b2, eval_shape=False)
     assert torch.equal(a, b)
+
+
+def test_encode_once_composition_equals_model_forward_on_expanded_rows():
+    """tests/oracle_impressions.score_impressions (every news encoded once, user side per (impression, candidate) row) is the
+    oracle's eval forward on the B * K expanded rows -- the reference's layout (util.py:86-111) -- when both use the same
+    GraphSAGE source count."""
+    import oracle_impressions
+    from lime_cikm25_amd import make_config, synth
+    cfg = make_config(max_history_num=6, max_title_length=8, max_abstract_length=16, batch_size=32, vocabulary_size=500)
+    from lime_cikm25_amd import Model
+    model = Model(cfg)
+    model.initialize()
+    synth.fill_state_dict(model, 9)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    B, K = 4, 5
+    batch = synth.make_batch(cfg, B, K, seed=10)
+    got = oracle_impressions.score_impressions(sd, cfg, batch, n_src=B * K, rows_per_pass=2 * K)
+    exp = type(batch)()
+    for k, v in batch.items():
+        exp[k] = v.reshape((B * K,) + tuple(v.shape[2:])) if (k.startswith('news_') or k == 'remaining_lifetime') else v.repeat_interleave(K, dim=0)
+    want = O.model_forward(sd, cfg, exp, eval_shape=True).view(B, K)                 # n_src = rows = B * K
+    assert rel_err(got.numpy(), want.numpy()) < 1e-5
