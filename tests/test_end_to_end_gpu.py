@@ -96,3 +96,43 @@ def test_trainer_loop_selects_and_saves_the_best_epoch(tmp_path):
     fresh = Model(cfg).cuda()
     payload = load_checkpoint(best_file, fresh)                      # the reference's main.py:45 reads the same key
     assert model.model_name in payload
+
+
+def test_trainer_dev_pass_fits_the_node_slots_when_batch_exceeds_history(tmp_path):
+    """config.batch_size (8) > max_history_num (4), as at the reference's own settings (64 > 50): the dev pass scores
+    config.batch_size rows per forward (trainer.py:153) -- twice that would exceed the H + batch_size GraphSAGE node slots
+     -- and the cached and the re-encoding dev pass write the same rank file.  No truth file is passed: the Trainer
+    writes it from the corpus's dev labels, in the reference's format (config.py:262-276)."""
+    from lime_cikm25_amd.trainer import Trainer
+    g = json.load(open(os.path.join(GOLDEN_DIR, 'formats.json')))
+    L = g['lines']
+    d = str(tmp_path)
+    cfg = make_config(max_history_num=g['max_history_num'], max_title_length=g['max_title_length'],
+                      max_abstract_length=g['max_abstract_length'], vocabulary_size=len(g['word_dict']), negative_sample_num=2,
+                      category_num=len(g['category_dict']) + 1, subCategory_num=len(g['subCategory_dict']) + 1,
+                      user_num=len(g['user_ID_dict']), batch_size=8, epoch=1, lr=1e-3, dataset='adressa',
+                      model_dir=d + '/models', best_model_dir=d + '/best', dev_res_dir=d + '/dev/res', result_dir=d + '/results')
+    assert cfg.batch_size > cfg.max_history_num
+    corpus = formats.build_corpus(cfg, [L['train_news'], L['dev_news'], L['test_news']],
+                                  [L['train_behaviors'], L['dev_behaviors'], L['test_behaviors']], g['news_ID_dict'],
+                                  g['user_ID_dict'], g['category_dict'], g['subCategory_dict'], g['word_dict'], dataset='adressa')
+    assert len(corpus.dev_indices) > 2 * cfg.batch_size - 1 > cfg.max_history_num + cfg.batch_size        # 2x would not fit
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = Model(cfg)
+    model.initialize()
+    trainer = Trainer(model.cuda(), cfg, corpus, run_index=2)
+    truth = os.path.join(d, 'dev', 'ref', 'truth-adressa.txt')
+    assert trainer.truth_file == truth and os.path.exists(truth)
+    assert trainer.train() == 1
+    cached = trainer.evaluate(7)
+    trainer.cached_eval = False
+    plain = trainer.evaluate(8)
+    name = model.model_name
+    assert open(os.path.join(trainer.dev_res_dir, '%s-7.txt' % name)).read() == open(os.path.join(trainer.dev_res_dir, '%s-8.txt' % name)).read()
+    assert cached == plain and all(0.0 <= v <= 1.0 for v in cached)
+    with pytest.raises(ValueError):
+        util.compute_scores_cached(model, trainer.dev, corpus.dev_indices, os.path.join(d, 'x.txt'), truth, rows_per_forward=2 * cfg.batch_size)
+    with pytest.raises(ValueError):                                     # no labels, no file: refused before any training
+        del corpus.dev_labels
+        Trainer(model, cfg, corpus, run_index=3)
