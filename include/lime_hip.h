@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LIME_ABI_VERSION 3
+#define LIME_ABI_VERSION 4
 
 typedef enum {
     LIME_OK = 0,
@@ -91,6 +91,12 @@ typedef struct {
     int32_t res_mod;      /* > 0 (res_ids == NULL): residual row = (r / res_div) % res_mod -- a periodic table */
     int32_t pool32;       /* 1: (LayerNorm epilogue) c is [M / 32, N]: row r = mean of result rows 32 r .. 32 r + 31 */
     float* ln_rstd;       /* optional [M]: 1 / sqrt(var + eps) of every row's LayerNorm, kept for lime_layernorm_bwd_f32 */
+    const int32_t* m_dev; /* optional DEVICE int: the launch computes min(*m_dev, M) rows -- M is then the capacity the buffers were
+                             sized for.  Lets a launch captured in a HIP graph follow a per-batch row count (the live rows that
+                             lime_compact_sequences counted) without a host round trip.  Big-M kernel only (M >= 4096, 16-byte operands). */
+    const int32_t* c_ids; /* optional int32 [M]: the A rows are a compacted row list -- result row r is stored at c[c_ids[r] * ldc] and
+                             the periodic residual is res[(c_ids[r] % res_mod) * ldr].  Needs res with res_mod > 0, no LayerNorm, act none
+                             (the in_proj GEMM over the non-padding tokens of a batch). */
 } lime_linear_args;
 
 int lime_linear_f32(const lime_linear_args* args, void* stream);
@@ -161,6 +167,32 @@ int lime_embed_pe_f32(const int32_t* ids, const float* table, int64_t ld_table, 
 int lime_token_attention_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const uint8_t* key_mask,
                              float* out, int64_t ldo, int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim,
                              int32_t head_stride, float scale, void* stream);
+
+/*
+ * lime_token_attention_rows_f32: lime_token_attention_f32 (unmasked, heads padded to 32 columns) over COMPACTED sequences: the
+ * q / k / v row of token (seq * S + t) is row_map[seq * S + t] -- a live token's own row, or one of the S rows that all padding
+ * tokens at position t share (lime_compact_sequences) -- and min(*n_seq_dev, n_seq) sequences are computed when n_seq_dev is
+ * given (a device int: the launch sits in a HIP graph, the count changes per batch).  out rows stay dense: (seq * S + t).
+ * S in {32, 64, 96, 128, 256, 512}; q / k / v 16-byte aligned, ld_qkv % 4 == 0.
+ */
+int lime_token_attention_rows_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const int32_t* row_map,
+                                  const int32_t* n_seq_dev, float* out, int64_t ldo, int32_t n_seq, int32_t S, int32_t n_head,
+                                  int32_t head_dim, float scale, void* stream);
+
+/*
+ * lime_compact_sequences: index lists for encoding only what differs in a batch of token sequences (ids int32 [n_seq, S], 0 = the
+ * padding word).  The reference encodes every slot (newsEncoders.py:311-321), including history slots padded with the all-zero
+ * <PAD> news (corpus.py:476-477) and the padding behind every text; those are exact repetitions:
+ *   seq_inv  [n_seq]          compact index of every sequence; all-padding sequences share ONE representative (index n_live)
+ *   ids_c    [(n_seq + 1) S]  ids in compact order (representative: zeros)
+ *   row_map  [(n_seq + 1) S]  compact token row -> its q/k/v row: itself when live, pad_base + t for a padding token
+ *   tok_ids / tok_rows [(n_seq + 1) S]  ids and compact rows of the live tokens, in (compact sequence, position) order
+ *   counts   [4]              n_live + 1, (n_live + 1) S, live tokens, n_live   (device memory: lime_linear_args.m_dev, n_seq_dev)
+ * Ordered and deterministic (no atomics).  work: lime_compact_sequences_workspace(n_seq) int32 words.
+ */
+int lime_compact_sequences(const int32_t* ids, int32_t n_seq, int32_t S, int32_t pad_base, int32_t* seq_inv, int32_t* ids_c,
+                           int32_t* row_map, int32_t* tok_ids, int32_t* tok_rows, int32_t* counts, int32_t* work, void* stream);
+int64_t lime_compact_sequences_workspace(int32_t n_seq);
 
 /*
  * lime_token_attention_bf16: the unmasked encoder-layer attention on bf16 storage (config 3): q / k / v bf16 with every

@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_ui
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblime_hip.so')
 
-ABI_VERSION = 3          # LIME_ABI_VERSION of include/lime_hip.h this binding was written against
+ABI_VERSION = 4          # LIME_ABI_VERSION of include/lime_hip.h this binding was written against
 LIME_ACT = {None: 0, 'none': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3}
 
 
@@ -29,6 +29,7 @@ class LinearArgs(Structure):
         ('act', c_int32),
         ('res_mod', c_int32), ('pool32', c_int32),
         ('ln_rstd', c_void_p),
+        ('m_dev', c_void_p), ('c_ids', c_void_p),
     ]
 
 
@@ -75,6 +76,11 @@ SIGNATURES = {
                                     c_int32, c_void_p]),
     'lime_token_attention_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
                                            c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    'lime_token_attention_rows_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                                                c_int32, c_int32, c_int32, c_float, c_void_p]),
+    'lime_compact_sequences': (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p]),
+    'lime_compact_sequences_workspace': (c_int64, [c_int32]),
     'lime_pad_heads_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'lime_mean_pool_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     'lime_bucketize_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),

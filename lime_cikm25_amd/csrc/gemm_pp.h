@@ -13,6 +13,8 @@ struct PPParams {
     float* c; long ldc; int M, N, K;
     int ln_count;        // LayerNorm divides by this many columns (N unless the caller zero-padded N)
     int n_row_blocks, n_col_blocks;
+    const int* m_dev;    // optional device-side row count: the kernel runs min(*m_dev, M) rows (M is the capacity)
+    const int* c_ids;    // optional (CID instantiations): output row of A row r is c_ids[r]; a periodic residual is indexed by it
 #ifdef LIME_STAMPS
     unsigned long long* stamps;
 #endif

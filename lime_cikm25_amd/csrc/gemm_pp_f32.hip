@@ -132,7 +132,11 @@ __device__ __forceinline__ float row16_sum(float v) {
 // POOL: (LayerNorm epilogue) instead of the [M, N] result, row r of C is the mean of result rows 32 r .. 32 r + 31 -- a
 //      wave's 32 output rows -- so the mean pooling over the tokens of a news (newsEncoders.py:317,321) never sees the
 //      activations in HBM: S = 32 sequences are finished here, longer ones by a mean over their S / 32 block rows.
-template <int NTL, bool LN, bool RELU, int RES, bool BF, bool POOL = false, bool RSTD = false>
+// CID: the A rows are a COMPACTED list (the live tokens of the batch): result row r is stored at row c_ids[r] of C, and a
+//      periodic residual (RES == 1 with res_mod) is indexed by c_ids[r] % res_mod -- in_proj over the non-padding tokens only.
+// p.m_dev (any instantiation): the row count is read from device memory (min(*m_dev, M)), so a launch captured into a HIP
+//      graph follows the batch's live-row count without a host round trip.
+template <int NTL, bool LN, bool RELU, int RES, bool BF, bool POOL = false, bool RSTD = false, bool CID = false>
 __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
     constexpr int ES = BF ? 2 : 4;                 // operand element size
     constexpr int EPS = 16 / ES;                   // elements per 16-byte segment
@@ -149,7 +153,13 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fi = lane & 15, kg = lane >> 4;          // MFMA 16x16x4: lane (i, kg) supplies row i, k slot kg
-    const int ntiles = p.n_row_blocks * p.n_col_blocks;
+    int M = p.M, n_row_blocks = p.n_row_blocks;
+    if (p.m_dev) {                                     // device-side row count (uniform: one scalar load)
+        const int m = __builtin_amdgcn_readfirstlane(*p.m_dev);
+        M = m < M ? (m > 0 ? m : 0) : M;
+        n_row_blocks = (M + BM - 1) / BM;
+    }
+    const int ntiles = n_row_blocks * p.n_col_blocks;
     // Tile -> workgroup assignment.  Workgroups go to the 8 XCDs round-robin by blockIdx, and (measured,
     // tools/probes/wg_map_probe) blockIdx b and b + 256 of a 512-workgroup launch share a CU.  Each XCD walks ONE contiguous
     // range of tiles (neighbouring row panels share its L2); inside the range tiles are dealt round-robin to the XCD's
@@ -175,6 +185,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
     unsigned a_voff[2], w_voff[NWI];
     int aid_next[2];                                   // gathered row ids of the NEXT tile (loaded a tile ahead)
     int rid_next[2] = {0, 0};                          // RES == 2: residual row ids of this lane's two output rows, next tile
+    int cid_next[2] = {0, 0};                          // CID: output rows of this lane's two result rows, next tile
     __amdgpu_buffer_rsrc_t rs_a = make_rsrc(p.a);
 
     auto tile_rc = [&](int tile, int& row0, int& col0) {
@@ -190,14 +201,22 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int row = row0 + 16 * (wave * 2 + j) + srow;
-            aid_next[j] = buf_load_i32(rs_aids, (gather_a && live && row < p.M) ? (unsigned)row * 4u : OOB);
+            aid_next[j] = buf_load_i32(rs_aids, (gather_a && live && row < M) ? (unsigned)row * 4u : OOB);
         }
         if constexpr (RES == 2) {
             const __amdgpu_buffer_rsrc_t rs_rids = make_rsrc(p.res_ids ? (const void*)p.res_ids : (const void*)p.w);
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const int row = row0 + 32 * wave + 16 * tt + fi;
-                rid_next[tt] = buf_load_i32(rs_rids, (live && row < p.M) ? (unsigned)row * 4u : OOB);
+                rid_next[tt] = buf_load_i32(rs_rids, (live && row < M) ? (unsigned)row * 4u : OOB);
+            }
+        }
+        if constexpr (CID) {
+            const __amdgpu_buffer_rsrc_t rs_cids = make_rsrc(p.c_ids);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int row = row0 + 32 * wave + 16 * tt + fi;
+                cid_next[tt] = buf_load_i32(rs_cids, (live && row < M) ? (unsigned)row * 4u : OOB);
             }
         }
     };
@@ -210,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
         for (int j = 0; j < 2; ++j) {
             const int rl = 16 * (wave * 2 + j) + srow;
             const unsigned rowsel = gather_a ? (unsigned)aid_next[j] : (unsigned)rl;
-            a_voff[j] = (row0 + rl < p.M) ? rowsel * (unsigned)lda4 + (unsigned)lseg * 16u : OOB;
+            a_voff[j] = (row0 + rl < M) ? rowsel * (unsigned)lda4 + (unsigned)lseg * 16u : OOB;
         }
 #pragma unroll
         for (int j = 0; j < NWI; ++j) {
@@ -303,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
 
     // C layout of D^T (16x16 tile): lane (i, kg) holds output row (token) 16 tt + i of the wave's 32, columns
     // 16 t + 4 kg + r in acc[tt][t][r].
-    auto acc_init = [&](int tile, int par, const int* rid) {
+    auto acc_init = [&](int tile, int par, const int* rid, const int* cid) {
         int row0, col0;
         tile_rc(tile, row0, col0);
         float* const bs = Bs + (par ? BN : 0);
@@ -328,9 +347,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
             for (int tt = 0; tt < 2; ++tt) {
                 const int rl = 32 * wave + 16 * tt + fi, row = row0 + rl;
                 unsigned ro = OOB, po = OOB;
-                if (row < p.M) {
+                if (row < M) {
                     if constexpr (RES == 1) {
-                        ro = (p.res_mod > 0 ? (unsigned)(row % p.res_mod) : (unsigned)rl) * (unsigned)ldr4;
+                        if constexpr (CID) ro = (unsigned)(cid[tt] % p.res_mod) * (unsigned)ldr4;      // dispatcher: res_mod > 0
+                        else ro = (p.res_mod > 0 ? (unsigned)(row % p.res_mod) : (unsigned)rl) * (unsigned)ldr4;
                     } else if constexpr (RES == 3) {
                         ro = (unsigned)rl * (unsigned)ldr4;
                     } else {
@@ -362,11 +382,11 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
         }
     };
 
-    auto epilogue = [&](int tile, int par) {
+    auto epilogue = [&](int tile, int par, const int* cid) {
         int row0, col0;
         tile_rc(tile, row0, col0);
         const float* const bs = Bs + (par ? BN : 0) + 4 * kg;
-        const __amdgpu_buffer_rsrc_t rs_c = make_rsrc((char*)p.c + ((long)row0 * p.ldc + col0) * ES);
+        const __amdgpu_buffer_rsrc_t rs_c = make_rsrc((char*)p.c + ((CID ? 0L : (long)row0 * p.ldc) + col0) * ES);
         float sum[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < NT16; ++t) {
@@ -402,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int rl = 32 * wave + 16 * tt + fi;
-            cof[tt] = (row0 + rl < p.M) ? (unsigned)rl * (unsigned)ldc4 + (unsigned)kg * (4u * ES) : OOB;
+            cof[tt] = (row0 + rl < M) ? (unsigned)(CID ? cid[tt] : rl) * (unsigned)ldc4 + (unsigned)kg * (4u * ES) : OOB;
         }
         if constexpr (RSTD) {                          // the training forward keeps 1 / sqrt(var + eps) for lime_layernorm_bwd_f32
             const __amdgpu_buffer_rsrc_t rs_r = make_rsrc(p.ln_rstd + row0);
@@ -410,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
             for (int tt = 0; tt < 2; ++tt) {
                 const int rl = 32 * wave + 16 * tt + fi;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rstd[tt]), rs_r,
-                                                      (kg == 0 && row0 + rl < p.M) ? (unsigned)rl * 4u : OOB, 0, 0);
+                                                      (kg == 0 && row0 + rl < M) ? (unsigned)rl * 4u : OOB, 0, 0);
             }
         }
         const float* const gs = Gs + 4 * kg;
@@ -419,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
             // block row (row0 + 32 wave) / 32 of C: the column means over this wave's 32 output rows (all valid or all beyond M)
             const int rl0 = 32 * wave;
             const __amdgpu_buffer_rsrc_t rs_p = make_rsrc((char*)p.c + ((long)((row0 + rl0) >> 5) * p.ldc + col0) * 4);
-            const bool rows_ok = row0 + rl0 < p.M;
+            const bool rows_ok = row0 + rl0 < M;
 #pragma unroll
             for (int t = 0; t < NT16; ++t) {
                 const f32x4 ga = *reinterpret_cast<const f32x4*>(gs + 16 * t);
@@ -466,6 +486,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
     if (tile < 0) return;
     prefetch_ids(tile);
     int rid_cur[2] = {rid_next[0], rid_next[1]};
+    int cid_cur[2] = {cid_next[0], cid_next[1]};
     loader_set_tile(tile);
     prefetch_ids(tile_at(ti + nw_x));
     issue_a(0, 0);
@@ -480,7 +501,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
 #endif
     for (; tile >= 0; ti += nw_x, tile = tile_at(ti), par ^= 1) {
         const bool more = ti + nw_x < tcount;
-        acc_init(tile, par, rid_cur);
+        const int cid_epi[2] = {cid_cur[0], cid_cur[1]};       // the loader moves on before this tile's epilogue
+        acc_init(tile, par, rid_cur, cid_cur);
         PSTAMP(0)                                     // 0: accumulator init (residual loads issued)
         for (int c = 0; c + 1 < nchunk; ++c) {
             issue_a(stage ^ 1, c + 1);
@@ -498,6 +520,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
         if (more) {
             rid_cur[0] = rid_next[0];
             rid_cur[1] = rid_next[1];
+            cid_cur[0] = cid_next[0];
+            cid_cur[1] = cid_next[1];
             loader_set_tile(tbase + ti + nw_x);
             prefetch_ids(tile_at(ti + 2 * nw_x));
             issue_a(stage ^ 1, 0);
@@ -513,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
         stage ^= 1;
         // the stores retire under the next tile's first chunk; the bias image this reads is double-buffered by tile parity
         // (the next tile's acc_init rewrites the other half)
-        epilogue(tile, par);
+        epilogue(tile, par, cid_epi);
         PSTAMP(6)                                     // 6: epilogue
     }
 #ifdef LIME_STAMPS
@@ -535,7 +559,7 @@ int num_cus() {
     return n;
 }
 
-template <int NTL, bool LN, bool RELU, int RES, bool BF = false, bool POOL = false, bool RSTD = false>
+template <int NTL, bool LN, bool RELU, int RES, bool BF = false, bool POOL = false, bool RSTD = false, bool CID = false>
 int launch(const PPParams& p0, hipStream_t stream) {
     PPParams p = p0;
     p.n_row_blocks = (p.M + BM - 1) / BM;
@@ -546,9 +570,9 @@ int launch(const PPParams& p0, hipStream_t stream) {
 #ifdef LIME_STAMPS
     p.stamps = g_pp_stamp_buf;
 #endif
-    hipLaunchKernelGGL((gemm_pp_kernel<NTL, LN, RELU, RES, BF, POOL, RSTD>), dim3((unsigned)nwg), dim3(256), 0, stream, p);
-    lime_set_last_linear_kernel("gemm_pp_kernel<%d, %s, %s, %d, %s, %s, %s>", NTL, LN ? "true" : "false", RELU ? "true" : "false", RES,
-                                BF ? "true" : "false", POOL ? "true" : "false", RSTD ? "true" : "false");   // as rocprofv3 prints it
+    hipLaunchKernelGGL((gemm_pp_kernel<NTL, LN, RELU, RES, BF, POOL, RSTD, CID>), dim3((unsigned)nwg), dim3(256), 0, stream, p);
+    lime_set_last_linear_kernel("gemm_pp_kernel<%d, %s, %s, %d, %s, %s, %s, %s>", NTL, LN ? "true" : "false", RELU ? "true" : "false", RES,
+                                BF ? "true" : "false", POOL ? "true" : "false", RSTD ? "true" : "false", CID ? "true" : "false");   // as rocprofv3 prints it
     return lime_check_launch("lime_linear_f32");
 }
 
@@ -561,6 +585,8 @@ int lime_linear_pp(const lime_linear_args* a, hipStream_t s) {
     const bool has_res = a->res != nullptr, ln = a->ln_gamma != nullptr;
     const bool relu = a->act == LIME_ACT_RELU;
     if (a->M < 4096 || a->a_pe != nullptr) return LIME_PP_NOT_APPLICABLE;
+    if (a->c_ids && !(has_res && !a->res_ids && a->res_mod > 0 && !ln && a->act == LIME_ACT_NONE)) return LIME_PP_NOT_APPLICABLE;
+    if (a->c_ids && (long)a->M * a->ldc * 4 >= 0x7FFFFFF0L) return LIME_PP_NOT_APPLICABLE;    // scattered rows: offsets from C's base
     if (!(a->act == LIME_ACT_NONE || (relu && !has_res))) return LIME_PP_NOT_APPLICABLE;
     if (a->K % 4 || a->N % 4 || a->K < 2 * 16) return LIME_PP_NOT_APPLICABLE;      // >= 2 chunks: a barrier between the
                                                                                      // bias image's write and its read
@@ -592,6 +618,12 @@ int lime_linear_pp(const lime_linear_args* a, hipStream_t s) {
     p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps; p.ln_rstd = a->ln_rstd;
     p.c = a->c; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K; p.ln_count = a->N;
     p.n_row_blocks = p.n_col_blocks = 0;
+    p.m_dev = a->m_dev; p.c_ids = a->c_ids;
+    if (a->c_ids) {                                    // compacted in_proj: periodic residual, rows scattered by c_ids
+        const int pad5c = (a->N + 319) / 320 * 320 - a->N, pad4c = (a->N + 255) / 256 * 256 - a->N;
+        if (!(pad5c < pad4c) || !tail_ok(320)) return LIME_PP_NOT_APPLICABLE;
+        return launch<10, false, false, 1, false, false, false, true>(p, s);
+    }
     if (ln) {
         if (!tail_ok(320)) return LIME_PP_NOT_APPLICABLE;
         if (a->ln_rstd) {                              // training forward: residual + LayerNorm, rstd kept
@@ -659,6 +691,7 @@ extern "C" int lime_linear_bf16(const lime_linear_bf16_args* a, void* stream) {
     p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps; p.ln_rstd = nullptr;
     p.c = (float*)a->c; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K; p.ln_count = ln ? a->ln_count : a->N;
     p.n_row_blocks = p.n_col_blocks = 0;
+    p.m_dev = nullptr; p.c_ids = nullptr;
     hipStream_t s = (hipStream_t)stream;
     if (ln) {
         switch (a->res_kind) {

@@ -52,6 +52,8 @@ struct AttnP {
     const float* q; const float* k; const float* v; long ld; const unsigned char* mask;
     float* out; long ldo; int n_seq, S, n_head, hd, hs; float scale; int n_pair; int vec2; int n_group;
     int out_pad;         // BF: zero columns written behind the last head (the next GEMM reads K rounded up to 8)
+    const int* row_map;  // MAP: q / k / v row of token (seq * S + t) is row_map[seq * S + t] (padding tokens share S table rows)
+    const int* n_seq_dev;  // MAP: optional device-side sequence count (min(*n_seq_dev, n_seq) sequences are computed)
 #ifdef LIME_STAMPS
     unsigned long long* stamps;
 #endif
@@ -87,9 +89,13 @@ __device__ __forceinline__ f32x2 load2(const float* src, long ld, int r, int c, 
 // copies the whole accumulator array at a merge.
 // BF (FAST only): q / k / v / out are bf16 (lime_token_attention_bf16); they are widened to fp32 on the way into LDS /
 // the fragments and the products stay on the exact-fp32 MFMA, so scores, softmax and P V are computed as in the fp32 path.
-template <int NT, bool FAST, bool BF = false>
+// MAP (FAST, fp32 only): the compacted-sequence variant (lime_token_attention_rows_f32) -- operand rows are looked up in
+// p.row_map (one dependent 4-byte load per 16-byte operand load; it rides in the same prefetch), the sequence count may come
+// from device memory.  Output rows stay dense (seq * S + t).
+template <int NT, bool FAST, bool BF = false, bool MAP = false>
 __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_attn_kernel(const AttnP p) {
     static_assert(!BF || FAST, "the bf16 variant exists for the FAST shapes only");
+    static_assert(!MAP || (FAST && !BF), "the row-map variant exists for the fp32 FAST shapes only");
     constexpr int G = (NT >= 3) ? 1 : (4 / NT);   // (sequence, head) pairs per group
     constexpr int WPP = 4 / G;                     // waves per pair
     constexpr int SP = NT * 32;                    // padded sequence length
@@ -104,6 +110,16 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 31, fh = lane >> 5;
     const int S = p.S, hd = p.hd, hs = p.hs;
+    int n_pair = p.n_pair, n_group = p.n_group;
+    if constexpr (MAP) {
+        if (p.n_seq_dev) {
+            int ns = __builtin_amdgcn_readfirstlane(*p.n_seq_dev);
+            ns = ns < p.n_seq ? (ns > 0 ? ns : 0) : p.n_seq;
+            n_pair = ns * p.n_head;
+            n_group = (n_pair + (NT >= 3 ? 1 : 4 / NT) - 1) / (NT >= 3 ? 1 : 4 / NT);
+        }
+        if (n_group == 0) return;
+    }
     const bool vec2 = p.vec2 != 0;
     const int krow = 4 * fh;                       // key row of accumulator register r: (r & 3) + 8 * (r >> 2) + 4 * fh
 
@@ -120,7 +136,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
             if constexpr (BF) {                    // 8 bf16 = 16 bytes per load: four loads cover a 32-column head row
                 const int c = (e & 3) * 8, r = (e >> 2) % SP, g = (e >> 2) / SP;
                 int pair = group * G + g;
-                pair = pair < p.n_pair ? pair : p.n_pair - 1;
+                pair = pair < n_pair ? pair : n_pair - 1;
                 const int seq = pair / p.n_head, head = pair - seq * p.n_head;
                 const long off = ((long)seq * S + r) * p.ld + head * hs + c;
                 kreg[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned short*>(p.k) + off);
@@ -128,16 +144,18 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
             } else if constexpr (FAST) {
                 const int c = (e & 7) * 4, r = (e >> 3) % SP, g = (e >> 3) / SP;
                 int pair = group * G + g;
-                pair = pair < p.n_pair ? pair : p.n_pair - 1;
+                pair = pair < n_pair ? pair : n_pair - 1;
                 const int seq = pair / p.n_head, head = pair - seq * p.n_head;
-                const long off = ((long)seq * S + r) * p.ld + head * hs + c;
+                long row = (long)seq * S + r;
+                if constexpr (MAP) row = p.row_map[row];
+                const long off = row * p.ld + head * hs + c;
                 kreg[i] = *reinterpret_cast<const f32x4*>(p.k + off);
                 vreg[i] = *reinterpret_cast<const f32x4*>(p.v + off);
             } else {
                 const int c = (e & 15) * 2, r = (e >> 4) % SP, g = (e >> 4) / SP;
                 const int pair = group * G + g;
                 f32x2 kv = {0.f, 0.f}, vv = {0.f, 0.f};
-                if (pair < p.n_pair) {
+                if (pair < n_pair) {
                     const int seq = pair / p.n_head, head = pair - seq * p.n_head;
                     const long base = (long)seq * S * p.ld + head * hs;
                     kv = load2(p.k + base, p.ld, r, c, S, hd, vec2);
@@ -155,7 +173,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
             if constexpr (BF) {
                 const int c = (e & 3) * 8, r = (e >> 2) % SP, g = (e >> 2) / SP;
                 u32x4 kb = __builtin_bit_cast(u32x4, kreg[i]), vb = __builtin_bit_cast(u32x4, vreg[i]);
-                if (group * G + g >= p.n_pair) { kb = u32x4{0u, 0u, 0u, 0u}; vb = kb; }
+                if (group * G + g >= n_pair) { kb = u32x4{0u, 0u, 0u, 0u}; vb = kb; }
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
                     f32x4 kf;
@@ -173,7 +191,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
             } else if constexpr (FAST) {
                 const int c = (e & 7) * 4, r = (e >> 3) % SP, g = (e >> 3) / SP;
                 f32x4 kv = kreg[i], vv = vreg[i];
-                if (group * G + g >= p.n_pair) { kv = f32x4{0.f, 0.f, 0.f, 0.f}; vv = kv; }
+                if (group * G + g >= n_pair) { kv = f32x4{0.f, 0.f, 0.f, 0.f}; vv = kv; }
                 *reinterpret_cast<f32x4*>(&Ks[(g * SP + r) * LDH + c]) = kv;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) Vs[(g * 32 + c + j) * LDVT + r] = vv[j];
@@ -188,7 +206,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
             for (int e = tid; e < G * SP; e += 256) {
                 const int key = e % SP, pair = group * G + e / SP;
                 float f = key >= S ? 2.f : 0.f;
-                if (f == 0.f && p.mask && pair < p.n_pair && p.mask[(long)(pair / p.n_head) * S + key] == 0) f = 1.f;
+                if (f == 0.f && p.mask && pair < n_pair && p.mask[(long)(pair / p.n_head) * S + key] == 0) f = 1.f;
                 Flag[e] = f;
             }
         }
@@ -210,7 +228,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
     auto q_rows = [&](int grp, int qt, q_t* dst) {
         int pr = grp * G + g;
         if constexpr (BF) {                           // four 8-byte loads of 4 bf16, widened
-            pr = pr < p.n_pair ? pr : p.n_pair - 1;
+            pr = pr < n_pair ? pr : n_pair - 1;
             const int sq = pr / p.n_head, hh = pr - sq * p.n_head;
             const unsigned short* qsrc = reinterpret_cast<const unsigned short*>(p.q) + ((long)sq * S + qt * 32 + fi) * p.ld + hh * hs + fh * 4;
 #pragma unroll
@@ -222,13 +240,15 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
                 dst[kk] = f;
             }
         } else if constexpr (FAST) {                  // S == NT * 32: every query row exists
-            pr = pr < p.n_pair ? pr : p.n_pair - 1;
+            pr = pr < n_pair ? pr : n_pair - 1;
             const int sq = pr / p.n_head, hh = pr - sq * p.n_head;
-            const float* qsrc = p.q + ((long)sq * S + qt * 32 + fi) * p.ld + hh * hs + fh * 4;
+            long qrow = (long)sq * S + qt * 32 + fi;
+            if constexpr (MAP) qrow = p.row_map[qrow];
+            const float* qsrc = p.q + qrow * p.ld + hh * hs + fh * 4;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) dst[kk] = *reinterpret_cast<const f32x4*>(qsrc + kk * 8);
         } else {
-            if (pr >= p.n_pair || qt * 32 >= S) return;
+            if (pr >= n_pair || qt * 32 >= S) return;
             const int sq = pr / p.n_head, hh = pr - sq * p.n_head;
             const float* qsrc = p.q + ((long)sq * S + qt * 32) * p.ld + hh * hs;
             const int qrows = S - qt * 32;
@@ -249,14 +269,14 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
 #endif
     int group = blockIdx.x;
     if (PREFETCH) { fetch(group); prefetch_q(group); }
-    for (; group < p.n_group; group += gridDim.x) {
+    for (; group < n_group; group += gridDim.x) {
         if (!PREFETCH) fetch(group);
         stash(group);
         ASTAMP(0)
         lds_barrier();
         ASTAMP(1)
         const int pair = group * G + g;
-        const bool live = pair < p.n_pair;
+        const bool live = pair < n_pair;
         const int seq = live ? pair / p.n_head : 0, head = live ? pair - seq * p.n_head : 0;
         const int qt0 = wave % WPP;
         if (!PREFETCH) { if (live && qt0 * 32 < S) load_q(group, qt0); }
@@ -265,7 +285,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
             for (int i = 0; i < NQ; ++i) qraw[i] = qnext[i];
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (PREFETCH && group + (int)gridDim.x < p.n_group) {          // next group's K / V / Q: in flight under the MFMAs
+        if (PREFETCH && group + (int)gridDim.x < n_group) {          // next group's K / V / Q: in flight under the MFMAs
             fetch(group + gridDim.x);
             prefetch_q(group + gridDim.x);
         }
@@ -431,7 +451,42 @@ int launch(AttnP p, hipStream_t s) {
     return lime_check_launch("lime_token_attention_f32");
 }
 
+template <int NT>
+int launch_map(AttnP p, hipStream_t s) {
+    constexpr int G = (NT >= 3) ? 1 : (4 / NT);
+    p.n_group = (p.n_pair + G - 1) / G;
+    const int per_cu = NT <= 2 ? 3 : (NT <= 4 ? 2 : 1);
+    long blocks = (long)attn_num_cus() * per_cu;
+    if (blocks > p.n_group) blocks = p.n_group;
+    hipLaunchKernelGGL((token_attn_kernel<NT, true, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    return lime_check_launch("lime_token_attention_rows_f32");
+}
+
 }  // namespace
+
+extern "C" int lime_token_attention_rows_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const int32_t* row_map,
+                                             const int32_t* n_seq_dev, float* out, int64_t ldo, int32_t n_seq, int32_t S,
+                                             int32_t n_head, int32_t head_dim, float scale, void* stream) {
+    LIME_REQUIRE(q && k && v && out && row_map, LIME_ERR_BAD_ARG, "lime_token_attention_rows_f32: NULL pointer");
+    LIME_REQUIRE(n_seq >= 0 && n_head > 0 && head_dim > 0 && head_dim <= 32, LIME_ERR_BAD_ARG,
+                 "lime_token_attention_rows_f32: bad dims n_seq=%d n_head=%d head_dim=%d", n_seq, n_head, head_dim);
+    LIME_REQUIRE(S > 0 && S <= 512 && S % 32 == 0 && (S / 32 <= 4 || S / 32 == 8 || S / 32 == 16), LIME_ERR_UNSUPPORTED,
+                 "lime_token_attention_rows_f32: S must be 32, 64, 96, 128, 256 or 512 (got %d)", S);
+    LIME_REQUIRE(ld_qkv >= (int64_t)n_head * 32 && ld_qkv % 4 == 0 && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0),
+                 LIME_ERR_BAD_ARG, "lime_token_attention_rows_f32: heads are 32 columns apart (zero padded), rows 16-byte aligned");
+    LIME_REQUIRE(ldo >= (int64_t)n_head * head_dim, LIME_ERR_BAD_ARG, "lime_token_attention_rows_f32: ldo smaller than n_head * head_dim");
+    if (n_seq == 0) return LIME_OK;
+    AttnP p{q, k, v, (long)ld_qkv, nullptr, out, (long)ldo, n_seq, S, n_head, head_dim, 32, scale, n_seq * n_head, 1, 0, 0, row_map, n_seq_dev};
+    hipStream_t s = (hipStream_t)stream;
+    switch (S / 32) {
+        case 1: return launch_map<1>(p, s);
+        case 2: return launch_map<2>(p, s);
+        case 3: return launch_map<3>(p, s);
+        case 4: return launch_map<4>(p, s);
+        case 8: return launch_map<8>(p, s);
+        default: return launch_map<16>(p, s);
+    }
+}
 
 extern "C" int lime_token_attention_f32(const float* q, const float* k, const float* v, int64_t ld_qkv,
                                         const uint8_t* key_mask, float* out, int64_t ldo, int32_t n_seq, int32_t S,
@@ -448,7 +503,7 @@ extern "C" int lime_token_attention_f32(const float* q, const float* k, const fl
     // 8-byte loads need an even head_dim and leading dimension and 8-byte aligned bases
     const int vec2 = (head_dim % 2 == 0) && (head_stride % 2 == 0) && (ld_qkv % 2 == 0) &&
                      (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 8 == 0);
-    AttnP p{q, k, v, (long)ld_qkv, key_mask, out, (long)ldo, n_seq, S, n_head, head_dim, head_stride, scale, n_seq * n_head, vec2, 0, 0};
+    AttnP p{q, k, v, (long)ld_qkv, key_mask, out, (long)ldo, n_seq, S, n_head, head_dim, head_stride, scale, n_seq * n_head, vec2, 0, 0, nullptr, nullptr};
     hipStream_t s = (hipStream_t)stream;
     const int nt = (S + 31) / 32;
     if (nt <= 1) return launch<1>(p, s);
@@ -483,7 +538,7 @@ extern "C" int lime_token_attention_bf16(const uint16_t* q, const uint16_t* k, c
         if (st != 1) return st;
     }
     AttnP p{(const float*)q, (const float*)k, (const float*)v, (long)ld_qkv, nullptr, (float*)out, (long)ldo, n_seq, S, n_head,
-            head_dim, 32, scale, n_seq * n_head, 1, 0, pad};
+            head_dim, 32, scale, n_seq * n_head, 1, 0, pad, nullptr, nullptr};
     switch (S / 32) {
         case 1: return launch_bf16<1>(p, s);
         case 2: return launch_bf16<2>(p, s);

@@ -25,6 +25,11 @@ from .layers import Attention, MultiHeadAttention
 # tokens encoded per pass of the token encoder: bounds the activation workspace (9.2 KB / token)
 MAX_TOKENS_PER_PASS = 4 * 1024 * 1024
 
+# Encode only what differs (encode_tokens_compact): all-padding sequences share one representative, in_proj runs over the live
+# tokens only.  Exact (same arithmetic per row, nothing cached between forwards); LIME_DENSE_TOKENS=1 (or DEDUP = False) runs
+# every token of every slot through the layer as the reference does -- the A/B switch behind bench.py's "dense" figures.
+DEDUP = os.environ.get('LIME_DENSE_TOKENS', '0') != '1'
+
 
 def _no_train_dropout(module, p):
     if module.training and p > 0:
@@ -46,11 +51,19 @@ _SIDE = {}
 # Independent branches of the forward CAN be forked onto side streams (fork / join with wait_stream, which is also how
 # the fork is recorded into the HIP graph): branch 0 = freshness encoder, 2 = candidate-aware attention weights (small,
 # latency-bound kernels that otherwise sit on the critical path in front of the token encoders), 1 = title chain beside the
-# body chain.  OVERLAP_BRANCHES is the set that is forked (LIME_OVERLAP_STREAMS = 0: none, 2: the two small branches --
+# body chain, 3 = the body encoder's preparation under the title encoder, 4 = category representation + stacked intent weights, 5 = the
+# body half of the intent attention's hidden GEMM, 6 = the candidate side of the interest match (same-box A/B at config 2b, ms per
+# step: {0,2} 2.414, {0,2,3} 2.372, {0,2,4} 2.446 -- short kernels in front of a persistent GEMM delay some of its statically
+# scheduled workgroups --, {0,2,5,6} 2.415, all 2.466).  OVERLAP_BRANCHES is the set that is forked (LIME_OVERLAP_STREAMS = 0: none, 2: the two small branches --
 # the default, 4.557 vs 4.593 ms --, 1: all three).  The title / body fork is off by default: the big GEMMs hold two
 # workgroups of 256 VGPRs x 4 waves and 61 KB LDS on every CU, so nothing else becomes resident beside them and that fork
 # measured slower (4.651 ms).
-OVERLAP_BRANCHES = {'0': frozenset(), '1': frozenset((0, 1, 2)), '2': frozenset((0, 2))}[os.environ.get('LIME_OVERLAP_STREAMS', '2')]
+def _branches(spec):
+    named = {'0': frozenset(), '1': frozenset((0, 1, 2, 3, 4, 5, 6)), '2': frozenset((0, 2, 3))}
+    return named[spec] if spec in named else frozenset(int(x) for x in spec.split('+'))       # e.g. LIME_OVERLAP_STREAMS=0+2+4
+
+
+OVERLAP_BRANCHES = _branches(os.environ.get('LIME_OVERLAP_STREAMS', '2'))
 SERIAL_STREAMS = False          # bench.py's instrumented pass forces everything onto one stream
 
 
@@ -409,6 +422,77 @@ def encode_tokens(ids, table, pe, transformer, nhead, pooled_out=None):
     return x
 
 
+def encode_tokens_compact(ids, table, pe, transformer, nhead, pooled_out):
+    """``encode_tokens(..., pooled_out)`` without the repetitions of a padded batch (csrc/compact.hip): the history slots of an
+    impression are padded with the all-zero <PAD> news (corpus.py:476-477, dataset.py:105-141) and every text with the padding
+    word behind it; the reference encodes them all (newsEncoders.py:311-321).
+
+      * sequence level: an all-padding sequence pools to the same vector wherever it stands (no mask, no cross-sequence term in
+        the layer), so the live sequences + ONE all-padding representative go through the layer (n_c = live + 1 sequences) and
+        ``pooled_out[s] = pooled_c[seq_inv[s]]``;
+      * token level: the in_proj row of a padding token is (E[0] + PE[t]) W^T + b, a function of its position alone: S table
+        rows computed once; in_proj runs over the live tokens (rows scattered to their compact positions) and attention looks
+        every token's q / k / v row up through ``row_map``.  From the attention output on every position is distinct.
+
+    Counts live in device memory (lime_linear_args.m_dev / n_seq_dev), buffers have their full-batch size: the forward stays one
+    HIP graph.  Same kernels, same per-row arithmetic as the dense path; results differ from it only through the S padding rows
+    coming from the small-M GEMM kernel (different k order, ~1e-7).  Returns None (the result is ``pooled_out``).
+    """
+    return compact_run(compact_prepare(ids, table, pe, transformer, nhead), table, pe, transformer, nhead, pooled_out)
+
+
+def compact_prepare(ids, table, pe, transformer, nhead):
+    """Everything of ``encode_tokens_compact`` in front of the big GEMMs -- index lists, padded in_proj weights, the positional
+    table through in_proj, the S rows shared by the padding tokens: a dozen short launches that depend on the ids and the
+    weights only, so the caller can run them on a side stream under another encoder's GEMMs."""
+    M, S = ids.shape
+    E = table.shape[1]
+    hd = E // nhead
+    W = nhead * 32
+    sa = transformer.layers[0].self_attn
+    cap = (M + 1) * S
+    cmp = ops.compact_sequences(ids)                                           # pad rows live at qkv[cap : cap + S]
+    w_in = ops.pad_heads(sa.in_proj_weight, 3 * nhead, hd, 32)
+    b_in = ops.pad_heads(sa.in_proj_bias, 3 * nhead, hd, 32)
+    pew = ops.linear(pe[:S], w_in, b_in)                                       # [S, 3W]: positional term + bias
+    qkv = torch.empty((cap + S, 3 * W), dtype=torch.float32, device=ids.device)
+    zeros = torch.zeros(S, dtype=torch.int32, device=ids.device)
+    ops.linear(table, w_in, None, a_ids=zeros, res=pew, res_mod=S, out=qkv[cap:])                     # the S padding rows
+    return cmp, w_in, pew, qkv
+
+
+def compact_run(prep, table, pe, transformer, nhead, pooled_out):
+    cmp, w_in, pew, qkv = prep
+    M, S, cap = cmp.n_seq, cmp.S, cmp.cap
+    E = table.shape[1]
+    hd = E // nhead
+    W = nhead * 32
+    layer = transformer.layers[0]
+    sa = layer.self_attn
+    ops.linear(table, w_in, None, a_ids=cmp.tok_ids, res=pew, res_mod=S, out=qkv[:cap], m_dev=cmp.n_live_tokens,
+               c_ids=cmp.tok_rows, n_alg=3 * E)                                                        # live tokens only
+    attn = ops.token_attention_rows(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], cmp.row_map, cmp.n_compact, M + 1, S, nhead, hd,
+                                    1.0 / math.sqrt(hd))
+    x1 = ops.linear(attn, sa.out_proj.weight, sa.out_proj.bias, res=table, res_ids=cmp.ids_c, res_pe=pe, res_period=S,
+                    ln=(layer.norm1.weight, layer.norm1.bias), ln_eps=layer.norm1.eps, m_dev=cmp.n_rows)
+    h = ops.linear(x1, layer.linear1.weight, layer.linear1.bias, act='relu', m_dev=cmp.n_rows)
+    blocks = ops.linear(h, layer.linear2.weight, layer.linear2.bias, res=x1, ln=(layer.norm2.weight, layer.norm2.bias),
+                        ln_eps=layer.norm2.eps, pool32=True, m_dev=cmp.n_rows)                         # [cap / 32, E] block means
+    pooled_c = blocks if S == 32 else ops.mean_pool(blocks, M + 1, S // 32)
+    ops.gather_rows(cmp.seq_inv, pooled_c, pooled_out)
+    return None
+
+
+def compact_applicable(ids, table, transformer, nhead):
+    """The compacted path covers the shapes of the big-M kernels: one post-LN layer without a final norm, head_dim <= 32,
+    S a multiple of 32 that the row-map attention is built for, at least 4096 token rows, 16-byte aligned table rows."""
+    M, S = ids.shape
+    E = table.shape[1]
+    return (DEDUP and len(transformer.layers) == 1 and transformer.norm is None and E % nhead == 0 and E // nhead <= 32 and
+            E % 4 == 0 and S % 32 == 0 and (S // 32 <= 4 or S // 32 in (8, 16)) and (M + 1) * S >= 4096 and
+            ids.dtype == torch.int32 and ids.is_contiguous())
+
+
 def encode_tokens_bf16(ids, table_bf16, pe, transformer, nhead, pooled_out):
     """encode_tokens + mean pool on the bf16 matrix cores (BASELINE config 3).
 
@@ -531,39 +615,71 @@ class CROWN(NewsEncoder):
         if bf16:                                                   # the word table in bf16, rows padded to 8 columns
             table_b = ops.to_bf16(table, cols_out=(E + 7) // 8 * 8)
         main = torch.cuda.current_stream()
-        side = _side_stream(dev, 1)
-        side.wait_stream(main)
-        for half, (ids, pos, tr, S) in enumerate(((title_text, self.title_pos_encoder, self.title_transformer, T),
-                                                  (content_text, self.body_pos_encoder, self.body_transformer, L))):
-            step = max(1, MAX_TOKENS_PER_PASS // S)
-            with torch.cuda.stream(side if half == 0 else main):
-                for m0 in range(0, M, step):
-                    m1 = min(M, m0 + step)
-                    if bf16:
-                        encode_tokens_bf16(ids[m0:m1], table_b, pos.table(), tr, self.head_num,
-                                           xin[half * M + m0:half * M + m1, :E])
-                        continue
-                    encode_tokens(ids[m0:m1], table, pos.table(), tr, self.head_num,
-                                  pooled_out=xin[half * M + m0:half * M + m1, :E])                                   # :311-321
-        main.wait_stream(side)
-        # category representation (:340-342) and the raw category / subCategory rows of feature_fusion (:221-225)
-        sub_table = self.subCategory_embedding.weight
-        ops.topic_rep(category, subCategory, self.category_embedding.weight, sub_table, self.category_affine.weight,
-                      self.category_affine.bias, out=xin[:M, E:kin], emb_out=out[:, 2 * D:2 * D + Dc + sub_table.shape[1]])
-        ops.topic_rep(category, subCategory, self.category_embedding.weight, sub_table, self.category_affine.weight,
-                      self.category_affine.bias, out=xin[M:, E:kin])
+        # branch 4: the category representation (:340-342), the raw category / subCategory rows of feature_fusion (:221-225) and
+        # the stacked intent weights -- they depend on ids and weights only, and run beside the token encoders
+        side4 = _side_stream(dev, 4)
+        side4.wait_stream(main)
+        with torch.cuda.stream(side4):
+            sub_table = self.subCategory_embedding.weight
+            ops.topic_rep(category, subCategory, self.category_embedding.weight, sub_table, self.category_affine.weight,
+                          self.category_affine.bias, out=xin[:M, E:kin], emb_out=out[:, 2 * D:2 * D + Dc + sub_table.shape[1]])
+            ops.topic_rep(category, subCategory, self.category_embedding.weight, sub_table, self.category_affine.weight,
+                          self.category_affine.bias, out=xin[M:, E:kin])
+            w_int = torch.cat([lin.weight for lin in self.intent_layers], dim=0)
+            b_int = torch.cat([lin.bias for lin in self.intent_layers], dim=0)
+        encoders = ((title_text, self.title_pos_encoder, self.title_transformer, T),
+                    (content_text, self.body_pos_encoder, self.body_transformer, L))
+        step_of = lambda S: min(max(1, MAX_TOKENS_PER_PASS // S),
+                                # the compacted in_proj scatters rows with 32-bit byte offsets from the base of qkv ([rows, 3 * 320] fp32)
+                                max(1, (0x7FFFFFF0 // (3 * self.head_num * 32 * 4)) // S - 2) if (DEDUP and not bf16) else M)
+        one_pass = (not bf16 and all(M <= step_of(S) and compact_applicable(ids, table, tr, self.head_num)
+                                     for ids, pos, tr, S in encoders))
+        if one_pass:
+            # both encoders on the compacted path in one pass each: the body's preparation (index lists, padded weights, padding
+            # rows: a dozen short launches) runs on branch 3 under the title encoder's GEMMs
+            (t_ids, t_pos, t_tr, _), (b_ids, b_pos, b_tr, _) = encoders
+            side3 = _side_stream(dev, 3)
+            side3.wait_stream(main)
+            with torch.cuda.stream(side3):
+                prep_b = compact_prepare(b_ids, table, b_pos.table(), b_tr, self.head_num)
+            prep_t = compact_prepare(t_ids, table, t_pos.table(), t_tr, self.head_num)
+            compact_run(prep_t, table, t_pos.table(), t_tr, self.head_num, xin[:M, :E])                        # :311-317
+            main.wait_stream(side3)
+            compact_run(prep_b, table, b_pos.table(), b_tr, self.head_num, xin[M:, :E])                        # :312-321
+        else:
+            side = _side_stream(dev, 1)
+            side.wait_stream(main)
+            for half, (ids, pos, tr, S) in enumerate(encoders):
+                step = step_of(S)
+                with torch.cuda.stream(side if half == 0 else main):
+                    for m0 in range(0, M, step):
+                        m1 = min(M, m0 + step)
+                        if bf16:
+                            encode_tokens_bf16(ids[m0:m1], table_b, pos.table(), tr, self.head_num,
+                                               xin[half * M + m0:half * M + m1, :E])
+                            continue
+                        if compact_applicable(ids[m0:m1], table, tr, self.head_num):
+                            encode_tokens_compact(ids[m0:m1], table, pos.table(), tr, self.head_num,
+                                                  pooled_out=xin[half * M + m0:half * M + m1, :E])
+                            continue
+                        encode_tokens(ids[m0:m1], table, pos.table(), tr, self.head_num,
+                                      pooled_out=xin[half * M + m0:half * M + m1, :E])                                   # :311-321
+            main.wait_stream(side)
+        main.wait_stream(side4)
         # k intent layers (:284-295): [2M, 350] x [400, 350]^T each, ReLU fused, written side by side
         # (one GEMM against the k weight matrices stacked row-wise: the k layers share their input)
-        w_int = torch.cat([lin.weight for lin in self.intent_layers], dim=0)
-        b_int = torch.cat([lin.bias for lin in self.intent_layers], dim=0)
         intents = ops.linear(xin[:, :kin], w_int, b_int, act='relu')
-        # intent attention (:355-356): tanh(affine1) on the GEMM, the rest in the fuse kernel
+        # intent attention (:355-356): tanh(affine1) on the GEMM (title on the main stream, body on branch 5), the rest in the fuse kernel
         A = self.title_intent_attention.affine1.out_features
         hidden = torch.empty((2 * M * k, A), dtype=torch.float32, device=dev)
         iv = intents.view(2 * M * k, D)
+        side5 = _side_stream(dev, 5)
+        side5.wait_stream(main)
         for half, att in enumerate((self.title_intent_attention, self.body_intent_attention)):
-            ops.linear(iv[half * M * k:(half + 1) * M * k], att.affine1.weight, att.affine1.bias, act='tanh',
-                       out=hidden[half * M * k:(half + 1) * M * k])
+            with torch.cuda.stream(main if half == 0 else side5):
+                ops.linear(iv[half * M * k:(half + 1) * M * k], att.affine1.weight, att.affine1.bias, act='tanh',
+                           out=hidden[half * M * k:(half + 1) * M * k])
+        main.wait_stream(side5)
         ops.intent_fuse(iv, hidden, self.title_intent_attention.affine2.weight.view(-1),
                         self.body_intent_attention.affine2.weight.view(-1), out, M, k, D, A)          # :355-371
         return out

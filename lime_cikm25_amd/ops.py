@@ -61,11 +61,15 @@ def _mask_u8(mask, name):
 
 
 def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=0, res=None, res_div=1, res_ids=None,
-           res_pe=None, res_period=0, ln=None, ln_eps=1e-5, res_mod=0, pool32=False, ln_rstd=None, n_alg=None):
+           res_pe=None, res_period=0, ln=None, ln_eps=1e-5, res_mod=0, pool32=False, ln_rstd=None, n_alg=None, m_dev=None,
+           c_ids=None):
     """C = epilogue(A . W^T + bias) -- see ``lime_linear_f32`` in include/lime_hip.h.
 
     n_alg: the number of USEFUL output columns when w carries zero padding rows (in_proj with heads padded to 32 columns:
     900 of 960); only bench.py's per-kernel FLOP accounting reads it.
+    m_dev: int32 device tensor (1 element): the launch computes min(m_dev, M) rows, M being the capacity of the buffers.
+    c_ids: int32 [M]: result row r is stored at out[c_ids[r]] (out is then passed in, any number of rows) and the periodic
+    residual is res[c_ids[r] % res_mod] -- the in_proj over a compacted token list (``compact_sequences``).
 
     a: [M, K] (or the [V, K] table when a_ids is given, M = len(a_ids)); w: [N, K]; out: [M, N] (may be a view).
     ln: (gamma, beta) for the fused LayerNorm (N <= 320); ln_rstd: optional [M] output of the rows' 1 / sqrt(var + eps).
@@ -87,9 +91,17 @@ def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=
     if out is None:
         out = torch.empty((rows_out, N), dtype=torch.float32, device=a.device)
     _mat(out, 'out')
-    if tuple(out.shape) != (rows_out, N):
+    if c_ids is not None:
+        if out.shape[1] != N or res_mod <= 0:
+            raise ValueError('c_ids needs an [*, N] out and a periodic residual (res_mod > 0)')
+        args_c_ids = _vec(c_ids, 'c_ids', M, dtype=torch.int32)
+    elif tuple(out.shape) != (rows_out, N):
         raise ValueError('out must be [%d, %d], got %s' % (rows_out, N, tuple(out.shape)))
     args = LinearArgs()
+    if c_ids is not None:
+        args.c_ids = args_c_ids.data_ptr()
+    if m_dev is not None:
+        args.m_dev = _vec(m_dev, 'm_dev', 1, dtype=torch.int32).data_ptr()
     args.pool32 = 1 if pool32 else 0
     args.a, args.lda = a.data_ptr(), _ld(a)
     args.a_ids = a_ids.data_ptr() if a_ids is not None else None
@@ -133,7 +145,8 @@ def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=
         e0.record()
         check(lib.lime_linear_f32(ctypes.byref(args), _stream()), 'lime_linear_f32')
         e1.record()
-        PROFILE.append((lib.lime_last_linear_kernel().decode(), M, N, K, n_alg or N, e0, e1))
+        m_run = M if m_dev is None else min(M, int(m_dev.item()))      # the rows this launch computed
+        PROFILE.append((lib.lime_last_linear_kernel().decode(), m_run, N, K, n_alg or N, e0, e1))
         return out
     check(lib.lime_linear_f32(ctypes.byref(args), _stream()), 'lime_linear_f32')
     return out
@@ -175,6 +188,63 @@ def token_attention(q, k, v, n_seq, S, n_head, head_dim, scale, key_mask=None, o
     check(lib.lime_token_attention_f32(_p(q), _p(k), _p(v), _ld(q), _p(m), _p(out), _ld(out), n_seq, S, n_head, head_dim, hs,
                                        scale, _stream()), 'lime_token_attention_f32')
     return out
+
+
+def token_attention_rows(q, k, v, row_map, n_seq_dev, n_seq, S, n_head, head_dim, scale, out=None):
+    """``lime_token_attention_rows_f32``: attention over compacted sequences.  q / k / v: column views (heads 32 columns apart) of
+    one buffer that also holds the S rows shared by the padding tokens; row_map: int32 [n_seq * S] -> row of that buffer;
+    n_seq_dev: int32 device tensor (1 element) or None; out: [n_seq * S, n_head * head_dim] (rows of sequences beyond the
+    device count are left untouched)."""
+    lib = _lib.load()
+    for t, n in ((q, 'q'), (k, 'k'), (v, 'v')):
+        _mat(t, n)
+        if t.shape[1] != n_head * 32:
+            raise ValueError('%s must have n_head * 32 columns' % n)
+    if not (_ld(q) == _ld(k) == _ld(v)):
+        raise ValueError('q, k and v must share one leading dimension')
+    _vec(row_map, 'row_map', dtype=torch.int32)
+    if row_map.numel() < n_seq * S:
+        raise ValueError('row_map must cover n_seq * S tokens')
+    if n_seq_dev is not None:
+        _vec(n_seq_dev, 'n_seq_dev', 1, dtype=torch.int32)
+    if out is None:
+        out = torch.empty((n_seq * S, n_head * head_dim), dtype=torch.float32, device=q.device)
+    _mat(out, 'out')
+    check(lib.lime_token_attention_rows_f32(_p(q), _p(k), _p(v), _ld(q), _p(row_map), _p(n_seq_dev), _p(out), _ld(out), n_seq, S,
+                                            n_head, head_dim, scale, _stream()), 'lime_token_attention_rows_f32')
+    return out
+
+
+class Compacted:
+    """Index lists of ``compact_sequences`` (all int32 device tensors; see lime_compact_sequences in include/lime_hip.h)."""
+    __slots__ = ('n_seq', 'S', 'cap', 'seq_inv', 'ids_c', 'row_map', 'tok_ids', 'tok_rows', 'counts')
+
+    n_compact = property(lambda self: self.counts[0:1])      # device counts as 1-element views (m_dev / n_seq_dev arguments)
+    n_rows = property(lambda self: self.counts[1:2])
+    n_live_tokens = property(lambda self: self.counts[2:3])
+
+
+def compact_sequences(ids, pad_base=None):
+    """ids int32 [n_seq, S] -> ``Compacted``: the live sequences (+ one all-padding representative) and their live tokens.
+    pad_base: the q/k/v row where the S padding rows start (default: right behind the (n_seq + 1) * S compact rows)."""
+    lib = _lib.load()
+    if ids.dim() != 2 or ids.dtype != torch.int32 or not ids.is_cuda or not ids.is_contiguous():
+        raise TypeError('ids must be a contiguous CUDA int32 [n_seq, S] tensor')
+    n_seq, S = ids.shape
+    cap = (n_seq + 1) * S
+    c = Compacted()
+    c.n_seq, c.S, c.cap = n_seq, S, cap
+    dev = ids.device
+    buf = torch.empty(n_seq + 4 * cap + 4 + int(lib.lime_compact_sequences_workspace(n_seq)), dtype=torch.int32, device=dev)
+    c.seq_inv = buf[:n_seq]
+    o = n_seq
+    c.ids_c, c.row_map, c.tok_ids, c.tok_rows = (buf[o + i * cap:o + (i + 1) * cap] for i in range(4))
+    o += 4 * cap
+    c.counts = buf[o:o + 4]
+    work = buf[o + 4:]
+    check(lib.lime_compact_sequences(_p(ids), n_seq, S, cap if pad_base is None else pad_base, _p(c.seq_inv), _p(c.ids_c), _p(c.row_map),
+                                     _p(c.tok_ids), _p(c.tok_rows), _p(c.counts), _p(work), _stream()), 'lime_compact_sequences')
+    return c
 
 
 def pad_heads(src, n_blk, head_dim, head_stride):

@@ -134,6 +134,13 @@ class CROWN(UserEncoder):
         B, H, D = history_embedding.shape
         N = candidate_news_representation.shape[1]
         cand = candidate_news_representation.contiguous()
+        # the candidate side of the match (:162) needs the candidates only: branch 6, beside the history chain
+        from .newsEncoders import _side_stream
+        main = torch.cuda.current_stream()
+        side6 = _side_stream(cand.device, 6)
+        side6.wait_stream(main)
+        with torch.cuda.stream(side6):
+            qp = ops.linear(cand.view(B * N, D), self.Q.weight, self.Q.bias)                                 # :162
         if self.use_candidate_aware_attn:
             if agg is None:
                 agg = self.attention_weights(category, subCategory, user_category, user_subCategory, user_history_mask)
@@ -141,7 +148,7 @@ class CROWN(UserEncoder):
         g = self.graph_sage.forward_closed_form(history_embedding, self.user_node_embedding,
                                                 n_src=B if n_src is None else n_src)                          # :121,:151-157
         kp = ops.linear(g.view(B * H, D), self.K.weight, None)                                               # :161
-        qp = ops.linear(cand.view(B * N, D), self.Q.weight, self.Q.bias)                                     # :162
+        main.wait_stream(side6)
         w = weighting
         user, logits = ops.interest_match(
             kp, qp, g.reshape(-1), cand.reshape(-1), remaining_lifetime, B, N, H, self.attention_dim, D,

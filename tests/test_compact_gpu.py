@@ -1,0 +1,145 @@
+"""Encoding only what differs in a padded batch (csrc/compact.hip, newsEncoders.encode_tokens_compact): the index lists against a
+numpy statement, the compacted in_proj GEMM (device-side row count, scattered result rows) and the row-map attention against
+the dense kernels on the same data, the compacted token encoder against the dense one, and the model with DEDUP on against
+DEDUP off (every token of every slot through the layer, as the reference computes it, newsEncoders.py:311-321) -- including a
+batch without any padding and one that is nothing but padding."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err
+from lime_cikm25_amd import Model, make_config, newsEncoders, ops, synth
+from oracle import lime_oracle as O
+from test_model_gpu import gpu_model, run
+
+pytestmark = pytest.mark.gpu
+
+
+def random_ids(n_seq, S, seed, p_empty=0.4, vocab=1000):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(1, S + 1, size=n_seq)
+    lens[rng.random(n_seq) < p_empty] = 0
+    ids = rng.integers(1, vocab, size=(n_seq, S))
+    ids[np.arange(S)[None, :] >= lens[:, None]] = 0
+    holes = rng.random((n_seq, S)) < 0.02                       # padding words INSIDE a text are handled too
+    ids[holes] = 0
+    return ids.astype(np.int32)
+
+
+def np_compact(ids):
+    n_seq, S = ids.shape
+    live = (ids != 0).any(axis=1)
+    src = np.flatnonzero(live)
+    n_live = len(src)
+    inv = np.full(n_seq, n_live, dtype=np.int64)
+    inv[src] = np.arange(n_live)
+    ids_c = np.concatenate([ids[src], np.zeros((1, S), np.int32)])
+    rows = np.arange((n_live + 1) * S).reshape(n_live + 1, S)
+    cap = (n_seq + 1) * S
+    row_map = np.where(ids_c != 0, rows, cap + np.arange(S)[None, :])
+    tok = np.flatnonzero(ids_c.reshape(-1) != 0)
+    return inv, ids_c, row_map, ids_c.reshape(-1)[tok], tok, n_live
+
+
+@pytest.mark.parametrize('n_seq,S,p_empty', [(300, 32, 0.4), (77, 128, 0.5), (40, 512, 0.3), (64, 32, 0.0), (50, 64, 1.0)])
+def test_compact_sequences_against_numpy(n_seq, S, p_empty):
+    ids = random_ids(n_seq, S, seed=n_seq + S, p_empty=p_empty)
+    c = ops.compact_sequences(torch.from_numpy(ids).cuda())
+    inv, ids_c, row_map, tok_ids, tok_rows, n_live = np_compact(ids)
+    counts = c.counts.cpu().numpy()
+    assert counts.tolist() == [n_live + 1, (n_live + 1) * S, len(tok_ids), n_live]
+    assert np.array_equal(c.seq_inv.cpu().numpy(), inv)
+    n = (n_live + 1) * S
+    assert np.array_equal(c.ids_c.cpu().numpy()[:n], ids_c.reshape(-1))
+    assert np.array_equal(c.row_map.cpu().numpy()[:n], row_map.reshape(-1))
+    assert np.array_equal(c.tok_ids.cpu().numpy()[:len(tok_ids)], tok_ids)
+    assert np.array_equal(c.tok_rows.cpu().numpy()[:len(tok_ids)], tok_rows)
+
+
+def test_compacted_inproj_and_row_map_attention_equal_the_dense_kernels():
+    """in_proj over the live tokens (m_dev, c_ids) writes exactly the rows the dense in_proj writes for them (same kernel, same
+    k order: bitwise), and attention through row_map equals attention over the materialised rows (bitwise)."""
+    n_seq, S, E, nhead = 200, 32, 300, 10
+    hd, Wd = E // nhead, nhead * 32
+    g = torch.Generator().manual_seed(3)
+    ids_np = random_ids(n_seq, S, seed=5, p_empty=0.0, vocab=700)
+    ids = torch.from_numpy(ids_np).cuda()
+    table = (torch.randn(700, E, generator=g) * 0.3).cuda()
+    w = ops.pad_heads((torch.randn(3 * E, E, generator=g) * 0.05).cuda(), 3 * nhead, hd, 32)
+    pew = torch.randn(S, 3 * Wd, generator=g).cuda()
+    dense = ops.linear(table, w, None, a_ids=ids.reshape(-1), res=pew, res_mod=S)          # [n_seq * S, 960], big-M kernel
+    c = ops.compact_sequences(ids)
+    cap = c.cap
+    qkv = torch.full((cap + S, 3 * Wd), float('nan'), device='cuda')
+    ops.linear(table, w, None, a_ids=c.tok_ids, res=pew, res_mod=S, out=qkv[:cap], m_dev=c.n_live_tokens, c_ids=c.tok_rows)
+    torch.cuda.synchronize()
+    live = torch.from_numpy(ids_np.reshape(-1) != 0).cuda()
+    assert torch.equal(qkv[:n_seq * S][live], dense[live])                                   # p_empty = 0: compact order = original
+    assert torch.isnan(qkv[:n_seq * S][~live]).all() and torch.isnan(qkv[(n_seq + 1) * S:cap]).all()   # nothing else was written
+    # padding rows from the dense result of a padding token at each position (any sequence: they only depend on t)
+    pad_rows = ops.linear(table, w, None, a_ids=torch.zeros(S, dtype=torch.int32, device='cuda'), res=pew, res_mod=S)
+    qkv[cap:] = pad_rows
+    full = qkv[:(n_seq + 1) * S].clone()
+    rm = c.row_map[:(n_seq + 1) * S].long()
+    full = qkv[rm]                                                                           # materialised rows
+    want = ops.token_attention(full[:, :Wd], full[:, Wd:2 * Wd], full[:, 2 * Wd:], n_seq + 1, S, nhead, hd, 1.0 / math.sqrt(hd), head_stride=32)
+    got = ops.token_attention_rows(qkv[:, :Wd], qkv[:, Wd:2 * Wd], qkv[:, 2 * Wd:], c.row_map, c.n_compact, n_seq + 1, S, nhead, hd,
+                                   1.0 / math.sqrt(hd))
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize('S', [32, 128])
+def test_compact_token_encoder_equals_the_dense_one(S):
+    cfg = make_config(vocabulary_size=3000, max_title_length=S, max_abstract_length=128)
+    model, sd = gpu_model(cfg, seed=91)
+    enc = model.news_encoder.base_news_encoder
+    tr, pos = (enc.title_transformer, enc.title_pos_encoder)
+    n_seq = 300
+    ids = torch.from_numpy(random_ids(n_seq, S, seed=17, p_empty=0.45, vocab=3000)).cuda()
+    table = enc.word_embedding.weight
+    dense = torch.empty(n_seq, 300, device='cuda')
+    comp = torch.empty(n_seq, 300, device='cuda')
+    with torch.no_grad():
+        newsEncoders.encode_tokens(ids, table, pos.table(), tr, enc.head_num, pooled_out=dense)
+        assert newsEncoders.compact_applicable(ids, table, tr, enc.head_num)
+        newsEncoders.encode_tokens_compact(ids, table, pos.table(), tr, enc.head_num, pooled_out=comp)
+    torch.cuda.synchronize()
+    e = rel_err(comp.cpu().numpy(), dense.cpu().numpy())
+    print('S=%d compact vs dense pooled: %.2e' % (S, e))
+    assert e < 2e-6
+    # all-padding sequences: one vector, bit for bit
+    empty = (ids == 0).all(dim=1)
+    assert int(empty.sum()) > 10 and bool((comp[empty] == comp[empty][0]).all())
+
+
+@pytest.mark.parametrize('mode', ['mind_shaped', 'no_padding', 'only_padding'])
+def test_model_with_and_without_dedup(mode, monkeypatch):
+    """Config-2 shape.  DEDUP off = every token of every slot through the layer (the reference's way); DEDUP on must give the
+    same logits (<= 2e-6 relative; the oracle is 1e-3 away from neither)."""
+    cfg = make_config(vocabulary_size=50000)
+    model, sd = gpu_model(cfg, seed=23)
+    batch = synth.make_batch(cfg, 32, 5, seed=24)
+    if mode == 'no_padding':
+        rng = np.random.default_rng(0)
+        for k in ('user_title_text', 'user_content_text', 'news_title_text', 'news_content_text'):
+            batch[k] = torch.from_numpy(rng.integers(1, cfg.vocabulary_size, size=tuple(batch[k].shape)).astype(np.int32))
+    if mode == 'only_padding':
+        for k in ('user_title_text', 'user_content_text', 'news_title_text', 'news_content_text'):
+            batch[k] = torch.zeros_like(batch[k])
+    monkeypatch.setattr(newsEncoders, 'DEDUP', True)
+    got = run(model, batch, False)
+    model._graphs.clear()
+    monkeypatch.setattr(newsEncoders, 'DEDUP', False)
+    dense = run(model, batch, False)
+    model._graphs.clear()
+    e = rel_err(got.numpy(), dense.numpy())
+    print('%s: dedup vs dense %.2e' % (mode, e))
+    assert torch.isfinite(got).all() and e < 2e-6
+    if mode == 'mind_shaped':
+        want = O.model_forward(sd, cfg, batch)
+        assert rel_err(got.numpy(), want.numpy()) < 1e-3
+        monkeypatch.setattr(newsEncoders, 'DEDUP', True)
+        assert torch.equal(run(model, batch, False), got)                      # ordered compaction: bitwise reproducible
