@@ -188,6 +188,33 @@ class Run:
         return self._step([t.cuda(non_blocking=True) for t in p])
 
 
+def executed_flops_per_impression(run):
+    """FLOPs the DEFAULT path executes per impression on this run's batches: as flops_per_impression, with the token encoders
+    counted over what newsEncoders.encode_tokens_compact really runs -- the live sequences + one all-padding representative
+    through the layer, in_proj over the live tokens only.  Also returns the batches' padding statistics."""
+    cfg = run.cfg
+    if cfg.content_encoder != 'CROWN' or getattr(cfg, 'compute_dtype', 'fp32') != 'fp32' or run.name == 'cfg5':
+        return None, None
+    import torch
+    H, T, L = cfg.max_history_num, cfg.max_title_length, cfg.max_abstract_length
+    tot, stats = 0.0, {'title': [0, 0, 0, 0], 'body': [0, 0, 0, 0]}
+    for b in run.batches_cpu:
+        for key, S, (ck, uk) in (('title', T, ('news_title_text', 'user_title_text')), ('body', L, ('news_content_text', 'user_content_text'))):
+            ids = torch.cat([b[ck].reshape(-1, S), b[uk].reshape(-1, S)])
+            live_seq = int((ids != 0).any(dim=1).sum())
+            live_tok = int((ids != 0).sum())
+            n_c = live_seq + 1
+            tot += n_c * (S * (2 * 300 * 300 + 4 * 300 * 512) + 1200 * S * S) + live_tok * 2 * 300 * 900
+            st = stats[key]
+            st[0] += ids.shape[0]; st[1] += live_seq; st[2] += ids.numel(); st[3] += live_tok
+    nb = len(run.batches_cpu)
+    N = run.N
+    user = 50000 * (H + N) + 2400 * N * H + 960000 * H + 320800 * N + 320000
+    per_imp = tot / nb / run.B + (H + N) * 6854800 + user
+    pad = {k: {'sequences': v[0] // nb, 'live_sequences': round(v[1] / nb, 1), 'live_token_fraction': round(v[3] / v[2], 4)} for k, v in stats.items()}
+    return per_imp, pad
+
+
 def timed(run, steps, warmup, barrier, step=None):
     step = step or run.step
     out = None
@@ -331,6 +358,26 @@ def bench_workload(name, steps, warmup, rank, world, dist, D, args, full=True):
         h2d = {'value_with_h2d': round(world * B * steps / hdt, 2), 'ms_per_step_with_h2d': round(hdt / steps * 1e3, 4),
                'h2d_bytes_per_step': nbytes,
                'h2d_note': 'all 26 input tensors copied from pinned host memory with .cuda(non_blocking=True) inside every step'}
+    dense = None
+    fexec, pad_stats = executed_flops_per_impression(run)
+    if fexec is not None and not train:
+        # the same K steps with the repetition shortcuts OFF: every token of every slot through the encoder layer, as the
+        # reference computes it (newsEncoders.py:311-321) -- what LIME_DENSE_TOKENS=1 runs
+        from lime_cikm25_amd import newsEncoders
+        newsEncoders.DEDUP = False
+        run.model._graphs.clear()
+        try:
+            ddt, dlogits = timed(run, steps, 3, barrier)
+            ddt = D.max_over_ranks(ddt, device='cuda')
+        finally:
+            newsEncoders.DEDUP = True
+            run.model._graphs.clear()
+        dense = {'value': round(world * B * steps / ddt, 2), 'ms_per_step': round(ddt / steps * 1e3, 4),
+                 'note': 'LIME_DENSE_TOKENS=1: every token of every history / candidate slot goes through the encoder layer, padding '
+                         'news and padding tokens included (what the reference computes); `value` is the default path, which encodes '
+                         'all-padding sequences once and runs in_proj over the live tokens -- same logits',
+                 'max_abs_logit_difference_vs_default': float((dlogits.float().cpu() - run.step().float().cpu()).abs().max())
+                 if len(run.batches) == 1 else None}
     by_kernel = kernel_profile(run, min(steps, 20) if full else min(steps, 5)) if rank == 0 else {}
     if dist is not None:
         dist.barrier()
@@ -358,6 +405,17 @@ def bench_workload(name, steps, warmup, rank, world, dist, D, args, full=True):
         'end_to_end': {'flops_per_impression': fimp, 'achieved_tflops': round(value * fimp / 1e12, 2),
                        'frac_of_f32_mfma_peak': round(value * fimp / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4)},
     }
+    if fexec is not None and not train:
+        e2e = out['end_to_end']
+        e2e['note'] = ('flops_per_impression is the DENSE algorithmic count of BASELINE.md section 3 (every slot, every token); the '
+                       'default path executes flops_per_impression_executed on these batches (padding statistics in input_padding), '
+                       'so achieved_tflops is a dense-EQUIVALENT rate and may exceed the MFMA peak; the hardware rate is '
+                       'achieved_tflops_executed')
+        e2e['flops_per_impression_executed'] = round(fexec)
+        e2e['achieved_tflops_executed'] = round(value * fexec / 1e12, 2)
+        e2e['frac_of_f32_mfma_peak_executed'] = round(value * fexec / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4)
+        out['input_padding'] = pad_stats
+        out['dense'] = dense
     if sustained:
         out['sustained'] = sustained
     if h2d:
@@ -372,6 +430,7 @@ def brief(res):
     r = res['roofline'] or {}
     return {'metric': res['metric'], 'value': res['value'], 'unit': res['unit'], 'steps': res['steps'], 'warmup': res['warmup'],
             'ms_per_step': res['ms_per_step'], 'dtype': res['dtype'], 'workload': res['config']['workload'],
+            'dense': res.get('dense'),
             'end_to_end_tflops': res['end_to_end']['achieved_tflops'],
             'dominant_kernel': {k: r.get(k) for k in ('kernel', 'achieved', 'peak', 'frac', 'frac_padded', 'avg_launch_us', 'launches')}}
 

@@ -217,7 +217,7 @@ def token_attention_rows(q, k, v, row_map, n_seq_dev, n_seq, S, n_head, head_dim
 
 class Compacted:
     """Index lists of ``compact_sequences`` (all int32 device tensors; see lime_compact_sequences in include/lime_hip.h)."""
-    __slots__ = ('n_seq', 'S', 'cap', 'seq_inv', 'ids_c', 'row_map', 'tok_ids', 'tok_rows', 'counts')
+    __slots__ = ('n_seq', 'S', 'cap', 'seq_inv', 'seq_src', 'ids_c', 'row_map', 'tok_ids', 'tok_rows', 'counts')
 
     n_compact = property(lambda self: self.counts[0:1])      # device counts as 1-element views (m_dev / n_seq_dev arguments)
     n_rows = property(lambda self: self.counts[1:2])
@@ -242,6 +242,7 @@ def compact_sequences(ids, pad_base=None):
     o += 4 * cap
     c.counts = buf[o:o + 4]
     work = buf[o + 4:]
+    c.seq_src = work[n_seq:2 * n_seq + 1]          # compact -> original sequence (-1: the all-padding representative)
     check(lib.lime_compact_sequences(_p(ids), n_seq, S, cap if pad_base is None else pad_base, _p(c.seq_inv), _p(c.ids_c), _p(c.row_map),
                                      _p(c.tok_ids), _p(c.tok_rows), _p(c.counts), _p(work), _stream()), 'lime_compact_sequences')
     return c

@@ -337,6 +337,47 @@ class _TokenEncoder(torch.autograd.Function):
                 dn1_b, dn2_w, dn2_b)
 
 
+class _SeqExpand(torch.autograd.Function):
+    """pooled[s] = pooled_c[seq_inv[s]]: the compact sequences' pooled vectors back on every slot (all-padding slots share the
+    representative's).  Backward: every live compact row has exactly one slot (a gather by seq_src), the representative's
+    gradient is the sum over the all-padding slots -- a fixed-order torch reduction, no atomics."""
+
+    @staticmethod
+    def forward(ctx, pooled_c, seq_inv, seq_src, n_live):
+        out = torch.empty((seq_inv.numel(), pooled_c.shape[1]), dtype=torch.float32, device=pooled_c.device)
+        ops.gather_rows(seq_inv, pooled_c.contiguous(), out)
+        ctx.save_for_backward(seq_inv, seq_src)
+        ctx.n_live = n_live
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        seq_inv, seq_src = ctx.saved_tensors
+        n_live = ctx.n_live
+        dout = dout.contiguous()
+        d = torch.empty((n_live + 1, dout.shape[1]), dtype=torch.float32, device=dout.device)
+        if n_live:
+            ops.gather_rows(seq_src[:n_live].contiguous(), dout, d[:n_live])
+        pad = (seq_inv == n_live).to(dout.dtype).unsqueeze(1)
+        d[n_live] = (dout * pad).sum(dim=0)
+        return d, None, None, None
+
+
+# Training with every dropout off (p = 0): an all-padding sequence pools to the same vector in every slot, so the encoder runs on
+# the live sequences + one representative, forward and backward (the representative collects the gradients of all its slots).
+# With dropout on every slot draws its own masks (the reference's behaviour) and nothing is shared.  LIME_DENSE_TOKENS=1 turns
+# it off, as on the scoring path.
+def _dedup_sequences(ids):
+    from . import newsEncoders
+    if not newsEncoders.DEDUP or ids.shape[0] < 64:
+        return None
+    cmp = ops.compact_sequences(ids)
+    n_c, _, _, n_live = (int(v) for v in cmp.counts.tolist())          # one host read per encoder call (the step is eager)
+    if n_c >= ids.shape[0]:
+        return None                                                    # nothing repeats
+    return cmp, n_c, n_live
+
+
 def _draw_seed():
     """A fresh 62-bit seed from torch's CPU generator (torch.manual_seed makes a run repeatable)."""
     return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
@@ -356,10 +397,18 @@ def encode_tokens(ids, table, pos_encoder, transformer, nhead, p_embedding=0.0):
         raise NotImplementedError('the HIP encoder layer applies one dropout probability to all of its sites; got %s (embedding, '
                                   'positional, attention, dropout1, dropout, dropout2): put the news encoder into one mode' % ps)
     p = float(ps[0])
-    return _TokenEncoder.apply(ids.contiguous(), nhead, layer.norm1.eps, layer.norm2.eps, p, _draw_seed() if p > 0 else 0, table,
-                               pos_encoder.table(), sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias,
-                               layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, layer.norm1.weight,
-                               layer.norm1.bias, layer.norm2.weight, layer.norm2.bias)
+    ids = ids.contiguous()
+    dd = _dedup_sequences(ids) if p == 0 else None
+    run = lambda rows: _TokenEncoder.apply(rows, nhead, layer.norm1.eps, layer.norm2.eps, p, _draw_seed() if p > 0 else 0, table,
+                                           pos_encoder.table(), sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias,
+                                           layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias,
+                                           layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias)
+    if dd is None:
+        return run(ids)
+    cmp, n_c, n_live = dd
+    S = ids.shape[1]
+    pooled_c = run(cmp.ids_c[:n_c * S].view(n_c, S))
+    return _SeqExpand.apply(pooled_c, cmp.seq_inv, cmp.seq_src, n_live)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -143,3 +143,31 @@ def test_model_with_and_without_dedup(mode, monkeypatch):
         assert rel_err(got.numpy(), want.numpy()) < 1e-3
         monkeypatch.setattr(newsEncoders, 'DEDUP', True)
         assert torch.equal(run(model, batch, False), got)                      # ordered compaction: bitwise reproducible
+
+
+def test_training_gradients_with_and_without_dedup(monkeypatch):
+    """Training step's forward + backward (dropout off) with the all-padding sequences encoded once -- the representative
+    collects the gradients of all its slots -- against the same step with every slot encoded: loss and every parameter
+    gradient (fixed-order reductions on both sides; the difference is fp32 summation order)."""
+    from lime_cikm25_amd.training import negative_log_softmax
+    cfg = make_config(vocabulary_size=4000, max_history_num=20, max_title_length=32, max_abstract_length=64, batch_size=16)
+    model, sd = gpu_model(cfg, seed=33)
+    model.eval()
+    model.training = True
+    batch = [v.cuda() for v in synth.make_batch(cfg, 16, 5, seed=34).values()]
+    grads = {}
+    for flag in (True, False):
+        monkeypatch.setattr(newsEncoders, 'DEDUP', flag)
+        model.zero_grad(set_to_none=True)
+        loss = negative_log_softmax(model(*batch))
+        loss.backward()
+        grads[flag] = (float(loss.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    (l1, g1), (l0, g0) = grads[True], grads[False]
+    assert abs(l1 - l0) < 1e-6 * max(1.0, abs(l0)) and set(g1) == set(g0) and len(g1) > 40
+    worst = 0.0
+    for k in g0:
+        a, b = g1[k].double(), g0[k].double()
+        scale = float(b.abs().max()) + 1e-12
+        worst = max(worst, float((a - b).abs().max()) / scale)
+    print('dedup vs dense gradients: worst max-normalised difference %.2e' % worst)
+    assert worst < 2e-5
