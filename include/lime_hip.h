@@ -130,6 +130,9 @@ typedef struct {
     int32_t act;
     int32_t pool32;       /* 1: LayerNorm epilogue with a bf16 residual (res_kind 3) only; M % 32 == 0; fp32 block means */
     int32_t reserved;     /* must be 0 */
+    const int32_t* m_dev; /* optional device int: min(*m_dev, M) rows are computed (see lime_linear_args.m_dev) */
+    const int32_t* c_ids; /* optional int32 [M]: result row r goes to c[c_ids[r] * ldc], the fp32 periodic residual (res_kind 1 with
+                             res_mod > 0) is indexed by c_ids[r] % res_mod; no LayerNorm, act none (see lime_linear_args.c_ids) */
 } lime_linear_bf16_args;
 
 int lime_linear_bf16(const lime_linear_bf16_args* args, void* stream);
@@ -193,6 +196,12 @@ int lime_token_attention_rows_f32(const float* q, const float* k, const float* v
 int lime_compact_sequences(const int32_t* ids, int32_t n_seq, int32_t S, int32_t pad_base, int32_t* seq_inv, int32_t* ids_c,
                            int32_t* row_map, int32_t* tok_ids, int32_t* tok_rows, int32_t* counts, int32_t* work, void* stream);
 int64_t lime_compact_sequences_workspace(int32_t n_seq);
+
+/* lime_token_attention_rows_bf16: lime_token_attention_bf16 over compacted sequences (row_map / n_seq_dev as in
+ * lime_token_attention_rows_f32); S in {32, 64, 128}, even head_dim. */
+int lime_token_attention_rows_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ld_qkv, const int32_t* row_map,
+                                   const int32_t* n_seq_dev, uint16_t* out, int64_t ldo, int32_t n_seq, int32_t S, int32_t n_head,
+                                   int32_t head_dim, float scale, int32_t out_cols, void* stream);
 
 /*
  * lime_token_attention_bf16: the unmasked encoder-layer attention on bf16 storage (config 3): q / k / v bf16 with every

@@ -47,6 +47,7 @@ class LinearBf16Args(ctypes.Structure):
         ('M', c_int32), ('N', c_int32), ('K', c_int32),
         ('act', c_int32),
         ('pool32', c_int32), ('reserved', c_int32),
+        ('m_dev', c_void_p), ('c_ids', c_void_p),
     ]
 
 
@@ -78,6 +79,8 @@ SIGNATURES = {
                                            c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
     'lime_token_attention_rows_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                                 c_int32, c_int32, c_int32, c_float, c_void_p]),
+    'lime_token_attention_rows_bf16': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                                                 c_int32, c_int32, c_int32, c_float, c_int32, c_void_p]),
     'lime_compact_sequences': (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p]),
     'lime_compact_sequences_workspace': (c_int64, [c_int32]),

@@ -691,7 +691,13 @@ extern "C" int lime_linear_bf16(const lime_linear_bf16_args* a, void* stream) {
     p.ln_g = a->ln_gamma; p.ln_b = a->ln_beta; p.ln_eps = a->ln_eps; p.ln_rstd = nullptr;
     p.c = (float*)a->c; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K; p.ln_count = ln ? a->ln_count : a->N;
     p.n_row_blocks = p.n_col_blocks = 0;
-    p.m_dev = nullptr; p.c_ids = nullptr;
+    p.m_dev = a->m_dev; p.c_ids = a->c_ids;
+    if (a->c_ids) {
+        LIME_REQUIRE(a->res_kind == 1 && a->res_mod > 0 && !ln && !relu && bn == 320 && (long)a->M * a->ldc * 2 < lim, LIME_ERR_UNSUPPORTED,
+                     "lime_linear_bf16: c_ids needs the fp32 periodic residual (res_kind 1, res_mod > 0), no LayerNorm / activation, N in "
+                     "320-column blocks and M * ldc * 2 < 2 GB");
+        return launch<10, false, false, 1, true, false, false, true>(p, (hipStream_t)stream);
+    }
     hipStream_t s = (hipStream_t)stream;
     if (ln) {
         switch (a->res_kind) {

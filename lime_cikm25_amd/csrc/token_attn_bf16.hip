@@ -28,6 +28,8 @@ constexpr float LOG2E = 1.4426950408889634f;
 struct AttnB {
     const unsigned short* q; const unsigned short* k; const unsigned short* v; long ld;
     unsigned short* out; long ldo; int n_seq, S, n_head, hd; float scale; int n_pair, n_group, out_pad;
+    const int* row_map;      // MAP: q / k / v row of token (seq * S + t) is row_map[seq * S + t] (lime_compact_sequences)
+    const int* n_seq_dev;    // MAP: optional device-side sequence count
 };
 
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {          // two floats -> two bf16 (round to nearest even)
@@ -37,7 +39,7 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {          // two 
     return (a >> 16) | (b & 0xFFFF0000u);
 }
 
-template <int NT>
+template <int NT, bool MAP = false>
 __global__ __launch_bounds__(256, (NT <= 2) ? 4 : 3) void token_attn_bf16_kernel(const AttnB p) {
     constexpr int G = 4 / NT;                      // (sequence, head) pairs per group: 4, 2, 1
     constexpr int SP = NT * 32;                    // sequence length
@@ -50,6 +52,16 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 4 : 3) void token_attn_bf16_kernel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fi = lane & 31, fh = lane >> 5;
     const int S = p.S, hd = p.hd;
+    int n_pair = p.n_pair, n_group = p.n_group;
+    if constexpr (MAP) {
+        if (p.n_seq_dev) {
+            int ns = __builtin_amdgcn_readfirstlane(*p.n_seq_dev);
+            ns = ns < p.n_seq ? (ns > 0 ? ns : 0) : p.n_seq;
+            n_pair = ns * p.n_head;
+            n_group = (n_pair + 4 / NT - 1) / (4 / NT);
+        }
+        if (n_group == 0) return;
+    }
     // wave -> (pair of the group, query tile): NT waves per pair, one 32-query tile each
     const int g = wave / NT, qt = wave % NT;
 
@@ -60,16 +72,20 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 4 : 3) void token_attn_bf16_kernel
             const int e = tid + i * 256;
             const int c = (e & 3) * 8, r = (e >> 2) % SP, gg = (e >> 2) / SP;
             int pair = group * G + gg;
-            pair = pair < p.n_pair ? pair : p.n_pair - 1;
+            pair = pair < n_pair ? pair : n_pair - 1;
             const int seq = pair / p.n_head, head = pair - seq * p.n_head;
-            const long off = ((long)seq * S + r) * p.ld + head * 32 + c;
+            long row = (long)seq * S + r;
+            if constexpr (MAP) row = p.row_map[row];
+            const long off = row * p.ld + head * 32 + c;
             kreg[i] = *reinterpret_cast<const u32x4*>(p.k + off);
             vreg[i] = *reinterpret_cast<const u32x4*>(p.v + off);
         }
         int pr = group * G + g;
-        pr = pr < p.n_pair ? pr : p.n_pair - 1;
+        pr = pr < n_pair ? pr : n_pair - 1;
         const int sq = pr / p.n_head, hh = pr - sq * p.n_head;
-        const unsigned short* qsrc = p.q + ((long)sq * S + qt * 32 + fi) * p.ld + hh * 32 + 8 * fh;
+        long qrow = (long)sq * S + qt * 32 + fi;
+        if constexpr (MAP) qrow = p.row_map[qrow];
+        const unsigned short* qsrc = p.q + qrow * p.ld + hh * 32 + 8 * fh;
         qnext[0] = *reinterpret_cast<const u32x4*>(qsrc);              // d = 8 fh .. + 7
         qnext[1] = *reinterpret_cast<const u32x4*>(qsrc + 16);         // d = 16 + 8 fh .. + 7
     };
@@ -79,7 +95,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 4 : 3) void token_attn_bf16_kernel
             const int e = tid + i * 256;
             const int c = (e & 3) * 8, r = (e >> 2) % SP, gg = (e >> 2) / SP;
             u32x4 kb = kreg[i], vb = vreg[i];
-            if (group * G + gg >= p.n_pair) { kb = u32x4{0u, 0u, 0u, 0u}; vb = kb; }
+            if (group * G + gg >= n_pair) { kb = u32x4{0u, 0u, 0u, 0u}; vb = kb; }
             *reinterpret_cast<u32x4*>(&Kb[(gg * SP + r) * KP + c]) = kb;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -96,16 +112,16 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 4 : 3) void token_attn_bf16_kernel
 
     int group = blockIdx.x;
     fetch(group);
-    for (; group < p.n_group; group += gridDim.x) {
+    for (; group < n_group; group += gridDim.x) {
         stash(group);
         qreg[0] = qnext[0];
         qreg[1] = qnext[1];
         lds_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (group + (int)gridDim.x < p.n_group) fetch(group + gridDim.x);       // in flight under this group's work
+        if (group + (int)gridDim.x < n_group) fetch(group + gridDim.x);       // in flight under this group's work
         __builtin_amdgcn_sched_barrier(0);
         const int pair = group * G + g;
-        if (pair < p.n_pair) {
+        if (pair < n_pair) {
             const int seq = pair / p.n_head, head = pair - seq * p.n_head;
             // ---- S^T = K Q^T ---------------------------------------------------------------------------------------
             f32x16 sc[NT];
@@ -200,13 +216,13 @@ int attn_cus() {
     return n;
 }
 
-template <int NT>
+template <int NT, bool MAP = false>
 int launch(AttnB p, hipStream_t s) {
     constexpr int G = 4 / NT;
     p.n_group = (p.n_pair + G - 1) / G;
     long blocks = (long)attn_cus() * (NT <= 2 ? 4 : 3);            // 36 KB LDS, <= 128 / 170 VGPRs: 4 / 3 workgroups per CU
     if (blocks > p.n_group) blocks = p.n_group;
-    hipLaunchKernelGGL((token_attn_bf16_kernel<NT>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((token_attn_bf16_kernel<NT, MAP>), dim3((unsigned)blocks), dim3(256), 0, s, p);
     return lime_check_launch("lime_token_attention_bf16");
 }
 
@@ -219,10 +235,32 @@ int lime_token_attention_bf16_mfma(const uint16_t* q, const uint16_t* k, const u
                                    hipStream_t s) {
     if (!(S == 32 || S == 64 || S == 128) || scale <= 0.f) return 1;
     if ((uintptr_t)out % 4 != 0 || ldo % 2 != 0 || head_dim % 2 != 0) return 1;        // 4-byte output stores
-    AttnB p{q, k, v, (long)ld_qkv, out, (long)ldo, n_seq, S, n_head, head_dim, scale, n_seq * n_head, 0, out_pad};
+    AttnB p{q, k, v, (long)ld_qkv, out, (long)ldo, n_seq, S, n_head, head_dim, scale, n_seq * n_head, 0, out_pad, nullptr, nullptr};
     switch (S / 32) {
         case 1: return launch<1>(p, s);
         case 2: return launch<2>(p, s);
         default: return launch<4>(p, s);
+    }
+}
+
+extern "C" int lime_token_attention_rows_bf16(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ld_qkv, const int32_t* row_map,
+                                              const int32_t* n_seq_dev, uint16_t* out, int64_t ldo, int32_t n_seq, int32_t S, int32_t n_head,
+                                              int32_t head_dim, float scale, int32_t out_cols, void* stream) {
+    LIME_REQUIRE(q && k && v && out && row_map, LIME_ERR_BAD_ARG, "lime_token_attention_rows_bf16: NULL pointer");
+    LIME_REQUIRE(n_seq >= 0 && n_head > 0 && head_dim > 0 && head_dim <= 32 && head_dim % 2 == 0 && scale > 0.f, LIME_ERR_BAD_ARG,
+                 "lime_token_attention_rows_bf16: bad dims n_seq=%d n_head=%d head_dim=%d", n_seq, n_head, head_dim);
+    LIME_REQUIRE(S == 32 || S == 64 || S == 128, LIME_ERR_UNSUPPORTED, "lime_token_attention_rows_bf16: S must be 32, 64 or 128 (got %d)", S);
+    LIME_REQUIRE(ld_qkv >= (int64_t)n_head * 32 && ld_qkv % 8 == 0 && (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0),
+                 LIME_ERR_BAD_ARG, "lime_token_attention_rows_bf16: heads are 32 bf16 columns apart, rows 16-byte aligned");
+    const int pad = out_cols - n_head * head_dim;
+    LIME_REQUIRE(pad >= 0 && pad <= 32 && ldo >= out_cols && (uintptr_t)out % 4 == 0 && ldo % 2 == 0, LIME_ERR_BAD_ARG,
+                 "lime_token_attention_rows_bf16: out_cols must be in [n_head * head_dim, n_head * head_dim + 32] and <= ldo (even)");
+    if (n_seq == 0) return LIME_OK;
+    AttnB p{q, k, v, (long)ld_qkv, out, (long)ldo, n_seq, S, n_head, head_dim, scale, n_seq * n_head, 0, pad, row_map, n_seq_dev};
+    hipStream_t s = (hipStream_t)stream;
+    switch (S / 32) {
+        case 1: return launch<1, true>(p, s);
+        case 2: return launch<2, true>(p, s);
+        default: return launch<4, true>(p, s);
     }
 }

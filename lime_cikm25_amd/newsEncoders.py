@@ -545,6 +545,52 @@ def encode_tokens_bf16(ids, table_bf16, pe, transformer, nhead, pooled_out):
     return ops.mean_pool_bf16(x, M, S, E, out=pooled_out)
 
 
+def encode_tokens_bf16_compact(ids, table_bf16, pe, transformer, nhead, pooled_out):
+    """``encode_tokens_bf16`` on the compacted batch (see ``encode_tokens_compact``): live sequences + one all-padding
+    representative through the layer, in_proj over the live tokens, the row-map bf16 attention.  The S padding rows come from
+    the same bf16 GEMM kernel as the live rows (lime_linear_bf16 takes any M)."""
+    M, S = ids.shape
+    EP = table_bf16.shape[1]
+    E = pe.shape[1]
+    hd = E // nhead
+    W = nhead * 32
+    layer = transformer.layers[0]
+    sa = layer.self_attn
+    dev = ids.device
+    cap = (M + 1) * S
+    padv = lambda v: torch.cat([v, v.new_zeros(EP - E)])
+    cmp = ops.compact_sequences(ids)
+    w_in = ops.pad_heads(sa.in_proj_weight, 3 * nhead, hd, 32)
+    b_in = ops.pad_heads(sa.in_proj_bias, 3 * nhead, hd, 32)
+    w_in_b = ops.to_bf16(w_in, cols_out=EP)
+    pew = ops.linear(pe[:S], w_in, b_in)                                       # fp32 [S, 3W]
+    qkv = torch.empty((cap + S, 3 * W), dtype=torch.bfloat16, device=dev)
+    zeros = torch.zeros(S, dtype=torch.int32, device=dev)
+    ops.linear_bf16(table_bf16, w_in_b, None, a_ids=zeros, res=pew, res_kind=1, res_mod=S, out=qkv[cap:])
+    ops.linear_bf16(table_bf16, w_in_b, None, a_ids=cmp.tok_ids, res=pew, res_kind=1, res_mod=S, out=qkv[:cap], m_dev=cmp.n_live_tokens,
+                    c_ids=cmp.tok_rows, n_alg=3 * E, k_alg=E)
+    attn = ops.token_attention_rows_bf16(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], cmp.row_map, cmp.n_compact, M + 1, S, nhead, hd,
+                                         1.0 / math.sqrt(hd), out_cols=EP)
+    w_o = ops.to_bf16(sa.out_proj.weight, rows_out=EP, cols_out=EP)
+    pe_p = torch.cat([pe[:S], pe.new_zeros(S, EP - E)], dim=1)
+    x1 = ops.linear_bf16(attn, w_o, padv(sa.out_proj.bias), res=table_bf16, res_kind=2, res_ids=cmp.ids_c, res_pe=pe_p, res_period=S,
+                         ln=(padv(layer.norm1.weight), padv(layer.norm1.bias)), ln_eps=layer.norm1.eps, ln_count=E, n_alg=E, k_alg=E,
+                         m_dev=cmp.n_rows)
+    h = ops.linear_bf16(x1, ops.to_bf16(layer.linear1.weight, cols_out=EP), layer.linear1.bias, act='relu', k_alg=E, m_dev=cmp.n_rows)
+    blocks = ops.linear_bf16(h, ops.to_bf16(layer.linear2.weight, rows_out=EP), padv(layer.linear2.bias), res=x1, res_kind=3,
+                             ln=(padv(layer.norm2.weight), padv(layer.norm2.bias)), ln_eps=layer.norm2.eps, ln_count=E, pool32=True,
+                             n_alg=E, m_dev=cmp.n_rows)                         # fp32 [cap / 32, EP] block means
+    pooled_c = ops.mean_pool(blocks[:, :E], M + 1, S // 32)
+    ops.gather_rows(cmp.seq_inv, pooled_c, pooled_out)
+    return None
+
+
+def compact_applicable_bf16(ids, transformer, nhead, E):
+    M, S = ids.shape
+    return (DEDUP and len(transformer.layers) == 1 and transformer.norm is None and E % nhead == 0 and E // nhead <= 32 and
+            (E // nhead) % 2 == 0 and S in (32, 64, 128) and (M + 1) * S >= 4096 and ids.dtype == torch.int32 and ids.is_contiguous())
+
+
 class CROWN(NewsEncoder):
     """newsEncoders.py:228-373: title/body transformer encoders, mean pooling, category-aware k-intent
     disentanglement, intent attention, title-body similarity, feature fusion.  -> [B, n, 900]."""
@@ -630,8 +676,8 @@ class CROWN(NewsEncoder):
         encoders = ((title_text, self.title_pos_encoder, self.title_transformer, T),
                     (content_text, self.body_pos_encoder, self.body_transformer, L))
         step_of = lambda S: min(max(1, MAX_TOKENS_PER_PASS // S),
-                                # the compacted in_proj scatters rows with 32-bit byte offsets from the base of qkv ([rows, 3 * 320] fp32)
-                                max(1, (0x7FFFFFF0 // (3 * self.head_num * 32 * 4)) // S - 2) if (DEDUP and not bf16) else M)
+                                # the compacted in_proj scatters rows with 32-bit byte offsets from the base of qkv ([rows, 3 * 320])
+                                max(1, (0x7FFFFFF0 // (3 * self.head_num * 32 * (2 if bf16 else 4))) // S - 2) if DEDUP else M)
         one_pass = (not bf16 and all(M <= step_of(S) and compact_applicable(ids, table, tr, self.head_num)
                                      for ids, pos, tr, S in encoders))
         if one_pass:
@@ -655,8 +701,8 @@ class CROWN(NewsEncoder):
                     for m0 in range(0, M, step):
                         m1 = min(M, m0 + step)
                         if bf16:
-                            encode_tokens_bf16(ids[m0:m1], table_b, pos.table(), tr, self.head_num,
-                                               xin[half * M + m0:half * M + m1, :E])
+                            enc_b = encode_tokens_bf16_compact if compact_applicable_bf16(ids[m0:m1], tr, self.head_num, E) else encode_tokens_bf16
+                            enc_b(ids[m0:m1], table_b, pos.table(), tr, self.head_num, xin[half * M + m0:half * M + m1, :E])
                             continue
                         if compact_applicable(ids[m0:m1], table, tr, self.head_num):
                             encode_tokens_compact(ids[m0:m1], table, pos.table(), tr, self.head_num,

@@ -490,7 +490,7 @@ def to_bf16(src, rows_out=None, cols_out=None, out=None):
 
 
 def linear_bf16(a, w, bias=None, act=None, out=None, a_ids=None, res=None, res_kind=0, res_mod=0, res_ids=None, res_pe=None,
-                res_period=0, ln=None, ln_eps=1e-5, ln_count=None, pool32=False, n_alg=None, k_alg=None):
+                res_period=0, ln=None, ln_eps=1e-5, ln_count=None, pool32=False, n_alg=None, k_alg=None, m_dev=None, c_ids=None):
     """``lime_linear_bf16``: a / w / out (and residual kinds 2, 3) bfloat16, bias / LayerNorm / residual kind 1 fp32."""
     lib = _lib.load()
     _mat(a, 'a', dtype=torch.bfloat16)
@@ -505,9 +505,16 @@ def linear_bf16(a, w, bias=None, act=None, out=None, a_ids=None, res=None, res_k
     if out is None:
         out = torch.empty((rows_out, N), dtype=odt, device=a.device)
     _mat(out, 'out', dtype=odt)
-    if tuple(out.shape) != (rows_out, N):
+    if c_ids is not None:
+        if out.shape[1] != N:
+            raise ValueError('out must have N columns')
+    elif tuple(out.shape) != (rows_out, N):
         raise ValueError('out must be [%d, %d], got %s' % (rows_out, N, tuple(out.shape)))
     args = _lib.LinearBf16Args()
+    if c_ids is not None:
+        args.c_ids = _vec(c_ids, 'c_ids', M, dtype=torch.int32).data_ptr()
+    if m_dev is not None:
+        args.m_dev = _vec(m_dev, 'm_dev', 1, dtype=torch.int32).data_ptr()
     args.pool32 = 1 if pool32 else 0
     args.a, args.lda = a.data_ptr(), _ld(a)
     args.a_ids = _vec(a_ids, 'a_ids', dtype=torch.int32).data_ptr() if a_ids is not None else None
@@ -543,7 +550,8 @@ def linear_bf16(a, w, bias=None, act=None, out=None, a_ids=None, res=None, res_k
         e0.record()
         check(lib.lime_linear_bf16(ctypes.byref(args), _stream()), 'lime_linear_bf16')
         e1.record()
-        PROFILE.append((lib.lime_last_linear_kernel().decode(), M, N, k_alg or K, n_alg or N, e0, e1))
+        m_run = M if m_dev is None else min(M, int(m_dev.item()))
+        PROFILE.append((lib.lime_last_linear_kernel().decode(), m_run, N, k_alg or K, n_alg or N, e0, e1))
         return out
     check(lib.lime_linear_bf16(ctypes.byref(args), _stream()), 'lime_linear_bf16')
     return out
@@ -558,6 +566,29 @@ def mean_pool_bf16(x, n_seq, S, dim, out=None):
         out = torch.empty((n_seq, dim), dtype=torch.float32, device=x.device)
     _mat(out, 'out')
     check(lib.lime_mean_pool_bf16(_p(x), _ld(x), _p(out), _ld(out), n_seq, S, dim, _stream()), 'lime_mean_pool_bf16')
+    return out
+
+
+def token_attention_rows_bf16(q, k, v, row_map, n_seq_dev, n_seq, S, n_head, head_dim, scale, out_cols=None, out=None):
+    """``lime_token_attention_rows_bf16``: the bf16 attention over compacted sequences (see ``token_attention_rows``)."""
+    lib = _lib.load()
+    for t, n in ((q, 'q'), (k, 'k'), (v, 'v')):
+        _mat(t, n, dtype=torch.bfloat16)
+        if t.shape[1] != n_head * 32:
+            raise ValueError('%s must have n_head * 32 columns' % n)
+    if not (_ld(q) == _ld(k) == _ld(v)):
+        raise ValueError('q, k and v must share one leading dimension')
+    _vec(row_map, 'row_map', dtype=torch.int32)
+    if row_map.numel() < n_seq * S:
+        raise ValueError('row_map must cover n_seq * S tokens')
+    if n_seq_dev is not None:
+        _vec(n_seq_dev, 'n_seq_dev', 1, dtype=torch.int32)
+    out_cols = n_head * head_dim if out_cols is None else out_cols
+    if out is None:
+        out = torch.empty((n_seq * S, out_cols), dtype=torch.bfloat16, device=q.device)
+    _mat(out, 'out', dtype=torch.bfloat16)
+    check(lib.lime_token_attention_rows_bf16(_p(q), _p(k), _p(v), _ld(q), _p(row_map), _p(n_seq_dev), _p(out), _ld(out), n_seq, S, n_head,
+                                             head_dim, scale, out_cols, _stream()), 'lime_token_attention_rows_bf16')
     return out
 
 

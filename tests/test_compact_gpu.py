@@ -171,3 +171,21 @@ def test_training_gradients_with_and_without_dedup(monkeypatch):
         worst = max(worst, float((a - b).abs().max()) / scale)
     print('dedup vs dense gradients: worst max-normalised difference %.2e' % worst)
     assert worst < 2e-5
+
+
+def test_bf16_model_with_and_without_dedup(monkeypatch):
+    """The bf16 token encoders (BASELINE config 3 arithmetic) on the compacted batch against the same model with every slot
+    encoded: the live rows, the padding rows and the layer behind them come from the same kernels with the same per-row
+    arithmetic."""
+    cfg = make_config(vocabulary_size=50000, compute_dtype='bf16')
+    model, sd = gpu_model(cfg, seed=29)
+    batch = synth.make_batch(cfg, 32, 5, seed=30)
+    monkeypatch.setattr(newsEncoders, 'DEDUP', True)
+    got = run(model, batch, False)
+    model._graphs.clear()
+    monkeypatch.setattr(newsEncoders, 'DEDUP', False)
+    dense = run(model, batch, False)
+    model._graphs.clear()
+    e = rel_err(got.numpy(), dense.numpy())
+    print('bf16 dedup vs dense %.2e' % e)
+    assert torch.isfinite(got).all() and e < 1e-5
