@@ -443,6 +443,9 @@ def main():
     ap.add_argument('--workload', default='cfg2b', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-also', action='store_true', help='skip the other BASELINE configurations beside the default line')
+    ap.add_argument('--plain', action='store_true',
+                    help='only the warm-up and the K timed steps of the default path (for rocprofv3 --pmc / --kernel-trace passes: no dense '
+                         'run, no sustained / H2D regions, no instrumented pass, no CPU baseline)')
     ap.add_argument('--overlap-streams', action='store_true',
                     help='fork the title / body / freshness / attention-weight branches onto side streams in the timed region')
     args = ap.parse_args()
@@ -469,6 +472,13 @@ def main():
         backend = os.environ.get('LIME_BENCH_BACKEND', 'gloo' if shared else 'nccl')
         D.init(backend=backend, device_id=torch.device('cuda', local_rank % ndev) if backend == 'nccl' else None)
 
+    if args.plain:
+        run = Run(args.workload, rank, world)
+        sync = torch.cuda.synchronize
+        dt, _ = timed(run, args.steps, args.warmup, sync)
+        print(json.dumps({'workload': args.workload, 'steps': args.steps, 'ms_per_step': round(dt / args.steps * 1e3, 4),
+                          'value': round(run.B * args.steps / dt, 2)}), flush=True)
+        return
     res = bench_workload(args.workload, args.steps, args.warmup, rank, world, dist, D, args, full=True)
     if rank == 0 and world == 1 and args.workload == 'cfg2b' and not args.no_also:
         also = {}

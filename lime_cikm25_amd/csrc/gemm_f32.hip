@@ -673,5 +673,9 @@ extern "C" int lime_linear_f32(const lime_linear_args* a, void* stream) {
         if (pe) return relu ? launch_one<1, 4, 4, 2, 4, false, true, 1, false, true>(p, 1, s) : launch_one<1, 4, 4, 2, 4, false, true, 0, false, true>(p, 1, s);
         return relu ? launch_one<1, 4, 4, 2, 4, false, false, 1, false, true>(p, 1, s) : launch_one<1, 4, 4, 2, 4, false, false, 0, false, true>(p, 1, s);
     }
+    {   // small / mid M (and anything the big-tile kernels above do not take): the deep-prefetch LDS-DMA kernel (gemm_mid_f32.hip)
+        const int st = lime_linear_mid(a, s);
+        if (st != LIME_PP_NOT_APPLICABLE) return st;
+    }
     return launch_small(p, vec, s);
 }

@@ -1,0 +1,175 @@
+// lime_linear_f32, small / mid-M instantiation: the GEMMs around the token encoders (M = 32 ... ~10 k rows: intent layers,
+// intent attention, LIME.project, gate_proj, SAGEConv, K / Q, the positional table through in_proj; K = 300 ... 1800).
+//
+// These launches are LATENCY bound, not throughput bound: a 64 x 64 tile of a K = 400 problem is 3 MFLOP (5 us at one CU's
+// MFMA rate) and there are fewer tiles than workgroup slots, so the time of a launch is the time of ONE tile's k loop.  The
+// register-staged kernel of gemm_f32.hip keeps one 32-deep chunk in flight (0.4 us of MFMAs against > 1 us of L2 / HBM load
+// latency): 17 us for [1600, 400] x [400, 400], 54 us for K = 1800.  Here the operands go global -> LDS by LDS-DMA
+// (buffer_load_dwordx4 ... lds: no staging registers, no ds_write) into a ring of SIX 16-deep stages, five chunks ahead of
+// the MFMAs (1 us of cover), one barrier per chunk; a workgroup computes one 64 x 64 tile and exits (48 KB LDS, three per
+// CU).  Same operand image, swizzle and transposed product as gemm_pp_f32.hip (D^T = W A^T on v_mfma_f32_16x16x4_f32: an
+// output row's 4 consecutive columns sit in one lane -> 16-byte bias / residual loads and result stores).
+//
+// Epilogue: out = act(acc + bias) + residual, act in {none, ReLU, tanh, sigmoid}; residual row of output row r:
+// res_ids[r] (gathered), (r / res_div) % res_mod (periodic table) or r / res_div (dense / broadcast rows).  A rows may be
+// gathered (a_ids).  No LayerNorm / pooling here (those shapes are the big-M kernel's).
+#include "common.h"
+#include "gemm_pp.h"
+
+namespace {
+
+constexpr int MB = 64, NB = 64, KB = 16, NS = 6;
+constexpr unsigned OOB = 0x80000000u;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct MidP {
+    const float* a; long lda; const int* a_ids;
+    const float* w; long ldw; const float* bias;
+    const float* res; long ldr; int res_div, res_mod; const int* res_ids;
+    float* c; long ldc; int M, N, K, act, n_col_blocks;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFF0, 0x00020000);
+}
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, float* lds_base, unsigned voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds_base, 16, voff, soff, 0, 0);
+#endif
+}
+__device__ __forceinline__ int swz4(int q) { return (0x78 >> (2 * q)) & 3; }        // see gemm_pp_f32.hip
+
+__device__ __forceinline__ float act_fn(float v, int act) {
+    if (act == LIME_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == LIME_ACT_TANH) return tanhf(v);
+    if (act == LIME_ACT_SIGMOID) return lime_sigmoid(v);
+    return v;
+}
+
+__global__ __launch_bounds__(256, 3) void gemm_mid_kernel(const MidP p) {
+    constexpr int A_ST = MB * KB, STAGE = (MB + NB) * KB;               // floats
+    __shared__ __attribute__((aligned(16))) float lds[NS * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, kg = lane >> 4;
+    const int rb = blockIdx.x / p.n_col_blocks;
+    const int row0 = rb * MB, col0 = (blockIdx.x - rb * p.n_col_blocks) * NB;
+
+    // ---- loader: this wave stages A rows 16 wave .. + 15 and W rows 16 wave .. + 15 of every chunk (one 1 KB DMA each) ----
+    const int srow = lane >> 2;
+    const int lseg = (lane & 3) ^ swz4((lane >> 4) & 3);
+    const int lda4 = (int)p.lda * 4, ldw4 = (int)p.ldw * 4;
+    const bool gather = p.a_ids != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_a = mk_rsrc(gather ? (const char*)p.a : (const char*)p.a + (long)row0 * p.lda * 4);
+    const __amdgpu_buffer_rsrc_t rs_w = mk_rsrc((const char*)p.w + (long)col0 * p.ldw * 4);
+    unsigned a_voff, w_voff;
+    {
+        const int rl = 16 * wave + srow;
+        unsigned rowsel = (unsigned)rl;
+        if (gather && row0 + rl < p.M) rowsel = (unsigned)p.a_ids[row0 + rl];
+        a_voff = (row0 + rl < p.M) ? rowsel * (unsigned)lda4 + (unsigned)lseg * 16u : OOB;
+        w_voff = (col0 + rl < p.N) ? (unsigned)rl * (unsigned)ldw4 + (unsigned)lseg * 16u : OOB;
+    }
+    const int nchunk = (p.K + KB - 1) / KB;
+    auto issue = [&](int c) {                       // chunk c -> stage c % NS; beyond K (or beyond the last chunk): zeros
+        const bool kin = c * KB + lseg * 4 < p.K;
+        float* const sb = lds + (c % NS) * STAGE;
+        dma16(rs_a, sb + wave * 256, kin ? a_voff : OOB, c * 64);
+        dma16(rs_w, sb + A_ST + wave * 256, kin ? w_voff : OOB, c * 64);
+    };
+
+    // ---- compute: wave owns output rows 16 wave .. + 15 x the tile's 64 columns (4 MFMA column tiles) ----------------------
+    const int pseg = (kg ^ swz4((fi >> 2) & 3)) * 4;
+    const int a_off = (16 * wave + fi) * KB + pseg, w_off = A_ST + fi * KB + pseg;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int c = 0; c < NS - 1; ++c) issue(c);
+    // Software pipeline by one chunk: iteration c waits for chunk c + 1, reads ITS fragments into registers and issues the
+    // MFMAs of chunk c behind those reads, so the LDS round trip of a chunk's five ds_read_b128 hides under the previous chunk's
+    // sixteen MFMAs (the exposed read + barrier + issue were ~0.2 us of every 0.4 us chunk).
+    auto read_frags = [&](int c, f32x4& af, f32x4 (&wf)[4]) {
+        const float* sb = lds + (c % NS) * STAGE;
+        af = *reinterpret_cast<const f32x4*>(sb + a_off);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const f32x4*>(sb + w_off + t * 16 * KB);
+    };
+    f32x4 af, wf[4], afn, wfn[4];
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NS - 2)) : "memory");      // chunk 0: this wave's pieces ...
+    lds_barrier();                                                            // ... and everyone's
+    read_frags(0, af, wf);
+    for (int c = 0; c < nchunk; ++c) {
+        // chunk c + 1 has landed when at most the 2 (NS - 3) younger DMA instructions of this wave are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NS - 3)) : "memory");
+        lds_barrier();                              // everyone's pieces of chunk c + 1; and every wave has READ stage c % NS
+        __builtin_amdgcn_sched_barrier(0);
+        issue(c + NS - 1);                          // into stage (c - 1) % NS, whose fragments were read an iteration ago
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(c + 1, afn, wfn);                // (past the last chunk: a zero-filled stage, never used)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][q], af[q], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        af = afn;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wf[t] = wfn[t];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs issued past the last chunk must land before the LDS is released
+
+    // ---- epilogue: lane (fi, kg) holds row 16 wave + fi, columns 16 t + 4 kg .. + 3 -------------------------------------------
+    const int row = row0 + 16 * wave + fi;
+    if (row >= p.M) return;
+    long rrow = -1;
+    if (p.res) {
+        if (p.res_ids) rrow = p.res_ids[row];
+        else if (p.res_mod > 0) rrow = (row / p.res_div) % p.res_mod;
+        else rrow = row / p.res_div;
+    }
+    float* const crow = p.c + (long)row * p.ldc;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int col = col0 + 16 * t + 4 * kg;
+        if (col >= p.N) continue;                   // N % 4 == 0: a group of four is in or out as a whole
+        f32x4 v = acc[t];
+        if (p.bias) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += p.bias[col + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_fn(v[j], p.act);
+        if (rrow >= 0) v += *reinterpret_cast<const f32x4*>(p.res + rrow * p.ldr + col);
+        *reinterpret_cast<f32x4*>(crow + col) = v;
+    }
+}
+
+inline bool al16(const void* ptr, long ld) { return ptr == nullptr || (((uintptr_t)ptr % 16) == 0 && (ld % 4) == 0); }
+
+}  // namespace
+
+// LIME_OK / error: launched; LIME_PP_NOT_APPLICABLE: the caller takes the general kernel.
+int lime_linear_mid(const lime_linear_args* a, hipStream_t s) {
+    static const bool off = getenv("LIME_GEMM_NO_MID") != nullptr;           // A/B switch for tools/, not a product option
+    if (off) return LIME_PP_NOT_APPLICABLE;
+    if (a->ln_gamma || a->pool32 || a->a_pe || a->ln_rstd || a->m_dev || a->c_ids || a->res_pe) return LIME_PP_NOT_APPLICABLE;
+    if (a->K % 4 || a->N % 4 || a->K < 16) return LIME_PP_NOT_APPLICABLE;
+    if (!al16(a->a, a->lda) || !al16(a->w, a->ldw) || !al16(a->c, a->ldc) || !al16(a->res, a->ldr)) return LIME_PP_NOT_APPLICABLE;
+    const long lim = 0x7FFFFFF0L;
+    if (64L * a->lda * 4 >= lim || 64L * a->ldw * 4 >= lim) return LIME_PP_NOT_APPLICABLE;
+    MidP p;
+    p.a = a->a; p.lda = a->lda; p.a_ids = a->a_ids;
+    p.w = a->w; p.ldw = a->ldw; p.bias = a->bias;
+    p.res = a->res; p.ldr = a->ldr; p.res_div = a->res_div > 0 ? a->res_div : 1; p.res_ids = a->res_ids;
+    p.res_mod = (a->res && !a->res_ids && a->res_mod > 0) ? a->res_mod : 0;
+    p.c = a->c; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act;
+    const long n_row_blocks = (a->M + MB - 1) / MB;
+    p.n_col_blocks = (a->N + NB - 1) / NB;
+    const long ntiles = n_row_blocks * p.n_col_blocks;
+    if (ntiles > 0x7FFFFFFFL) return LIME_PP_NOT_APPLICABLE;
+    hipLaunchKernelGGL(gemm_mid_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, p);
+    lime_set_last_linear_kernel("gemm_mid_kernel");
+    return lime_check_launch("lime_linear_f32");
+}

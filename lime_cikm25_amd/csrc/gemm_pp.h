@@ -21,3 +21,4 @@ struct PPParams {
 };
 
 int lime_linear_pp(const lime_linear_args* a, hipStream_t stream);
+int lime_linear_mid(const lime_linear_args* a, hipStream_t stream);      // gemm_mid_f32.hip, same return convention
