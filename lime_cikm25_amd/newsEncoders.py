@@ -671,8 +671,12 @@ class CROWN(NewsEncoder):
                           self.category_affine.bias, out=xin[:M, E:kin], emb_out=out[:, 2 * D:2 * D + Dc + sub_table.shape[1]])
             ops.topic_rep(category, subCategory, self.category_embedding.weight, sub_table, self.category_affine.weight,
                           self.category_affine.bias, out=xin[M:, E:kin])
-            w_int = torch.cat([lin.weight for lin in self.intent_layers], dim=0)
+            # the k intent weight matrices stacked row-wise, K = 350 carried as ldx = 352 zero-padded columns (16-byte rows: the
+            # LDS-DMA GEMM kernels take it; the two pad columns of xin are zeroed to match)
+            w_int = torch.nn.functional.pad(torch.cat([lin.weight for lin in self.intent_layers], dim=0), (0, ldx - kin))
             b_int = torch.cat([lin.bias for lin in self.intent_layers], dim=0)
+            if ldx > kin:
+                xin[:, kin:] = 0.0
         encoders = ((title_text, self.title_pos_encoder, self.title_transformer, T),
                     (content_text, self.body_pos_encoder, self.body_transformer, L))
         step_of = lambda S: min(max(1, MAX_TOKENS_PER_PASS // S),
@@ -714,7 +718,7 @@ class CROWN(NewsEncoder):
         main.wait_stream(side4)
         # k intent layers (:284-295): [2M, 350] x [400, 350]^T each, ReLU fused, written side by side
         # (one GEMM against the k weight matrices stacked row-wise: the k layers share their input)
-        intents = ops.linear(xin[:, :kin], w_int, b_int, act='relu')
+        intents = ops.linear(xin, w_int, b_int, act='relu')
         # intent attention (:355-356): tanh(affine1) on the GEMM (title on the main stream, body on branch 5), the rest in the fuse kernel
         A = self.title_intent_attention.affine1.out_features
         hidden = torch.empty((2 * M * k, A), dtype=torch.float32, device=dev)
