@@ -54,12 +54,15 @@ _SIDE = {}
 # body chain, 3 = the body encoder's preparation under the title encoder, 4 = category representation + stacked intent weights, 5 = the
 # body half of the intent attention's hidden GEMM, 6 = the candidate side of the interest match (same-box A/B at config 2b, ms per
 # step: {0,2} 2.414, {0,2,3} 2.372, {0,2,4} 2.446 -- short kernels in front of a persistent GEMM delay some of its statically
-# scheduled workgroups --, {0,2,5,6} 2.415, all 2.466).  OVERLAP_BRANCHES is the set that is forked (LIME_OVERLAP_STREAMS = 0: none, 2: the two small branches --
+# scheduled workgroups --, {0,2,5,6} 2.415, all 2.466), 7 = on the compacted path, the title encoder's chain beside the body
+# encoder's: the compacted launches have few tiles (423 / 251 / 502 on 512 workgroup slots for the title, a half-empty last round
+# for the body), so the two chains fill each other's gaps ({0,2,3} 2.288, {0,2,3,7} 2.210; on the dense path, whose launches fill
+# every slot for ten rounds, the same fork -- branch 1 -- measured slower).  OVERLAP_BRANCHES is the set that is forked (LIME_OVERLAP_STREAMS = 0: none, 2: the two small branches --
 # the default, 4.557 vs 4.593 ms --, 1: all three).  The title / body fork is off by default: the big GEMMs hold two
 # workgroups of 256 VGPRs x 4 waves and 61 KB LDS on every CU, so nothing else becomes resident beside them and that fork
 # measured slower (4.651 ms).
 def _branches(spec):
-    named = {'0': frozenset(), '1': frozenset((0, 1, 2, 3, 4, 5, 6)), '2': frozenset((0, 2, 3))}
+    named = {'0': frozenset(), '1': frozenset((0, 1, 2, 3, 4, 5, 6, 7)), '2': frozenset((0, 2, 3, 7))}
     return named[spec] if spec in named else frozenset(int(x) for x in spec.split('+'))       # e.g. LIME_OVERLAP_STREAMS=0+2+4
 
 
@@ -692,10 +695,14 @@ class CROWN(NewsEncoder):
             side3.wait_stream(main)
             with torch.cuda.stream(side3):
                 prep_b = compact_prepare(b_ids, table, b_pos.table(), b_tr, self.head_num)
-            prep_t = compact_prepare(t_ids, table, t_pos.table(), t_tr, self.head_num)
-            compact_run(prep_t, table, t_pos.table(), t_tr, self.head_num, xin[:M, :E])                        # :311-317
+            side1 = _side_stream(dev, 7)                   # branch 7: the (short) title chain beside the body chain
+            side1.wait_stream(main)
+            with torch.cuda.stream(side1):
+                prep_t = compact_prepare(t_ids, table, t_pos.table(), t_tr, self.head_num)
+                compact_run(prep_t, table, t_pos.table(), t_tr, self.head_num, xin[:M, :E])                    # :311-317
             main.wait_stream(side3)
             compact_run(prep_b, table, b_pos.table(), b_tr, self.head_num, xin[M:, :E])                        # :312-321
+            main.wait_stream(side1)
         else:
             side = _side_stream(dev, 1)
             side.wait_stream(main)
