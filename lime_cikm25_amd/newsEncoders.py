@@ -57,12 +57,13 @@ _SIDE = {}
 # scheduled workgroups --, {0,2,5,6} 2.415, all 2.466), 7 = on the compacted path, the title encoder's chain beside the body
 # encoder's: the compacted launches have few tiles (423 / 251 / 502 on 512 workgroup slots for the title, a half-empty last round
 # for the body), so the two chains fill each other's gaps ({0,2,3} 2.288, {0,2,3,7} 2.210; on the dense path, whose launches fill
-# every slot for ten rounds, the same fork -- branch 1 -- measured slower).  OVERLAP_BRANCHES is the set that is forked (LIME_OVERLAP_STREAMS = 0: none, 2: the two small branches --
+# every slot for ten rounds, the same fork -- branch 1 -- measured slower; beside the forked title chain branch 4 now pays:
+# {0,2,3,7} 2.242, {0,2,3,4,7} 2.206, + {5,6} 2.230).  OVERLAP_BRANCHES is the set that is forked (LIME_OVERLAP_STREAMS = 0: none, 2: the two small branches --
 # the default, 4.557 vs 4.593 ms --, 1: all three).  The title / body fork is off by default: the big GEMMs hold two
 # workgroups of 256 VGPRs x 4 waves and 61 KB LDS on every CU, so nothing else becomes resident beside them and that fork
 # measured slower (4.651 ms).
 def _branches(spec):
-    named = {'0': frozenset(), '1': frozenset((0, 1, 2, 3, 4, 5, 6, 7)), '2': frozenset((0, 2, 3, 7))}
+    named = {'0': frozenset(), '1': frozenset((0, 1, 2, 3, 4, 5, 6, 7)), '2': frozenset((0, 2, 3, 4, 7))}
     return named[spec] if spec in named else frozenset(int(x) for x in spec.split('+'))       # e.g. LIME_OVERLAP_STREAMS=0+2+4
 
 
@@ -704,7 +705,7 @@ class CROWN(NewsEncoder):
             compact_run(prep_b, table, b_pos.table(), b_tr, self.head_num, xin[M:, :E])                        # :312-321
             main.wait_stream(side1)
         else:
-            side = _side_stream(dev, 1)
+            side = _side_stream(dev, 7 if DEDUP else 1)   # compacted chunks: title beside body (branch 7); dense: branch 1 (off)
             side.wait_stream(main)
             for half, (ids, pos, tr, S) in enumerate(encoders):
                 step = step_of(S)
