@@ -16,7 +16,8 @@
  *     last failure of the calling thread;
  *   - calls are stateless and re-entrant; every entry point of the scoring path is bitwise reproducible run to run (no
  *     atomics in any reduction).  Two training-step kernels add with float atomics and are reproducible only up to the
- *     order of those fp32 additions: lime_embed_bwd_f32 (word rows repeat across tokens) and the S > 128 path of
+ *     order of those fp32 additions: lime_embed_bwd_f32 (word rows repeat across tokens; lime_embed_bwd_sorted_f32 is the atomic-free
+ *     replacement the training step uses) and the S > 128 path of
  *     lime_token_attention_bwd_f32 (dq from the key blocks).
  */
 #ifndef LIME_HIP_H
@@ -443,6 +444,15 @@ int lime_embed_bwd_f32(const int32_t* ids, const float* dx, int64_t lddx, float*
 
 /* The same for a table of at most 32 rows (FreshnessEncoder's two 10-row bucket tables, newsEncoders.py:75-76): per-column
  * LDS accumulation, no atomics, fixed summation order.  Rows whose id is outside [0, table_rows) are ignored. */
+/* lime_embed_bwd_sorted_f32: the same sum WITHOUT atomics -- bitwise reproducible.  order: the token positions sorted by id with a
+ * stable sort, sorted_ids = ids[order] (both int32 [rows]); every row of dtable that receives a contribution is written exactly
+ * once, in a fixed association (runs of equal ids summed in sorted order, in chunks of 256 positions; partials of a run that
+ * crosses chunks added in chunk order); rows without a contribution keep the caller's value -- zero dtable first.  dim <= 320.
+ * workspace: lime_embed_bwd_sorted_workspace(rows, dim) floats. */
+int lime_embed_bwd_sorted_f32(const int32_t* order, const int32_t* sorted_ids, const float* dx, int64_t lddx, float* dtable,
+                              int64_t ld_table, int64_t rows, int32_t dim, float* workspace, int64_t workspace_floats, void* stream);
+int64_t lime_embed_bwd_sorted_workspace(int64_t rows, int32_t dim);
+
 int lime_embed_bwd_small_f32(const int32_t* ids, const float* dx, int64_t lddx, float* dtable, int64_t ld_table, int64_t rows,
                              int32_t dim, int32_t table_rows, void* stream);
 

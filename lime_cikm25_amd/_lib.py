@@ -135,6 +135,9 @@ SIGNATURES = {
     'lime_token_attention_dropout_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                                    c_int32, c_int32, c_float, c_float, c_uint64, c_uint32, c_void_p, c_int64, c_void_p]),
     'lime_embed_bwd_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p]),
+    'lime_embed_bwd_sorted_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64,
+                                            c_void_p]),
+    'lime_embed_bwd_sorted_workspace': (c_int64, [c_int64, c_int32]),
     'lime_embed_bwd_small_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p]),
     'lime_grad_clip_coef_f32': (c_int32, [c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     'lime_adam_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float,

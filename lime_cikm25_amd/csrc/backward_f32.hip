@@ -6,7 +6,7 @@
 //   layernorm_bwd_kernel   dZ of y = LayerNorm(z) from (dY, y, rstd) + the column sums for d gamma / d beta / bias
 //   relu_bwd_kernel        dH *= (h > 0)
 //   token_attn_bwd_kernel  dQ / dK / dV of softmax(scale Q K^T) V per (sequence, head), probabilities recomputed
-//   embed_bwd_kernel       dTable[ids[r]] += dX[r]                (the one place with float atomics: word rows repeat)
+//   embed_bwd_kernel       dTable[ids[r]] += dX[r]                (float atomics; embed_bwd_sorted.hip is the fixed-order replacement)
 //   sumsq / clip / adam    clip_grad_norm_ + Adam over flat buffers, nll_softmax: the loss of trainer.py:71-73
 //
 // All dense reductions are fixed-order (partials in a caller workspace, then one summing pass).

@@ -853,8 +853,13 @@ def token_attention_dropout(q, k, v, n_seq, S, n_head, head_dim, scale, p, seed,
     return out
 
 
+DETERMINISTIC_EMBED_BWD = True      # word-table gradient by sort + segmented sum (no atomics); False: the float-atomic kernel
+
+
 def embed_bwd(ids, dx, dtable, hot_id=0):
-    """dtable[ids[r]] += dx[r]  (float atomics; tables of <= 32 rows: atomic-free LDS accumulation)."""
+    """dtable[ids[r]] += dx[r] for a ZEROED dtable.  Tables of <= 32 rows: atomic-free LDS accumulation; larger tables with
+    dim <= 320: stable sort of the positions by id + segmented sum in a fixed order (lime_embed_bwd_sorted_f32: bitwise
+    reproducible); otherwise (or with DETERMINISTIC_EMBED_BWD off) float atomics."""
     lib = _lib.load()
     _vec(ids, 'ids', dtype=torch.int32)
     _mat(dx, 'dx')
@@ -864,6 +869,14 @@ def embed_bwd(ids, dx, dtable, hot_id=0):
     if dtable.shape[0] <= 32:              # a handful of rows: per-column LDS accumulation instead of contended atomics
         check(lib.lime_embed_bwd_small_f32(_p(ids), _p(dx), _ld(dx), _p(dtable), _ld(dtable), ids.numel(), dx.shape[1],
                                            dtable.shape[0], _stream()), 'lime_embed_bwd_small_f32')
+        return dtable
+    if DETERMINISTIC_EMBED_BWD and dx.shape[1] <= 320 and ids.numel() > 0:
+        sorted_ids, order = torch.sort(ids, stable=True)
+        order = order.to(torch.int32)
+        need = int(lib.lime_embed_bwd_sorted_workspace(ids.numel(), dx.shape[1]))
+        ws = torch.empty(need, dtype=torch.float32, device=dx.device)
+        check(lib.lime_embed_bwd_sorted_f32(_p(order), _p(sorted_ids), _p(dx), _ld(dx), _p(dtable), _ld(dtable), ids.numel(), dx.shape[1],
+                                            _p(ws), need, _stream()), 'lime_embed_bwd_sorted_f32')
         return dtable
     check(lib.lime_embed_bwd_f32(_p(ids), _p(dx), _ld(dx), _p(dtable), _ld(dtable), ids.numel(), dx.shape[1], hot_id, _stream()),
           'lime_embed_bwd_f32')
