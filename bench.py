@@ -360,7 +360,7 @@ def bench_workload(name, steps, warmup, rank, world, dist, D, args, full=True):
                'h2d_note': 'all 26 input tensors copied from pinned host memory with .cuda(non_blocking=True) inside every step'}
     dense = None
     fexec, pad_stats = executed_flops_per_impression(run)
-    if fexec is not None and not train:
+    if not train:
         # the same K steps with the repetition shortcuts OFF: every token of every slot through the encoder layer, as the
         # reference computes it (newsEncoders.py:311-321) -- what LIME_DENSE_TOKENS=1 runs
         from lime_cikm25_amd import newsEncoders
@@ -405,6 +405,8 @@ def bench_workload(name, steps, warmup, rank, world, dist, D, args, full=True):
         'end_to_end': {'flops_per_impression': fimp, 'achieved_tflops': round(value * fimp / 1e12, 2),
                        'frac_of_f32_mfma_peak': round(value * fimp / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4)},
     }
+    if not train:
+        out['dense'] = dense
     if fexec is not None and not train:
         e2e = out['end_to_end']
         e2e['note'] = ('flops_per_impression is the DENSE algorithmic count of BASELINE.md section 3 (every slot, every token); the '
@@ -415,7 +417,6 @@ def bench_workload(name, steps, warmup, rank, world, dist, D, args, full=True):
         e2e['achieved_tflops_executed'] = round(value * fexec / 1e12, 2)
         e2e['frac_of_f32_mfma_peak_executed'] = round(value * fexec / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4)
         out['input_padding'] = pad_stats
-        out['dense'] = dense
     if sustained:
         out['sustained'] = sustained
     if h2d:

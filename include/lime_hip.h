@@ -94,7 +94,7 @@ typedef struct {
     float* ln_rstd;       /* optional [M]: 1 / sqrt(var + eps) of every row's LayerNorm, kept for lime_layernorm_bwd_f32 */
     const int32_t* m_dev; /* optional DEVICE int: the launch computes min(*m_dev, M) rows -- M is then the capacity the buffers were
                              sized for.  Lets a launch captured in a HIP graph follow a per-batch row count (the live rows that
-                             lime_compact_sequences counted) without a host round trip.  Big-M kernel only (M >= 4096, 16-byte operands). */
+                             lime_compact_sequences counted) without a host round trip.  Needs 16-byte friendly operands (the LDS-DMA kernels). */
     const int32_t* c_ids; /* optional int32 [M]: the A rows are a compacted row list -- result row r is stored at c[c_ids[r] * ldc] and
                              the periodic residual is res[(c_ids[r] % res_mod) * ldr].  Needs res with res_mod > 0, no LayerNorm, act none
                              (the in_proj GEMM over the non-padding tokens of a batch). */
@@ -171,6 +171,12 @@ int lime_embed_pe_f32(const int32_t* ids, const float* table, int64_t ld_table, 
 int lime_token_attention_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const uint8_t* key_mask,
                              float* out, int64_t ldo, int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim,
                              int32_t head_stride, float scale, void* stream);
+
+/* lime_token_attention_count_f32: lime_token_attention_f32 with an optional device-side sequence count (min(*n_seq_dev, n_seq)
+ * sequences are computed; n_seq is the capacity): the masked attention of a compacted batch inside a HIP graph. */
+int lime_token_attention_count_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const uint8_t* key_mask,
+                                   const int32_t* n_seq_dev, float* out, int64_t ldo, int32_t n_seq, int32_t S, int32_t n_head,
+                                   int32_t head_dim, int32_t head_stride, float scale, void* stream);
 
 /*
  * lime_token_attention_rows_f32: lime_token_attention_f32 (unmasked, heads padded to 32 columns) over COMPACTED sequences: the

@@ -77,6 +77,8 @@ SIGNATURES = {
                                     c_int32, c_void_p]),
     'lime_token_attention_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
                                            c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    'lime_token_attention_count_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                                                 c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
     'lime_token_attention_rows_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                                 c_int32, c_int32, c_int32, c_float, c_void_p]),
     'lime_token_attention_rows_bf16': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int32,

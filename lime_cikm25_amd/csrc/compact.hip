@@ -73,6 +73,7 @@ __global__ __launch_bounds__(1024) void seq_scan_kernel(const int* __restrict__ 
             seq_inv[s] = n_live;                                   // the all-padding representative
         }
     }
+    for (int i = n_live + 1 + tid; i <= n_seq; i += 1024) seq_src[i] = -1;      // unused compact slots: no source sequence
     if (tid == 0) {
         seq_src[n_live] = -1;
         tok_off[n_live] = n_tok;

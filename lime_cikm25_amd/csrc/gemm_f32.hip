@@ -621,8 +621,14 @@ extern "C" int lime_linear_f32(const lime_linear_args* a, void* stream) {
         const int st = lime_linear_pp(a, (hipStream_t)stream);
         if (st != LIME_PP_NOT_APPLICABLE) return st;
     }
-    LIME_REQUIRE(!a->m_dev && !a->c_ids, LIME_ERR_UNSUPPORTED,
-                 "lime_linear_f32: m_dev / c_ids need the big-M kernel (M >= 4096, 16-byte operands; c_ids: periodic residual, no LayerNorm, act none)");
+    LIME_REQUIRE(!a->c_ids, LIME_ERR_UNSUPPORTED,
+                 "lime_linear_f32: c_ids needs the big-M kernel (M >= 4096, 16-byte operands, periodic residual, no LayerNorm, act none)");
+    if (a->m_dev) {                                   // a device-side row count outside the big-M kernel: the mid-M kernel honours it
+        const int st = lime_linear_mid(a, (hipStream_t)stream);
+        LIME_REQUIRE(st != LIME_PP_NOT_APPLICABLE, LIME_ERR_UNSUPPORTED,
+                     "lime_linear_f32: m_dev needs 16-byte friendly operands (K, N multiples of 4, aligned rows) and no LayerNorm / pooling / a_pe");
+        return st;
+    }
     LIME_REQUIRE(!a->pool32, LIME_ERR_UNSUPPORTED,
                  "lime_linear_f32: pool32 needs the big-M kernel (M >= 4096 and a multiple of 32, LayerNorm + dense residual, 16-byte operands)");
 

@@ -28,6 +28,7 @@ struct MidP {
     const float* w; long ldw; const float* bias;
     const float* res; long ldr; int res_div, res_mod; const int* res_ids;
     float* c; long ldc; int M, N, K, act, n_col_blocks;
+    const int* m_dev;    // optional device-side row count (min(*m_dev, M) rows; workgroups of tiles beyond it exit)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base) {
@@ -55,6 +56,12 @@ __global__ __launch_bounds__(256, 3) void gemm_mid_kernel(const MidP p) {
     const int fi = lane & 15, kg = lane >> 4;
     const int rb = blockIdx.x / p.n_col_blocks;
     const int row0 = rb * MB, col0 = (blockIdx.x - rb * p.n_col_blocks) * NB;
+    int M = p.M;
+    if (p.m_dev) {
+        const int m = __builtin_amdgcn_readfirstlane(*p.m_dev);
+        M = m < M ? m : M;
+    }
+    if (row0 >= M) return;                           // (uniform per workgroup: nothing was issued yet)
 
     // ---- loader: this wave stages A rows 16 wave .. + 15 and W rows 16 wave .. + 15 of every chunk (one 1 KB DMA each) ----
     const int srow = lane >> 2;
@@ -67,8 +74,8 @@ __global__ __launch_bounds__(256, 3) void gemm_mid_kernel(const MidP p) {
     {
         const int rl = 16 * wave + srow;
         unsigned rowsel = (unsigned)rl;
-        if (gather && row0 + rl < p.M) rowsel = (unsigned)p.a_ids[row0 + rl];
-        a_voff = (row0 + rl < p.M) ? rowsel * (unsigned)lda4 + (unsigned)lseg * 16u : OOB;
+        if (gather && row0 + rl < M) rowsel = (unsigned)p.a_ids[row0 + rl];
+        a_voff = (row0 + rl < M) ? rowsel * (unsigned)lda4 + (unsigned)lseg * 16u : OOB;
         w_voff = (col0 + rl < p.N) ? (unsigned)rl * (unsigned)ldw4 + (unsigned)lseg * 16u : OOB;
     }
     const int nchunk = (p.K + KB - 1) / KB;
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(256, 3) void gemm_mid_kernel(const MidP p) {
 
     // ---- epilogue: lane (fi, kg) holds row 16 wave + fi, columns 16 t + 4 kg .. + 3 -------------------------------------------
     const int row = row0 + 16 * wave + fi;
-    if (row >= p.M) return;
+    if (row >= M) return;
     long rrow = -1;
     if (p.res) {
         if (p.res_ids) rrow = p.res_ids[row];
@@ -154,7 +161,7 @@ inline bool al16(const void* ptr, long ld) { return ptr == nullptr || (((uintptr
 int lime_linear_mid(const lime_linear_args* a, hipStream_t s) {
     static const bool off = getenv("LIME_GEMM_NO_MID") != nullptr;           // A/B switch for tools/, not a product option
     if (off) return LIME_PP_NOT_APPLICABLE;
-    if (a->ln_gamma || a->pool32 || a->a_pe || a->ln_rstd || a->m_dev || a->c_ids || a->res_pe) return LIME_PP_NOT_APPLICABLE;
+    if (a->ln_gamma || a->pool32 || a->a_pe || a->ln_rstd || a->c_ids || a->res_pe) return LIME_PP_NOT_APPLICABLE;
     if (a->K % 4 || a->N % 4 || a->K < 16) return LIME_PP_NOT_APPLICABLE;
     if (!al16(a->a, a->lda) || !al16(a->w, a->ldw) || !al16(a->c, a->ldc) || !al16(a->res, a->ldr)) return LIME_PP_NOT_APPLICABLE;
     const long lim = 0x7FFFFFF0L;
@@ -164,7 +171,7 @@ int lime_linear_mid(const lime_linear_args* a, hipStream_t s) {
     p.w = a->w; p.ldw = a->ldw; p.bias = a->bias;
     p.res = a->res; p.ldr = a->ldr; p.res_div = a->res_div > 0 ? a->res_div : 1; p.res_ids = a->res_ids;
     p.res_mod = (a->res && !a->res_ids && a->res_mod > 0) ? a->res_mod : 0;
-    p.c = a->c; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act;
+    p.c = a->c; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act; p.m_dev = a->m_dev;
     const long n_row_blocks = (a->M + MB - 1) / MB;
     p.n_col_blocks = (a->N + NB - 1) / NB;
     const long ntiles = n_row_blocks * p.n_col_blocks;

@@ -53,7 +53,7 @@ struct AttnP {
     float* out; long ldo; int n_seq, S, n_head, hd, hs; float scale; int n_pair; int vec2; int n_group;
     int out_pad;         // BF: zero columns written behind the last head (the next GEMM reads K rounded up to 8)
     const int* row_map;  // MAP: q / k / v row of token (seq * S + t) is row_map[seq * S + t] (padding tokens share S table rows)
-    const int* n_seq_dev;  // MAP: optional device-side sequence count (min(*n_seq_dev, n_seq) sequences are computed)
+    const int* n_seq_dev;  // optional device-side sequence count (min(*n_seq_dev, n_seq) sequences are computed)
 #ifdef LIME_STAMPS
     unsigned long long* stamps;
 #endif
@@ -111,13 +111,11 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
     const int fi = lane & 31, fh = lane >> 5;
     const int S = p.S, hd = p.hd, hs = p.hs;
     int n_pair = p.n_pair, n_group = p.n_group;
-    if constexpr (MAP) {
-        if (p.n_seq_dev) {
-            int ns = __builtin_amdgcn_readfirstlane(*p.n_seq_dev);
-            ns = ns < p.n_seq ? (ns > 0 ? ns : 0) : p.n_seq;
-            n_pair = ns * p.n_head;
-            n_group = (n_pair + (NT >= 3 ? 1 : 4 / NT) - 1) / (NT >= 3 ? 1 : 4 / NT);
-        }
+    if (p.n_seq_dev) {                                 // device-side sequence count (compacted batches; uniform scalar load)
+        int ns = __builtin_amdgcn_readfirstlane(*p.n_seq_dev);
+        ns = ns < p.n_seq ? (ns > 0 ? ns : 0) : p.n_seq;
+        n_pair = ns * p.n_head;
+        n_group = (n_pair + (NT >= 3 ? 1 : 4 / NT) - 1) / (NT >= 3 ? 1 : 4 / NT);
         if (n_group == 0) return;
     }
     const bool vec2 = p.vec2 != 0;
@@ -488,22 +486,22 @@ extern "C" int lime_token_attention_rows_f32(const float* q, const float* k, con
     }
 }
 
-extern "C" int lime_token_attention_f32(const float* q, const float* k, const float* v, int64_t ld_qkv,
-                                        const uint8_t* key_mask, float* out, int64_t ldo, int32_t n_seq, int32_t S,
-                                        int32_t n_head, int32_t head_dim, int32_t head_stride, float scale, void* stream) {
-    LIME_REQUIRE(q && k && v && out, LIME_ERR_BAD_ARG, "lime_token_attention_f32: NULL pointer");
+extern "C" int lime_token_attention_count_f32(const float* q, const float* k, const float* v, int64_t ld_qkv,
+                                              const uint8_t* key_mask, const int32_t* n_seq_dev, float* out, int64_t ldo, int32_t n_seq,
+                                              int32_t S, int32_t n_head, int32_t head_dim, int32_t head_stride, float scale, void* stream) {
+    LIME_REQUIRE(q && k && v && out, LIME_ERR_BAD_ARG, "lime_token_attention_count_f32: NULL pointer");
     LIME_REQUIRE(n_seq >= 0 && S > 0 && n_head > 0 && head_dim > 0, LIME_ERR_BAD_ARG,
-                 "lime_token_attention_f32: bad dims n_seq=%d S=%d n_head=%d head_dim=%d", n_seq, S, n_head, head_dim);
-    LIME_REQUIRE(head_dim <= 32, LIME_ERR_UNSUPPORTED, "lime_token_attention_f32: head_dim %d > 32", head_dim);
-    LIME_REQUIRE(head_stride >= head_dim, LIME_ERR_BAD_ARG, "lime_token_attention_f32: head_stride %d < head_dim %d", head_stride, head_dim);
-    LIME_REQUIRE(S <= 512, LIME_ERR_UNSUPPORTED, "lime_token_attention_f32: S %d > 512", S);
+                 "lime_token_attention_count_f32: bad dims n_seq=%d S=%d n_head=%d head_dim=%d", n_seq, S, n_head, head_dim);
+    LIME_REQUIRE(head_dim <= 32, LIME_ERR_UNSUPPORTED, "lime_token_attention_count_f32: head_dim %d > 32", head_dim);
+    LIME_REQUIRE(head_stride >= head_dim, LIME_ERR_BAD_ARG, "lime_token_attention_count_f32: head_stride %d < head_dim %d", head_stride, head_dim);
+    LIME_REQUIRE(S <= 512, LIME_ERR_UNSUPPORTED, "lime_token_attention_count_f32: S %d > 512", S);
     LIME_REQUIRE(ld_qkv >= (int64_t)n_head * head_stride && ldo >= (int64_t)n_head * head_dim, LIME_ERR_BAD_ARG,
-                 "lime_token_attention_f32: leading dimension smaller than n_head * head_dim");
+                 "lime_token_attention_count_f32: leading dimension smaller than n_head * head_dim");
     if (n_seq == 0) return LIME_OK;
     // 8-byte loads need an even head_dim and leading dimension and 8-byte aligned bases
     const int vec2 = (head_dim % 2 == 0) && (head_stride % 2 == 0) && (ld_qkv % 2 == 0) &&
                      (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 8 == 0);
-    AttnP p{q, k, v, (long)ld_qkv, key_mask, out, (long)ldo, n_seq, S, n_head, head_dim, head_stride, scale, n_seq * n_head, vec2, 0, 0, nullptr, nullptr};
+    AttnP p{q, k, v, (long)ld_qkv, key_mask, out, (long)ldo, n_seq, S, n_head, head_dim, head_stride, scale, n_seq * n_head, vec2, 0, 0, nullptr, n_seq_dev};
     hipStream_t s = (hipStream_t)stream;
     const int nt = (S + 31) / 32;
     if (nt <= 1) return launch<1>(p, s);
@@ -512,6 +510,13 @@ extern "C" int lime_token_attention_f32(const float* q, const float* k, const fl
     if (nt <= 4) return launch<4>(p, s);
     if (nt <= 8) return launch<8>(p, s);
     return launch<16>(p, s);
+}
+
+
+extern "C" int lime_token_attention_f32(const float* q, const float* k, const float* v, int64_t ld_qkv,
+                                        const uint8_t* key_mask, float* out, int64_t ldo, int32_t n_seq, int32_t S,
+                                        int32_t n_head, int32_t head_dim, int32_t head_stride, float scale, void* stream) {
+    return lime_token_attention_count_f32(q, k, v, ld_qkv, key_mask, nullptr, out, ldo, n_seq, S, n_head, head_dim, head_stride, scale, stream);
 }
 
 int lime_token_attention_bf16_mfma(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ld_qkv, uint16_t* out, int64_t ldo,

@@ -93,8 +93,9 @@ class MultiHeadAttention(nn.Module):
             nn.init.xavier_uniform_(lin.weight)
             nn.init.zeros_(lin.bias)
 
-    def project(self, x2d=None, table=None, ids=None):
-        """[tokens, 3*h*d_k] packed q|k|v; the operand is either a dense [tokens, d_model] matrix or a gather."""
+    def project(self, x2d=None, table=None, ids=None, m_dev=None):
+        """[tokens, 3*h*d_k] packed q|k|v; the operand is either a dense [tokens, d_model] matrix or a gather.  m_dev: optional
+        device-side row count (a compacted batch)."""
         assert self.d_k == self.d_v
         hd = self.h * self.d_k
         tokens = x2d.shape[0] if ids is None else ids.numel()
@@ -103,13 +104,13 @@ class MultiHeadAttention(nn.Module):
         # and N = 3 h d_k = 600 fills two 320-column tiles where 200 wasted a fifth of a 256-column one)
         w = torch.cat([self.W_Q.weight, self.W_K.weight, self.W_V.weight], dim=0)
         b = torch.cat([self.W_Q.bias, self.W_K.bias, self.W_V.bias], dim=0)
-        qkv = ops.linear(src, w, b, a_ids=ids)
+        qkv = ops.linear(src, w, b, a_ids=ids, m_dev=m_dev)
         return qkv
 
-    def attend(self, qkv, n_seq, S, mask):
+    def attend(self, qkv, n_seq, S, mask, n_seq_dev=None):
         hd = self.h * self.d_k
         return ops.token_attention(qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:], n_seq, S, self.h, self.d_k,
-                                   1.0 / self.attention_scalar, key_mask=mask)
+                                   1.0 / self.attention_scalar, key_mask=mask, n_seq_dev=n_seq_dev)
 
     def forward(self, Q, K, V, mask=None):
         if not (Q is K and K is V):

@@ -746,6 +746,29 @@ class CROWN(NewsEncoder):
 class MHSA(NewsEncoder):
     """newsEncoders.py:566-595: title-only multi-head self-attention + additive attention.  -> [B, n, 300]."""
 
+    def _encode_compact(self, ids, mask, out):
+        """The title encoder over the live sequences + ONE representative of the padding news' title (see
+        ``encode_tokens_compact``; sequence level only: this encoder masks its padding tokens, so their rows are needed).  A
+        sequence repeats the representative when its ids are all zero AND its mask is the padding news' mask (first position
+        set, corpus.py:476-477); an all-zero sequence with any other mask counts as live."""
+        n, T = ids.shape
+        mha = self.multiheadAttention
+        dev = ids.device
+        e0 = torch.arange(T, device=dev) == 0                                     # the padding news' mask (no host scalar: graph capture)
+        mask = mask.bool()
+        odd = (ids == 0).all(dim=1) & ~(mask == e0).all(dim=1)                   # all-zero ids under a different mask: live
+        ids_eff = ids.clone()
+        ids_eff[:, 0] = torch.where(odd, torch.full_like(ids[:, 0], -1), ids[:, 0])            # a sentinel makes them count as live
+        cmp = ops.compact_sequences(ids_eff)
+        ids_c = cmp.ids_c.clamp(min=0)                                           # the sentinel back to the padding word
+        src = cmp.seq_src.long()                                                 # compact -> original sequence, -1: no source
+        mask_c = torch.where((src < 0).unsqueeze(1), e0.unsqueeze(0), mask[src.clamp(min=0)]).contiguous()
+        qkv = mha.project(table=self.word_embedding.weight, ids=ids_c, m_dev=cmp.n_rows)
+        c = mha.attend(qkv, n + 1, T, mask_c, n_seq_dev=cmp.n_compact)
+        hidden = ops.linear(c, self.attention.affine1.weight, self.attention.affine1.bias, act='tanh', m_dev=cmp.n_rows)
+        pooled_c = ops.additive_pool(hidden, self.attention.affine2.weight.view(-1), c, n + 1, T, mask=mask_c)
+        ops.gather_rows(cmp.seq_inv, pooled_c, out)
+
     def __init__(self, config):
         super().__init__(config)
         self.max_sentence_length = config.max_title_length
@@ -771,7 +794,11 @@ class MHSA(NewsEncoder):
         step = max(1, MAX_TOKENS_PER_PASS // T)
         for m0 in range(0, M, step):
             m1 = min(M, m0 + step)
-            qkv = mha.project(table=self.word_embedding.weight, ids=title_text[m0:m1].reshape(-1))     # :588 + layers.py:224-226
+            ids = title_text[m0:m1]
+            if DEDUP and (m1 - m0 + 1) * T >= 4096 and ids.dtype == torch.int32 and ids.is_contiguous():
+                self._encode_compact(ids, mask[m0:m1], out[m0:m1, :F])
+                continue
+            qkv = mha.project(table=self.word_embedding.weight, ids=ids.reshape(-1))                    # :588 + layers.py:224-226
             c = mha.attend(qkv, m1 - m0, T, mask[m0:m1])                                                # layers.py:227-237
             hidden = ops.linear(c, self.attention.affine1.weight, self.attention.affine1.bias, act='tanh')
             ops.additive_pool(hidden, self.attention.affine2.weight.view(-1), c, m1 - m0, T, mask=mask[m0:m1],

@@ -168,7 +168,7 @@ def embed_pe(ids, table, pe=None, period=0, out=None):
     return out
 
 
-def token_attention(q, k, v, n_seq, S, n_head, head_dim, scale, key_mask=None, out=None, head_stride=None):
+def token_attention(q, k, v, n_seq, S, n_head, head_dim, scale, key_mask=None, out=None, head_stride=None, n_seq_dev=None):
     """softmax(Q K^T * scale [+mask]) V per (sequence, head); q/k/v: [n_seq*S, n_head*head_stride] views of one pitch
     (head_stride defaults to head_dim, the packed layout); out: [n_seq*S, n_head*head_dim]."""
     lib = _lib.load()
@@ -185,6 +185,11 @@ def token_attention(q, k, v, n_seq, S, n_head, head_dim, scale, key_mask=None, o
     m = _mask_u8(key_mask, 'key_mask')
     if m is not None and m.numel() != n_seq * S:
         raise ValueError('key_mask must have n_seq * S elements')
+    if n_seq_dev is not None:                      # a compacted batch: the sequence count lives on the device
+        _vec(n_seq_dev, 'n_seq_dev', 1, dtype=torch.int32)
+        check(lib.lime_token_attention_count_f32(_p(q), _p(k), _p(v), _ld(q), _p(m), _p(n_seq_dev), _p(out), _ld(out), n_seq, S, n_head,
+                                                 head_dim, hs, scale, _stream()), 'lime_token_attention_count_f32')
+        return out
     check(lib.lime_token_attention_f32(_p(q), _p(k), _p(v), _ld(q), _p(m), _p(out), _ld(out), n_seq, S, n_head, head_dim, hs,
                                        scale, _stream()), 'lime_token_attention_f32')
     return out

@@ -189,3 +189,29 @@ def test_bf16_model_with_and_without_dedup(monkeypatch):
     e = rel_err(got.numpy(), dense.numpy())
     print('bf16 dedup vs dense %.2e' % e)
     assert torch.isfinite(got).all() and e < 1e-5
+
+
+def test_mhsa_model_with_and_without_dedup(monkeypatch):
+    """LIME-MHSA-CROWN (title only, BASELINE configs[1] read literally) at full size: the padding news' title is encoded once.
+    This encoder masks its padding tokens, so a sequence repeats the representative only when ids AND mask are the padding
+    news' -- an all-zero title under a different mask (rows 3 and 7 below) must still be encoded on its own."""
+    cfg = make_config(vocabulary_size=50000, content_encoder='MHSA')
+    model, sd = gpu_model(cfg, seed=37)
+    batch = synth.make_batch(cfg, 32, 5, seed=38)
+    for r in (3, 7):                                       # all-zero ids with an unusual mask
+        batch['user_title_text'][r, 0] = 0
+        batch['user_title_mask'][r, 0] = True
+    batch['user_title_text'][3, 1] = 0
+    batch['user_title_mask'][3, 1] = False
+    batch['user_title_mask'][3, 1, 0] = False
+    batch['user_title_mask'][3, 1, 5] = True
+    monkeypatch.setattr(newsEncoders, 'DEDUP', True)
+    got = run(model, batch, False)
+    model._graphs.clear()
+    monkeypatch.setattr(newsEncoders, 'DEDUP', False)
+    dense = run(model, batch, False)
+    model._graphs.clear()
+    e = rel_err(got.numpy(), dense.numpy())
+    want = O.model_forward(sd, cfg, batch)
+    print('MHSA dedup vs dense %.2e, vs oracle %.2e' % (e, rel_err(got.numpy(), want.numpy())))
+    assert torch.isfinite(got).all() and e < 2e-6 and rel_err(got.numpy(), want.numpy()) < 1e-3
