@@ -473,7 +473,15 @@ __global__ __launch_bounds__(256) void sage_mean_kernel(const float* __restrict_
     const float inv = 1.0f / (float)n_src;
     for (int d = threadIdx.x; d < D; d += 256) {
         float acc = 0.f;
-        for (int u = 0; u < n_src; ++u) acc += (u < H) ? hist[(b * H + u) * D + d] : user_nodes[(long)(u - H) * D + d];
+        int u = 0;
+        for (; u + 8 <= n_src; u += 8) {             // eight node rows in flight, added in slot order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (u + k < H) ? hist[(b * H + u + k) * D + d] : user_nodes[(long)(u + k - H) * D + d];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += v[k];
+        }
+        for (; u < n_src; ++u) acc += (u < H) ? hist[(b * H + u) * D + d] : user_nodes[(long)(u - H) * D + d];
         out[b * D + d] = acc * inv;
     }
 }
@@ -498,12 +506,22 @@ __global__ __launch_bounds__(256) void interest_match_kernel(const float* __rest
     for (int e = threadIdx.x; e < A; e += 256) Qs[e] = qp[bn * A + e];
     __syncthreads();
     // a[h] = kp[b,h,:] . q * scale: a wave streams one key row (coalesced), lanes over A, shuffle reduction
-    for (int h = wave; h < H; h += 4) {
-        const float* krow = kp + (b * H + h) * A;
-        float part = 0.f;
-        for (int j = lane; j < A; j += 64) part += krow[j] * Qs[j];
-        part = wave_sum(part);
-        if (lane == 0) al[h] = part * scale;
+    // (four rows of a wave in flight: the loop is a chain of L2 round trips otherwise; the order of the additions is unchanged)
+    for (int h0 = wave; h0 < H; h0 += 16) {
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = lane; j < A; j += 64) {
+            const float q = Qs[j];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int h = h0 + 4 * u;
+                part[u] += (h < H ? kp[(b * H + h) * A + j] : 0.f) * q;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float t = wave_sum(part[u]);
+            if (lane == 0 && h0 + 4 * u < H) al[h0 + 4 * u] = t * scale;
+        }
     }
     __syncthreads();
     // softmax over the history (unmasked, userEncoders.py:164)
@@ -524,7 +542,15 @@ __global__ __launch_bounds__(256) void interest_match_kernel(const float* __rest
     float part = 0.f;
     for (int d = threadIdx.x; d < D; d += 256) {
         float u = 0.f;
-        for (int h = 0; h < H; ++h) u += (al[h] * inv) * g[(b * H + h) * D + d];
+        int h = 0;
+        for (; h + 8 <= H; h += 8) {                 // eight rows in flight, added in the same order
+            float gv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gv[k] = g[(b * H + h + k) * D + d];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) u += (al[h + k] * inv) * gv[k];
+        }
+        for (; h < H; ++h) u += (al[h] * inv) * g[(b * H + h) * D + d];
         if (user_rep) user_rep[bn * D + d] = u;
         part += u * cand[bn * D + d];
     }
