@@ -136,12 +136,15 @@ __device__ __forceinline__ float row16_sum(float v) {
 //      periodic residual (RES == 1 with res_mod) is indexed by c_ids[r] % res_mod -- in_proj over the non-padding tokens only.
 // p.m_dev (any instantiation): the row count is read from device memory (min(*m_dev, M)), so a launch captured into a HIP
 //      graph follows the batch's live-row count without a host round trip.
-template <int NTL, bool LN, bool RELU, int RES, bool BF, bool POOL = false, bool RSTD = false, bool CID = false>
+// TRIM: 16-column MFMA tiles left out at the end of a wave's slab: the N = 300 GEMMs (out_proj, linear2) run 19 tiles = 304
+//      columns instead of 20 (the loader keeps its 320-row geometry: the 20th weight piece is an out-of-range, zero-fill DMA).
+template <int NTL, bool LN, bool RELU, int RES, bool BF, bool POOL = false, bool RSTD = false, bool CID = false, int TRIM = 0>
 __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
     constexpr int ES = BF ? 2 : 4;                 // operand element size
     constexpr int EPS = 16 / ES;                   // elements per 16-byte segment
     constexpr int BKE = 64 / ES;                   // elements per chunk
-    constexpr int BN = NTL * 32;
+    constexpr int BN = NTL * 32;                   // loader / LDS geometry
+    constexpr int BNE = BN - 16 * TRIM;            // columns a tile really computes
     constexpr int A_ST = BM * BK, W_ST = BN * BK, STAGE = A_ST + W_ST;     // floats
     constexpr int NWI = BN / 64;                                            // weight DMA instructions per wave and chunk
     // ONE __shared__ object (a second one beside an LDS-DMA target makes hipcc drain vmcnt before every ds_read)
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
     auto tile_rc = [&](int tile, int& row0, int& col0) {
         const int rb = tile / p.n_col_blocks;
         row0 = rb * BM;
-        col0 = (tile - rb * p.n_col_blocks) * BN;
+        col0 = (tile - rb * p.n_col_blocks) * BNE;
     };
     auto prefetch_ids = [&](int tile) {                // ids of `tile` -> registers (any tile index: out of range reads 0)
         int row0, col0;
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
     // v_mfma_f32_16x16x4_f32: lane (i, kg) supplies A[i][k = kg] and B[k = kg][j = i]; the MFMA's k index is only a
     // summation label, so a lane reads ONE b128 = k 4 kg .. 4 kg + 3 of its row (logical segment kg) per operand tile and
     // chunk, and the four MFMAs q = 0..3 of a tile pair element q of both fragments: together they cover the chunk's 16 k.
-    constexpr int NT16 = 2 * NTL;                                  // 16-column tiles per wave
+    constexpr int NT16 = 2 * NTL - TRIM;                           // 16-column tiles per wave
     const int pseg = (kg ^ swz4((fi >> 2) & 3)) * 4;
     const int a_off = (32 * wave + fi) * BK + pseg, w_off = A_ST + fi * BK + pseg;
     f32x4 acc[2][NT16];
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
     // the DMA issue would otherwise also keep hipcc from hoisting those reads, and every group would start with an
     // exposed LDS round trip).
     constexpr int GT = 4;                                          // tiles per group
-    constexpr int NG = NT16 / GT;                                  // groups: 5 (320 columns) or 4 (256)
+    constexpr int NG = (NT16 + GT - 1) / GT;                       // groups: 5 (320 / 304 columns) or 4 (256); the last may be short
     auto compute = [&](int stage, int nstage, int nc) {
 #if defined(LIME_PP_ABLATE) && LIME_PP_ABLATE == 1       // tools/pp_ablate.py: no fragment reads, no MFMAs (DMA issued up front)
         if (nstage >= 0) issue_w(nstage, nc);
@@ -294,7 +297,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
             if (gb + 1 < NG) {
 #pragma unroll
                 for (int t = 0; t < GT; ++t)
-                    wf[(gb + 1) & 1][t] = *reinterpret_cast<const f32x4*>(sb + w_off + ((gb + 1) * GT + t) * 16 * BK);
+                    if ((gb + 1) * GT + t < NT16)
+                        wf[(gb + 1) & 1][t] = *reinterpret_cast<const f32x4*>(sb + w_off + ((gb + 1) * GT + t) * 16 * BK);
             }
             if constexpr (BF) {
                 // one v_mfma_f32_16x16x32_bf16 per tile: the b128 IS the lane's fragment (8 bf16 = k 8 kg .. 8 kg + 7)
@@ -302,8 +306,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
                 for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                     for (int t = 0; t < GT; ++t)
-                        acc[tt][gb * GT + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, wf[gb & 1][t]), __builtin_bit_cast(bf16x8, af[tt]), acc[tt][gb * GT + t], 0, 0, 0);
+                        if (gb * GT + t < NT16)
+                            acc[tt][gb * GT + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, wf[gb & 1][t]), __builtin_bit_cast(bf16x8, af[tt]), acc[tt][gb * GT + t], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -311,8 +316,9 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const PPParams p) {
                     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                         for (int t = 0; t < GT; ++t)
-                            acc[tt][gb * GT + t] =
-                                __builtin_amdgcn_mfma_f32_16x16x4f32(wf[gb & 1][t][q], af[tt][q], acc[tt][gb * GT + t], 0, 0, 0);
+                            if (gb * GT + t < NT16)
+                                acc[tt][gb * GT + t] =
+                                    __builtin_amdgcn_mfma_f32_16x16x4f32(wf[gb & 1][t][q], af[tt][q], acc[tt][gb * GT + t], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);         // pins the DMA issue between the MFMA groups
             if (nstage >= 0 && gb == wave) issue_w(nstage, nc);
@@ -559,20 +565,20 @@ int num_cus() {
     return n;
 }
 
-template <int NTL, bool LN, bool RELU, int RES, bool BF = false, bool POOL = false, bool RSTD = false, bool CID = false>
+template <int NTL, bool LN, bool RELU, int RES, bool BF = false, bool POOL = false, bool RSTD = false, bool CID = false, int TRIM = 0>
 int launch(const PPParams& p0, hipStream_t stream) {
     PPParams p = p0;
     p.n_row_blocks = (p.M + BM - 1) / BM;
-    p.n_col_blocks = (p.N + NTL * 32 - 1) / (NTL * 32);
+    p.n_col_blocks = (p.N + NTL * 32 - 16 * TRIM - 1) / (NTL * 32 - 16 * TRIM);
     const long ntiles = (long)p.n_row_blocks * p.n_col_blocks;
     long nwg = 2L * num_cus();
     if (nwg > ntiles) nwg = ntiles;
 #ifdef LIME_STAMPS
     p.stamps = g_pp_stamp_buf;
 #endif
-    hipLaunchKernelGGL((gemm_pp_kernel<NTL, LN, RELU, RES, BF, POOL, RSTD, CID>), dim3((unsigned)nwg), dim3(256), 0, stream, p);
-    lime_set_last_linear_kernel("gemm_pp_kernel<%d, %s, %s, %d, %s, %s, %s, %s>", NTL, LN ? "true" : "false", RELU ? "true" : "false", RES,
-                                BF ? "true" : "false", POOL ? "true" : "false", RSTD ? "true" : "false", CID ? "true" : "false");   // as rocprofv3 prints it
+    hipLaunchKernelGGL((gemm_pp_kernel<NTL, LN, RELU, RES, BF, POOL, RSTD, CID, TRIM>), dim3((unsigned)nwg), dim3(256), 0, stream, p);
+    lime_set_last_linear_kernel("gemm_pp_kernel<%d, %s, %s, %d, %s, %s, %s, %s, %d>", NTL, LN ? "true" : "false", RELU ? "true" : "false", RES,
+                                BF ? "true" : "false", POOL ? "true" : "false", RSTD ? "true" : "false", CID ? "true" : "false", TRIM);   // as rocprofv3 prints it
     return lime_check_launch("lime_linear_f32");
 }
 
@@ -628,7 +634,15 @@ int lime_linear_pp(const lime_linear_args* a, hipStream_t s) {
         if (!tail_ok(320)) return LIME_PP_NOT_APPLICABLE;
         if (a->ln_rstd) {                              // training forward: residual + LayerNorm, rstd kept
             if (res == 0 || a->pool32) return LIME_PP_NOT_APPLICABLE;
+            if (a->N <= 304 && a->N >= 304 - 64)
+                return res == 1 ? launch<10, true, false, 1, false, false, true, false, 1>(p, s)
+                                : launch<10, true, false, 2, false, false, true, false, 1>(p, s);
             return res == 1 ? launch<10, true, false, 1, false, false, true>(p, s) : launch<10, true, false, 2, false, false, true>(p, s);
+        }
+        if (a->N <= 304 && a->N >= 304 - 64 && res != 0) {   // 19 column tiles (304 columns) cover N = 300: 5 % less MFMA work, 8 registers less
+            if (res == 1) return a->pool32 ? launch<10, true, false, 1, false, true, false, false, 1>(p, s)
+                                           : launch<10, true, false, 1, false, false, false, false, 1>(p, s);
+            return launch<10, true, false, 2, false, false, false, false, 1>(p, s);
         }
         if (res == 0) return launch<10, true, false, 0>(p, s);
         if (res == 1) return a->pool32 ? launch<10, true, false, 1, false, true>(p, s) : launch<10, true, false, 1>(p, s);
@@ -702,8 +716,13 @@ extern "C" int lime_linear_bf16(const lime_linear_bf16_args* a, void* stream) {
     if (ln) {
         switch (a->res_kind) {
             case 0: return launch<10, true, false, 0, true>(p, s);
-            case 2: return launch<10, true, false, 2, true>(p, s);
-            case 3: return a->pool32 ? launch<10, true, false, 3, true, true>(p, s) : launch<10, true, false, 3, true>(p, s);
+            case 2: return (a->N <= 304 && a->N >= 240) ? launch<10, true, false, 2, true, false, false, false, 1>(p, s)
+                                                         : launch<10, true, false, 2, true>(p, s);
+            case 3:
+                if (a->N <= 304 && a->N >= 240)
+                    return a->pool32 ? launch<10, true, false, 3, true, true, false, false, 1>(p, s)
+                                     : launch<10, true, false, 3, true, false, false, false, 1>(p, s);
+                return a->pool32 ? launch<10, true, false, 3, true, true>(p, s) : launch<10, true, false, 3, true>(p, s);
             default: break;
         }
         LIME_REQUIRE(false, LIME_ERR_UNSUPPORTED, "lime_linear_bf16: LayerNorm with an fp32 residual is not built");
