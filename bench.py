@@ -243,8 +243,7 @@ def kernel_profile(run, steps):
             from lime_cikm25_amd.training import negative_log_softmax
             ts, model, b = run.ts, run.model, run.batches[0]
             for _ in range(steps):
-                ts.grad.zero_()
-                negative_log_softmax(model(*b)).backward()
+                ts.backward(negative_log_softmax(model(*b)))
                 ts.update()
         else:
             for _ in range(steps):

@@ -688,11 +688,33 @@ class TrainStep:
         self.step_count = 0
         self.last_norm = None
 
+    def backward(self, loss):
+        """``loss.backward()`` with the gradients landing in the flat bucket.  The parameters' ``.grad`` views are taken away for
+        the duration of the backward pass, so autograd hands every parameter its gradient tensor as it is (no accumulation
+        kernel: with the views in place AccumulateGrad runs one ``grad += g`` launch per parameter, 72 a step, and the bucket has
+        to be zeroed first); the tensors are then gathered into the bucket with one ``lime_multi_copy`` launch per 32
+        parameters and the views are put back.  A parameter that received no gradient in this step gets zeros."""
+        self._check_bucket()
+        views = [p.grad for _, p in self._params]
+        for _, p in self._params:
+            p.grad = None
+        try:
+            loss.backward()
+            pairs = []
+            for (_, p), v in zip(self._params, views):
+                if p.grad is None:
+                    v.zero_()
+                else:
+                    pairs.append((v, p.grad))
+            keep = ops.multi_copy(pairs)
+        finally:
+            for (_, p), v in zip(self._params, views):
+                p.grad = v
+        del keep
+
     def backward_and_update(self, loss):
         """loss.backward() into the flat bucket, all-reduce, clip, Adam.  Returns the (device) gradient norm."""
-        self._check_bucket()
-        self.grad.zero_()
-        loss.backward()
+        self.backward(loss)
         distributed.allreduce_mean_(self.grad, self.group)
         return self.update()
 
