@@ -58,12 +58,12 @@ _SIDE = {}
 # encoder's: the compacted launches have few tiles (423 / 251 / 502 on 512 workgroup slots for the title, a half-empty last round
 # for the body), so the two chains fill each other's gaps ({0,2,3} 2.288, {0,2,3,7} 2.210; on the dense path, whose launches fill
 # every slot for ten rounds, the same fork -- branch 1 -- measured slower; beside the forked title chain branch 4 now pays:
-# {0,2,3,7} 2.242, {0,2,3,4,7} 2.206, + {5,6} 2.230).  OVERLAP_BRANCHES is the set that is forked (LIME_OVERLAP_STREAMS = 0: none, 2: the two small branches --
+# {0,2,3,7} 2.242, {0,2,3,4,7} 2.206; three interleaved 300-step runs each: {0,2,3,4,7} 2.195, + 5 2.175, + 6 2.170, + {5,6} 2.155).  OVERLAP_BRANCHES is the set that is forked (LIME_OVERLAP_STREAMS = 0: none, 2: the two small branches --
 # the default, 4.557 vs 4.593 ms --, 1: all three).  The title / body fork is off by default: the big GEMMs hold two
 # workgroups of 256 VGPRs x 4 waves and 61 KB LDS on every CU, so nothing else becomes resident beside them and that fork
 # measured slower (4.651 ms).
 def _branches(spec):
-    named = {'0': frozenset(), '1': frozenset((0, 1, 2, 3, 4, 5, 6, 7)), '2': frozenset((0, 2, 3, 4, 7))}
+    named = {'0': frozenset(), '1': frozenset((0, 1, 2, 3, 4, 5, 6, 7)), '2': frozenset((0, 2, 3, 4, 5, 6, 7))}
     return named[spec] if spec in named else frozenset(int(x) for x in spec.split('+'))       # e.g. LIME_OVERLAP_STREAMS=0+2+4
 
 
