@@ -188,19 +188,33 @@ class LIME(nn.Module):
         """Flat batch of M news -> [M, output_dim].  title_text [M, T], content_text [M, L] int32; the rest [M]."""
         M = title_text.shape[0]
         cdim = self.base_news_encoder.news_embedding_dim
-        fused = torch.empty((M, 2 * cdim), dtype=torch.float32, device=title_text.device)
-        # the freshness branch (buckets, two 10-row tables, one small GEMM) does not depend on the content encoder and
-        # writes the other half of the fused rows: it runs on a side stream under the token encoders
         main = torch.cuda.current_stream()
         side = _side_stream(title_text.device)
+        if isinstance(self.project, nn.Identity):
+            fused = torch.empty((M, 2 * cdim), dtype=torch.float32, device=title_text.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.freshness_encoder.encode_flat(freshness, lifetime, fused[:, cdim:])
+            self.base_news_encoder.encode_flat(title_text, title_mask, content_text, category, subCategory, fused[:, :cdim])
+            main.wait_stream(side)
+            return fused
+        # project(cat(content, fresh)) = content W_c^T + (fresh W_f^T + b), and fresh = tanh(dense(cat(E_f[b1], E_l[b2]))) takes one of
+        # num_buckets^2 values: the freshness half of `project` is a [100, 400] table G per forward (three GEMMs on 10 / 100-row
+        # operands instead of one on M rows), gathered into the content GEMM as a residual by the bucket pair (newsEncoders.py:60-83,
+        # :151-153; same sums, associated per half).  The branch depends on the inputs' buckets and the weights only: side stream.
+        fe = self.freshness_encoder
+        E, nb = fe.freshness_embedding.embedding_dim, fe.num_buckets
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            self.freshness_encoder.encode_flat(freshness, lifetime, fused[:, cdim:])
-        self.base_news_encoder.encode_flat(title_text, title_mask, content_text, category, subCategory, fused[:, :cdim])
+            pair = torch.add(ops.bucketize(lifetime), ops.bucketize(freshness), alpha=nb)                  # b_f * nb + b_l, int32 [M]
+            t_f = ops.linear(fe.freshness_embedding.weight, fe.dense.weight[:, :E], None)                 # [nb, cdim]
+            t_l = ops.linear(fe.lifetime_embedding.weight, fe.dense.weight[:, E:], fe.dense.bias)         # [nb, cdim]
+            fresh = torch.tanh(t_f.unsqueeze(1) + t_l.unsqueeze(0)).view(nb * nb, -1)                     # row b_f * nb + b_l
+            table = ops.linear(fresh, self.project.weight[:, cdim:], self.project.bias)                   # [nb^2, final_dim]
+        content = torch.empty((M, cdim), dtype=torch.float32, device=title_text.device)
+        self.base_news_encoder.encode_flat(title_text, title_mask, content_text, category, subCategory, content)
         main.wait_stream(side)
-        if isinstance(self.project, nn.Identity):
-            return fused
-        return ops.linear(fused, self.project.weight, self.project.bias)             # newsEncoders.py:152-153
+        return ops.linear(content, self.project.weight[:, :cdim], None, res=table, res_ids=pair)         # newsEncoders.py:152-153
 
     # ---- per-news content cache (eval: a news occurs in many impressions, its token encoders need to run once) ----------
     def build_content_cache(self, title_text, title_mask, content_text, category, subCategory, rows_per_pass=8192):
