@@ -239,6 +239,10 @@ int lime_mean_pool_f32(const float* x, int64_t ldx, float* out, int64_t ldo, int
  * indices are bit-exact without a device logf.  out int32 [n].  NaN -> 0, +inf -> 9 (the reference raises).
  */
 int lime_bucketize_f32(const float* x, int32_t* out, int64_t n, void* stream);
+/* The same rule for another num_buckets (config.py:59): out = #{k : x >= cuts[k]} against an ascending device table of the
+ * num_buckets - 1 fp32 cut points of b = min(trunc(log(max(x,1)) / log(86400) * (num_buckets/7)), num_buckets - 1), which the
+ * host derives from the reference formula's own fp32 evaluation (lime_cikm25_amd.newsEncoders.bucket_cut_points). */
+int lime_bucketize_cuts_f32(const float* x, const float* cuts, int32_t n_cuts, int32_t* out, int64_t n, void* stream);
 
 /*
  * lime_topic_rep_f32: out[r, :] = category_affine(cat[cat_table[cat[r]], sub_table[sub[r]]])

@@ -104,6 +104,17 @@ __global__ __launch_bounds__(256) void bucketize_kernel(const float* __restrict_
     }
 }
 
+// the same against a caller-supplied ascending cut-point table (num_buckets != 10)
+__global__ __launch_bounds__(256) void bucketize_cuts_kernel(const float* __restrict__ x, const float* __restrict__ cuts, int n_cuts,
+                                                              int* __restrict__ out, long n) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float v = x[e];
+        int b = 0;
+        for (int k = 0; k < n_cuts; ++k) b += (v >= cuts[k]) ? 1 : 0;                          // NaN compares false
+        out[e] = b;
+    }
+}
+
 __global__ __launch_bounds__(256) void gather_rows_kernel(const int* __restrict__ idx, const float* __restrict__ table,
                                                            long ld_table, float* __restrict__ out, long ldo, long rows,
                                                            int dim) {
@@ -693,6 +704,14 @@ extern "C" int lime_bucketize_f32(const float* x, int32_t* out, int64_t n, void*
     if (n == 0) return LIME_OK;
     hipLaunchKernelGGL(bucketize_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, (long)n);
     return lime_check_launch("lime_bucketize_f32");
+}
+
+extern "C" int lime_bucketize_cuts_f32(const float* x, const float* cuts, int32_t n_cuts, int32_t* out, int64_t n, void* stream) {
+    LIME_REQUIRE(x && out && cuts, LIME_ERR_BAD_ARG, "lime_bucketize_cuts_f32: NULL pointer");
+    LIME_REQUIRE(n >= 0 && n_cuts >= 0 && n_cuts <= 4096, LIME_ERR_BAD_ARG, "lime_bucketize_cuts_f32: bad counts");
+    if (n == 0) return LIME_OK;
+    hipLaunchKernelGGL(bucketize_cuts_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, cuts, n_cuts, out, (long)n);
+    return lime_check_launch("lime_bucketize_cuts_f32");
 }
 
 extern "C" int lime_gather_rows_f32(const int32_t* idx, const float* table, int64_t ld_table, float* out, int64_t ldo,

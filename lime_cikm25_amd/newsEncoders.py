@@ -103,6 +103,41 @@ def _i32(t):
     return t if t.dtype == torch.int32 else t.to(torch.int32)
 
 
+def reference_bucket(x, num_buckets):
+    """The reference's bucket rule (newsEncoders.py:53-58) as torch evaluates it in fp32 on the CPU."""
+    x = torch.clamp(x.float(), min=1)
+    scaled = torch.log(x) / torch.log(torch.tensor(60 * 60 * 24.0))
+    return torch.clamp((scaled * (num_buckets / 7)).long(), max=num_buckets - 1)
+
+
+def bucket_cut_points(num_buckets):
+    """The num_buckets - 1 fp32 cut points of the bucket rule: the smallest float whose bucket is >= k, for k = 1 .. num_buckets - 1,
+    found by bisection over the bit patterns of the positive floats with the rule's own fp32 evaluation on the CPU (the rule is
+    monotone; a +-64-ulp window around every cut is re-checked).  Comparing against them reproduces the rule bit-exactly on the
+    device without depending on any logf (for num_buckets = 10 this is the table built into lime_bucketize_f32)."""
+    import numpy as np
+    top = int(np.array([np.finfo(np.float32).max], dtype=np.float32).view(np.uint32)[0])
+    one = int(np.array([1.0], dtype=np.float32).view(np.uint32)[0])
+    f = lambda bits: reference_bucket(torch.from_numpy(np.array(bits, dtype=np.uint32).view(np.float32).copy()), num_buckets)
+    cuts = []
+    for k in range(1, num_buckets):
+        lo, hi = one, top                                   # bucket(lo) = 0 < k <= bucket(hi)
+        if int(f([hi])[0]) < k:
+            raise ValueError('bucket %d is never reached with num_buckets = %d' % (k, num_buckets))
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            if int(f([mid])[0]) >= k:
+                hi = mid
+            else:
+                lo = mid
+        win = list(range(max(one, hi - 64), min(top, hi + 64) + 1))
+        b = f(win)
+        if not bool(((b >= k) == (torch.tensor(win) >= hi)).all()):
+            raise ValueError('the bucket rule is not monotone around its cut point %d (num_buckets = %d)' % (k, num_buckets))
+        cuts.append(hi)
+    return torch.from_numpy(np.array(cuts, dtype=np.uint32).view(np.float32).copy())
+
+
 class FreshnessEncoder(nn.Module):
     """newsEncoders.py:38-83.  hidden = content dim always: ``fusion_method == 'add' or 'gated'`` is truthy (:42-45)."""
 
@@ -111,8 +146,9 @@ class FreshnessEncoder(nn.Module):
         embedding_dim = config.freshness_embedding_dim
         hidden_dim = base_news_encoder.news_embedding_dim
         self.num_buckets = config.num_buckets
-        if self.num_buckets != 10:
-            raise NotImplementedError('bit-exact bucket cut points are derived for num_buckets = 10 (config.py:59)')
+        # num_buckets = 10 (config.py:59): the cut points are built into lime_bucketize_f32; any other count: derived here from the
+        # rule's own fp32 evaluation (a plain attribute, not a buffer: the state_dict keeps the reference's keys)
+        self._cuts = None if self.num_buckets == 10 else bucket_cut_points(self.num_buckets)
         self.freshness_embedding = nn.Embedding(self.num_buckets, embedding_dim)
         self.lifetime_embedding = nn.Embedding(self.num_buckets, embedding_dim)
         self.dense = nn.Linear(embedding_dim * 2, hidden_dim)
@@ -120,14 +156,20 @@ class FreshnessEncoder(nn.Module):
 
     def bucketize(self, x):
         """int64 like the reference (newsEncoders.py:53-58); computed by threshold comparison on the device."""
-        return ops.bucketize(x.float()).long()
+        return self.buckets(x.float()).long()
+
+    def buckets(self, x):
+        """int32 buckets of a flat fp32 tensor."""
+        if self._cuts is not None and self._cuts.device != x.device:
+            self._cuts = self._cuts.to(x.device)
+        return ops.bucketize(x, self._cuts)
 
     def encode_flat(self, freshness, lifetime, out):
         """freshness / lifetime: [M] fp32; out: [M, hidden] (may be a view of a wider buffer)."""
         M = freshness.numel()
         E = self.freshness_embedding.embedding_dim
-        fb = ops.bucketize(freshness)
-        lb = ops.bucketize(lifetime)
+        fb = self.buckets(freshness)
+        lb = self.buckets(lifetime)
         cat = torch.empty((M, 2 * E), dtype=torch.float32, device=out.device)
         ops.gather_rows(fb, self.freshness_embedding.weight, cat[:, :E])
         ops.gather_rows(lb, self.lifetime_embedding.weight, cat[:, E:])
@@ -206,7 +248,7 @@ class LIME(nn.Module):
         E, nb = fe.freshness_embedding.embedding_dim, fe.num_buckets
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            pair = torch.add(ops.bucketize(lifetime), ops.bucketize(freshness), alpha=nb)                  # b_f * nb + b_l, int32 [M]
+            pair = torch.add(fe.buckets(lifetime), fe.buckets(freshness), alpha=nb)                        # b_f * nb + b_l, int32 [M]
             t_f = ops.linear(fe.freshness_embedding.weight, fe.dense.weight[:, :E], None)                 # [nb, cdim]
             t_l = ops.linear(fe.lifetime_embedding.weight, fe.dense.weight[:, E:], fe.dense.bias)         # [nb, cdim]
             fresh = torch.tanh(t_f.unsqueeze(1) + t_l.unsqueeze(0)).view(nb * nb, -1)                     # row b_f * nb + b_l

@@ -280,11 +280,16 @@ def mean_pool(x, n_seq, S, out=None):
     return out
 
 
-def bucketize(x):
-    """int32 lifetime buckets (newsEncoders.py:53-58), bit-exact by threshold comparison."""
+def bucketize(x, cuts=None):
+    """int32 lifetime buckets (newsEncoders.py:53-58), bit-exact by threshold comparison.  cuts: fp32 device tensor of the
+    num_buckets - 1 ascending cut points for num_buckets != 10 (the default table is built into the kernel)."""
     lib = _lib.load()
     x = _vec(x.contiguous(), 'x')
     out = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+    if cuts is not None:
+        _vec(cuts, 'cuts')
+        check(lib.lime_bucketize_cuts_f32(_p(x), _p(cuts), cuts.numel(), _p(out), x.numel(), _stream()), 'lime_bucketize_cuts_f32')
+        return out
     check(lib.lime_bucketize_f32(_p(x), _p(out), x.numel(), _stream()), 'lime_bucketize_f32')
     return out
 

@@ -472,8 +472,8 @@ def mhsa_content(enc, title_text, title_mask, category, subCategory):
 def lime_tail(ne, content, freshness, lifetime):
     """LIME.forward, fusion 'concat' (newsEncoders.py:140-153), from the content encoder's output -> [M, 400]."""
     fe = ne.freshness_encoder
-    fb = ops.bucketize(freshness)
-    lb = ops.bucketize(lifetime)
+    fb = fe.buckets(freshness)
+    lb = fe.buckets(lifetime)
     fresh = linear(torch.cat([embedding(fe.freshness_embedding.weight, fb), embedding(fe.lifetime_embedding.weight, lb)], dim=1),
                    fe.dense, act='tanh')
     fused = torch.cat([content, fresh], dim=1)

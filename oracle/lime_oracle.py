@@ -45,10 +45,13 @@ BUCKET_THRESHOLDS = np.array(BUCKET_THRESHOLD_BITS, dtype=np.uint32).view(np.flo
 def bucketize(x, num_buckets=10):
     """newsEncoders.py:53-58.  x: float tensor -> int64 buckets in [0, num_buckets-1].
 
-    Only the reference default num_buckets=10 has a threshold table (the cut points depend on it).
+    The reference default num_buckets=10 has a threshold table (pinned by the goldens); other counts evaluate the rule directly.
     Non-finite inputs index out of range in the reference; here NaN -> 0 and +inf -> 9.
     """
-    assert num_buckets == 10, 'threshold table is derived for num_buckets=10 (config.py:59)'
+    if num_buckets != 10:                         # no threshold table: the rule itself, as torch evaluates it in fp32 on the CPU
+        xf = torch.clamp(x.detach().cpu().float(), min=1)
+        scaled = torch.log(xf) / torch.log(torch.tensor(60 * 60 * 24.0))
+        return torch.clamp((scaled * (num_buckets / 7)).long(), max=num_buckets - 1)
     xn = x.detach().cpu().float().numpy()
     b = np.searchsorted(BUCKET_THRESHOLDS, xn, side='right').astype(np.int64)
     b[np.isnan(xn)] = 0

@@ -301,3 +301,22 @@ def test_eval_harness_on_gpu(tmp_path):
         ref = scoring(tf, rf)
     assert np.allclose(got, ref, atol=1e-3)
     assert (tmp_path / 'hip.txt').read_text().count('\n') == 11
+
+
+@pytest.mark.parametrize('nb', [7, 16])
+def test_other_bucket_counts(nb):
+    """config.num_buckets != 10 (config.py:59): the device compares against cut points derived from the rule's own fp32 evaluation
+    -- bucket indices bit-exact with the rule on both sides of every cut, logits against the oracle."""
+    from lime_cikm25_amd.newsEncoders import bucket_cut_points
+    cfg = make_config(max_history_num=10, max_title_length=16, max_abstract_length=32, batch_size=8, vocabulary_size=5000, num_buckets=nb)
+    model, sd = gpu_model(cfg, seed=43)
+    cuts = bucket_cut_points(nb).numpy()
+    bits = cuts.view(np.uint32)
+    x = np.concatenate([(bits - 1).view(np.float32), cuts, (bits + 1).view(np.float32), np.array([0.0, 1.0, 86400.0, 3e38], np.float32)])
+    fe = model.news_encoder.freshness_encoder
+    got = fe.bucketize(torch.from_numpy(x).cuda()).cpu()
+    assert torch.equal(got, O.bucketize(torch.from_numpy(x), nb))
+    batch = synth.make_batch(cfg, 8, 2, seed=44)
+    batch['news_freshness'].reshape(-1)[:len(cuts)] = torch.from_numpy(cuts)
+    logits = run(model, batch, False)
+    assert rel_err(logits.numpy(), O.model_forward(sd, cfg, batch).numpy()) < TOL

@@ -111,3 +111,21 @@ def test_encode_once_composition_equals_model_forward_on_expanded_rows():
         exp[k] = v.reshape((B * K,) + tuple(v.shape[2:])) if (k.startswith('news_') or k == 'remaining_lifetime') else v.repeat_interleave(K, dim=0)
     want = O.model_forward(sd, cfg, exp, eval_shape=True).view(B, K)                 # n_src = rows = B * K
     assert rel_err(got.numpy(), want.numpy()) < 1e-5
+
+
+def test_bucket_cut_points_reproduce_the_table_and_the_rule():
+    """newsEncoders.bucket_cut_points derives the cut points of the bucket rule (newsEncoders.py:53-58) for any num_buckets from
+    the rule's own fp32 evaluation: for 10 it must give the table pinned by the reference's goldens, for other counts comparison
+    against the cut points must equal the rule on random values and on both sides of every cut."""
+    from lime_cikm25_amd.newsEncoders import bucket_cut_points, reference_bucket
+    assert np.array_equal(bucket_cut_points(10).numpy().view(np.uint32), np.array(O.BUCKET_THRESHOLD_BITS, dtype=np.uint32))
+    rng = np.random.default_rng(0)
+    for nb in (3, 7, 12, 25):
+        cuts = bucket_cut_points(nb).numpy()
+        assert len(cuts) == nb - 1 and np.all(np.diff(cuts) > 0)
+        bits = cuts.view(np.uint32)
+        near = np.concatenate([bits - 1, bits, bits + 1]).astype(np.uint32).view(np.float32)
+        x = np.concatenate([near, np.exp(rng.uniform(0, 80, 20000)).astype(np.float32), np.array([0.0, 0.5, 1.0, -3.0], np.float32)])
+        want = reference_bucket(torch.from_numpy(x), nb).numpy()
+        assert np.array_equal(np.searchsorted(cuts, x, side='right'), want)
+        assert np.array_equal(O.bucketize(torch.from_numpy(x), nb).numpy(), want)
