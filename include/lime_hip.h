@@ -324,6 +324,11 @@ int lime_lifetime_score_f32(const float* user, const float* news, const float* r
 /* lime_row_scale_f32: out[r, :] = scale[r] * x[r, :]   (layers.py:84 when use_residual_connection is off) */
 int lime_row_scale_f32(const float* x, const float* scale, float* out, int64_t rows, int32_t D, void* stream);
 
+/* lime_fuse_rows_f32: LIME's fusion_method 'add' (gate == NULL: out = a + b) and 'gated' (out = gate * a + (1 - gate) * b),
+ * newsEncoders.py:154-159; [rows, cols] matrices with leading dimensions. */
+int lime_fuse_rows_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* gate, int64_t ldg, float* out, int64_t ldo,
+                       int64_t rows, int32_t cols, void* stream);
+
 /* lime_gather_rows_f32: out[r, 0:dim) = table[idx[r], 0:dim)   (nn.Embedding lookups of small tables) */
 int lime_gather_rows_f32(const int32_t* idx, const float* table, int64_t ld_table, float* out, int64_t ldo, int64_t rows,
                          int32_t dim, void* stream);

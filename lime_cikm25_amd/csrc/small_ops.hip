@@ -104,6 +104,26 @@ __global__ __launch_bounds__(256) void bucketize_kernel(const float* __restrict_
     }
 }
 
+// LIME's 'add' / 'gated' fusion (newsEncoders.py:154-159): out = a + b, or gate * a + (1 - gate) * b
+__global__ __launch_bounds__(256) void fuse_rows_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
+                                                         const float* __restrict__ gate, long ldg, float* __restrict__ out, long ldo,
+                                                         long rows, int cols) {
+    const long total = rows * cols;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / cols;
+        const int c = (int)(e - r * cols);
+        const float x = a[r * lda + c], y = b[r * ldb + c];
+        float v;
+        if (gate) {
+            const float g = gate[r * ldg + c];
+            v = g * x + (1.0f - g) * y;
+        } else {
+            v = x + y;
+        }
+        out[r * ldo + c] = v;
+    }
+}
+
 // the same against a caller-supplied ascending cut-point table (num_buckets != 10)
 __global__ __launch_bounds__(256) void bucketize_cuts_kernel(const float* __restrict__ x, const float* __restrict__ cuts, int n_cuts,
                                                               int* __restrict__ out, long n) {
@@ -704,6 +724,17 @@ extern "C" int lime_bucketize_f32(const float* x, int32_t* out, int64_t n, void*
     if (n == 0) return LIME_OK;
     hipLaunchKernelGGL(bucketize_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, (long)n);
     return lime_check_launch("lime_bucketize_f32");
+}
+
+extern "C" int lime_fuse_rows_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* gate, int64_t ldg, float* out,
+                                  int64_t ldo, int64_t rows, int32_t cols, void* stream) {
+    LIME_REQUIRE(a && b && out, LIME_ERR_BAD_ARG, "lime_fuse_rows_f32: NULL pointer");
+    LIME_REQUIRE(rows >= 0 && cols > 0 && lda >= cols && ldb >= cols && ldo >= cols && (!gate || ldg >= cols), LIME_ERR_BAD_ARG,
+                 "lime_fuse_rows_f32: bad dims");
+    if (rows == 0) return LIME_OK;
+    hipLaunchKernelGGL(fuse_rows_kernel, dim3(grid_for(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, a, (long)lda, b, (long)ldb, gate,
+                       (long)ldg, out, (long)ldo, (long)rows, cols);
+    return lime_check_launch("lime_fuse_rows_f32");
 }
 
 extern "C" int lime_bucketize_cuts_f32(const float* x, const float* cuts, int32_t n_cuts, int32_t* out, int64_t n, void* stream) {

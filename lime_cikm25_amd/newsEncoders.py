@@ -189,7 +189,8 @@ class FreshnessEncoder(nn.Module):
 
 
 class LIME(nn.Module):
-    """newsEncoders.py:87-161 with fusion_method = 'concat' (the default and the scoring path)."""
+    """newsEncoders.py:87-161: content + freshness, fused by 'concat' + project (the default, 400 columns), 'add' or 'gated' (the
+    content encoder's 900 columns)."""
 
     def __init__(self, config, base_news_encoder):
         super().__init__()
@@ -202,18 +203,26 @@ class LIME(nn.Module):
                                          config.category_embedding_dim)
         self.base_news_encoder = base_news_encoder
         self.freshness_encoder = FreshnessEncoder(config, base_news_encoder)
-        self.fusion_method = config.fusion_method
-        if self.fusion_method != 'concat':
-            raise NotImplementedError("fusion_method %r: only 'concat' is on the scoring path (config.py:55)" % self.fusion_method)
+        self.fusion_method = config.fusion_method       # 'concat' (default), 'add' or 'gated' (newsEncoders.py:99, :111-126)
         self.auxiliary_loss = getattr(base_news_encoder, 'auxiliary_loss', None)      # newsEncoders.py:100-103
         content_dim = self.base_news_encoder.news_embedding_dim
         freshness_dim = content_dim                                                   # newsEncoders.py:106-107
-        self.output_dim = content_dim + freshness_dim
-        if self.final_dim:
-            self.project = nn.Linear(self.output_dim, self.final_dim)
-            self.output_dim = self.final_dim
-        else:
+        if self.fusion_method == 'concat':
+            self.output_dim = content_dim + freshness_dim
+            if self.final_dim:
+                self.project = nn.Linear(self.output_dim, self.final_dim)
+                self.output_dim = self.final_dim
+            else:
+                self.project = nn.Identity()
+        elif self.fusion_method == 'add':
+            self.output_dim = content_dim
             self.project = nn.Identity()
+        elif self.fusion_method == 'gated':
+            self.gate = nn.Linear(content_dim + freshness_dim, content_dim)
+            self.output_dim = content_dim
+            self.project = nn.Identity()
+        else:
+            raise ValueError('Unknown fusion method: %s' % self.fusion_method)
         self.news_embedding_dim = self.output_dim
 
     def initialize(self):
@@ -232,6 +241,15 @@ class LIME(nn.Module):
         cdim = self.base_news_encoder.news_embedding_dim
         main = torch.cuda.current_stream()
         side = _side_stream(title_text.device)
+        if self.fusion_method in ('add', 'gated'):                                   # newsEncoders.py:154-159
+            fused = torch.empty((M, 2 * cdim), dtype=torch.float32, device=title_text.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.freshness_encoder.encode_flat(freshness, lifetime, fused[:, cdim:])
+            self.base_news_encoder.encode_flat(title_text, title_mask, content_text, category, subCategory, fused[:, :cdim])
+            main.wait_stream(side)
+            gate = ops.linear(fused, self.gate.weight, self.gate.bias, act='sigmoid') if self.fusion_method == 'gated' else None
+            return ops.fuse_rows(fused[:, :cdim], fused[:, cdim:], gate)
         if isinstance(self.project, nn.Identity):
             fused = torch.empty((M, 2 * cdim), dtype=torch.float32, device=title_text.device)
             side.wait_stream(main)
@@ -266,6 +284,9 @@ class LIME(nn.Module):
         project is linear, so  rep = content . W[:, :c]^T  +  freshness . W[:, c:]^T + b : the first term depends on the news
         alone (all the token-encoder work), the second on the occurrence (two bucket lookups and two small GEMMs).  The
         cache holds the first term per news id; ``encode_cached`` adds the second.  Rebuild it when weights change."""
+        if self.fusion_method != 'concat':
+            raise NotImplementedError("the per-news content cache splits `project` into a content and a freshness half: fusion_method "
+                                      "'concat' only (got %r); score with Model.forward / util.compute_scores" % self.fusion_method)
         n = title_text.shape[0]
         cdim = self.base_news_encoder.news_embedding_dim
         dev = title_text.device

@@ -294,6 +294,23 @@ def bucketize(x, cuts=None):
     return out
 
 
+def fuse_rows(a, b, gate=None, out=None):
+    """LIME's 'add' / 'gated' fusion (newsEncoders.py:154-159): a + b, or gate * a + (1 - gate) * b; [rows, cols] matrices."""
+    lib = _lib.load()
+    _mat(a, 'a')
+    _mat(b, 'b')
+    if a.shape != b.shape or (gate is not None and gate.shape != a.shape):
+        raise ValueError('a, b (and gate) must have one shape')
+    if gate is not None:
+        _mat(gate, 'gate')
+    if out is None:
+        out = torch.empty(tuple(a.shape), dtype=torch.float32, device=a.device)
+    _mat(out, 'out')
+    check(lib.lime_fuse_rows_f32(_p(a), _ld(a), _p(b), _ld(b), _p(gate), _ld(gate) if gate is not None else 0, _p(out), _ld(out),
+                                 a.shape[0], a.shape[1], _stream()), 'lime_fuse_rows_f32')
+    return out
+
+
 def gather_rows(idx, table, out):
     lib = _lib.load()
     _vec(idx, 'idx', dtype=torch.int32)

@@ -67,7 +67,7 @@ class Trainer:
         self.truth_file = truth_file
         if getattr(config, 'dropout_rate', 0.0) == 0.0 and self.rank == 0:
             print('Trainer: config.dropout_rate is 0 -- the reference trains with 0.2 (config.py:78); pass dropout_rate=0.2 for its recipe')
-        self.cached_eval = cached_eval and config.lifetime_type == 'user_topic'
+        self.cached_eval = cached_eval and config.lifetime_type == 'user_topic' and config.fusion_method == 'concat'
         self.dc = device_corpus if device_corpus is not None else DeviceCorpus(corpus)
         self.dev = DeviceBehaviors.from_devtest(self.dc, corpus, 'dev')
         self.step = TrainStep(model, lr=config.lr, weight_decay=config.weight_decay, gradient_clip_norm=config.gradient_clip_norm)

@@ -476,7 +476,12 @@ def lime_tail(ne, content, freshness, lifetime):
     lb = fe.buckets(lifetime)
     fresh = linear(torch.cat([embedding(fe.freshness_embedding.weight, fb), embedding(fe.lifetime_embedding.weight, lb)], dim=1),
                    fe.dense, act='tanh')
+    if ne.fusion_method == 'add':                                                                                   # :154-155
+        return content + fresh
     fused = torch.cat([content, fresh], dim=1)
+    if ne.fusion_method == 'gated':                                                                                 # :156-159
+        gate = linear(fused, ne.gate, act='sigmoid')
+        return gate * content + (1 - gate) * fresh
     return fused if isinstance(ne.project, nn.Identity) else linear(fused, ne.project)
 
 

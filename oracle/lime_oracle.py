@@ -170,8 +170,8 @@ def freshness_encoder(sd, p, cfg, freshness, lifetime):
 
 def lime_news_encoder(sd, p, cfg, title_text, title_mask, content_text, category, subCategory, freshness, lifetime,
                       taps=None):
-    """LIME.forward with fusion_method='concat', newsEncoders.py:140-161.  -> [B, n, 400]."""
-    assert cfg.fusion_method == 'concat'
+    """LIME.forward, newsEncoders.py:140-161: fusion 'concat' (+ project, :151-153) -> [B, n, 400]; 'add' (:154-155) and 'gated'
+    (:156-159) -> [B, n, content dim]."""
     bp = p + 'base_news_encoder.'
     if cfg.content_encoder == 'CROWN':
         content = crown_news_encoder(sd, bp, cfg, title_text, content_text, category, subCategory, taps)
@@ -180,7 +180,17 @@ def lime_news_encoder(sd, p, cfg, title_text, title_mask, content_text, category
     else:
         raise ValueError('content encoder %r is outside the scoring path' % cfg.content_encoder)
     fresh, fb, lb = freshness_encoder(sd, p + 'freshness_encoder.', cfg, freshness, lifetime)
-    out = torch.cat([content, fresh], dim=-1) @ sd[p + 'project.weight'].t() + sd[p + 'project.bias']   # :152-153
+    if cfg.fusion_method == 'concat':
+        out = torch.cat([content, fresh], dim=-1)
+        if cfg.lime_output_dim:
+            out = out @ sd[p + 'project.weight'].t() + sd[p + 'project.bias']                           # :152-153
+    elif cfg.fusion_method == 'add':
+        out = content + fresh                                                                            # :155
+    elif cfg.fusion_method == 'gated':
+        gate = torch.sigmoid(torch.cat([content, fresh], dim=-1) @ sd[p + 'gate.weight'].t() + sd[p + 'gate.bias'])   # :157-158
+        out = gate * content + (1 - gate) * fresh                                                        # :159
+    else:
+        raise ValueError('Unknown fusion method: %s' % cfg.fusion_method)
     if taps is not None:
         taps.setdefault('content', []).append(content)
         taps.setdefault('freshness', []).append(fresh)

@@ -101,6 +101,12 @@ CASES = {
     # gradient goldens, the blocked attention backward
     'long_body': dict(cfg=dict(max_history_num=2, max_title_length=32, max_abstract_length=512, batch_size=2, **_SMALL),
                       B=2, N=2, seed=19, eval_shape=False, edit='none'),
+    # the other two fusion methods of LIME (newsEncoders.py:154-159): no `project`, the news representation keeps the content
+    # encoder's 900 columns and the whole user encoder runs 900 wide (10 heads x 90)
+    'fusion_add': dict(cfg=dict(fusion_method='add', max_history_num=6, max_title_length=8, max_abstract_length=16, batch_size=4, **_SMALL),
+                       B=4, N=3, seed=20, eval_shape=False, edit='none'),
+    'fusion_gated': dict(cfg=dict(fusion_method='gated', max_history_num=6, max_title_length=8, max_abstract_length=16, batch_size=4, **_SMALL),
+                         B=4, N=3, seed=21, eval_shape=False, edit='none'),
 }
 
 WEIGHT_SEED = 7

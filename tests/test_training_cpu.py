@@ -38,7 +38,7 @@ def oracle_grads(name, rows=None):
     return g, names, sd, loss.detach()
 
 
-@pytest.mark.parametrize('name', ['cfg1_crown', 'cfg1_mhsa', 'spill'])
+@pytest.mark.parametrize('name', ['cfg1_crown', 'cfg1_mhsa', 'spill', 'fusion_gated'])
 def test_oracle_gradients_match_the_reference(name):
     g, names, sd, loss = oracle_grads(name)
     assert abs(float(loss) - float(g['loss'])) < 1e-5 * max(1.0, abs(float(g['loss'])))
