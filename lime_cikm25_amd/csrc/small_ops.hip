@@ -88,6 +88,23 @@ __global__ __launch_bounds__(256) void mean_pool_vec4_kernel(const float* __rest
     }
 }
 
+// short "sequences" (the S / 32 block rows the pooled GEMM epilogue leaves: 4 rows at S = 128, 16 at S = 512): one thread per
+// (sequence, four columns), rows summed in order -- a workgroup per sequence would be 8,000+ workgroups of almost no work
+__global__ __launch_bounds__(256) void mean_pool_flat_kernel(const float* __restrict__ x, long ldx, float* __restrict__ out,
+                                                              long ldo, long n_seq, int S, int dim) {
+    const int nc = dim >> 2;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_seq * nc) return;
+    const long s = e / nc;
+    const int c = (int)(e - s * nc) * 4;
+    const float* px = x + s * S * ldx + c;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < S; ++t) acc += *reinterpret_cast<const f32x4*>(px + (long)t * ldx);
+    const float inv = 1.0f / (float)S;
+    float* po = out + s * ldo + c;
+    po[0] = acc[0] * inv; po[1] = acc[1] * inv; po[2] = acc[2] * inv; po[3] = acc[3] * inv;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // lifetime / freshness buckets: comparison against the fp32 cut points (see oracle/lime_oracle.py)
 // ---------------------------------------------------------------------------------------------------
@@ -709,7 +726,10 @@ extern "C" int lime_mean_pool_f32(const float* x, int64_t ldx, float* out, int64
     LIME_REQUIRE(n_seq >= 0 && S > 0 && dim > 0 && ldx >= dim && ldo >= dim, LIME_ERR_BAD_ARG, "lime_mean_pool_f32: bad dims");
     if (n_seq == 0) return LIME_OK;
     const bool v4 = dim % 4 == 0 && dim <= 1024 && ldx % 4 == 0 && ((uintptr_t)x % 16 == 0);
-    if (v4)
+    if (v4 && S <= 16 && n_seq >= 512)
+        hipLaunchKernelGGL(mean_pool_flat_kernel, dim3((unsigned)(((long)n_seq * (dim >> 2) + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           x, (long)ldx, out, (long)ldo, (long)n_seq, S, dim);
+    else if (v4)
         hipLaunchKernelGGL(mean_pool_vec4_kernel, dim3((unsigned)n_seq), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, out,
                            (long)ldo, S, dim);
     else
