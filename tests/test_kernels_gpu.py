@@ -596,3 +596,63 @@ def test_token_attention_bf16(ops, S):
     from lime_cikm25_amd._lib import LimeHipError
     with pytest.raises(LimeHipError):
         ops.token_attention_bf16(d[:96 * 2, :W], d[:96 * 2, W:2 * W], d[:96 * 2, 2 * W:], 2, 96, h, hd, scale)
+
+
+# ---------------------------------------------------------------------------------------------------
+# gemm_mid_kernel (csrc/gemm_mid_f32.hip): randomized shapes / epilogues against an fp64 statement
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('seed', range(24))
+def test_linear_mid_kernel_randomized(ops, seed):
+    """Small / mid-M launches with 16-byte friendly operands take the LDS-DMA ring kernel: random M, N, K (tails in every
+    direction), activation, bias, a gathered A operand, the three residual kinds, a device-side row count."""
+    import ctypes
+    from lime_cikm25_amd import _lib
+    rng = np.random.default_rng(1000 + seed)
+    M = int(rng.choice([1, 3, 31, 64, 65, 127, 200, 700, 1760, 3000]))
+    N = int(rng.choice([4, 60, 64, 68, 200, 400, 900])) 
+    K = int(rng.choice([16, 20, 52, 300, 400, 1000, 1800]))
+    act = [None, 'relu', 'tanh', 'sigmoid'][int(rng.integers(0, 4))]
+    bias = rnd(N, seed=seed + 1) if rng.random() < 0.7 else None
+    w = rnd(N, K, seed=seed + 2, scale=1 / math.sqrt(K))
+    gather = rng.random() < 0.3
+    if gather:
+        table = rnd(500, K, seed=seed + 3)
+        ids = torch.from_numpy(rng.integers(0, 500, size=M).astype(np.int32))
+        a_full = table[ids.long()]
+        a_arg, ids_arg = dev(table), dev(ids)
+    else:
+        a_full = rnd(M, K, seed=seed + 3)
+        a_arg, ids_arg = dev(a_full), None
+    kind = int(rng.integers(0, 4))                          # 0 none, 1 broadcast rows (res_div), 2 periodic (res_mod), 3 gathered (res_ids)
+    kw, res_rows = {}, None
+    if kind == 1:
+        div = int(rng.choice([1, 2, 50]))
+        res = rnd((M + div - 1) // div, N, seed=seed + 4)
+        res_rows = res[torch.arange(M) // div]
+        kw = dict(res=dev(res), res_div=div)
+    elif kind == 2:
+        mod = int(rng.choice([1, 7, 32]))
+        res = rnd(mod, N, seed=seed + 4)
+        res_rows = res[torch.arange(M) % mod]
+        kw = dict(res=dev(res), res_mod=mod)
+    elif kind == 3:
+        res = rnd(100, N, seed=seed + 4)
+        rid = torch.from_numpy(rng.integers(0, 100, size=M).astype(np.int32))
+        res_rows = res[rid.long()]
+        kw = dict(res=dev(res), res_ids=dev(rid))
+    want = a_full.double() @ w.double().t()
+    if bias is not None:
+        want = want + bias.double()
+    want = {'relu': torch.relu, 'tanh': torch.tanh, 'sigmoid': torch.sigmoid, None: lambda x: x}[act](want)
+    if res_rows is not None:
+        want = want + res_rows.double()
+    m_live = int(rng.integers(0, M + 1)) if rng.random() < 0.4 else None
+    out = torch.full((M, N), float('nan'), device='cuda')
+    m_dev = torch.tensor([m_live], dtype=torch.int32, device='cuda') if m_live is not None else None
+    got = ops.linear(a_arg, dev(w), dev(bias), act=act, a_ids=ids_arg, out=out, m_dev=m_dev, **kw)
+    torch.cuda.synchronize()
+    assert ctypes.string_at(_lib.load().lime_last_linear_kernel()).decode() == 'gemm_mid_kernel'
+    rows = M if m_live is None else m_live
+    if rows:
+        check(got[:rows], want[:rows].float(), what='M=%d N=%d K=%d act=%s kind=%d gather=%s m_dev=%s' % (M, N, K, act, kind, gather, m_live))
+    assert torch.isnan(got[rows:]).all()                     # rows beyond the device count are left untouched
