@@ -17,7 +17,7 @@ def main():
     src = os.path.join(ROOT, 'lime_cikm25_amd', 'csrc')
     if not os.path.exists(SO):
         subprocess.run(['hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', '-DLIME_STAMPS', '-o', SO,
-                        os.path.join(src, 'token_attn_f32.hip'), os.path.join(src, 'common.cpp')], check=True)
+                        os.path.join(src, 'token_attn_f32.hip'), os.path.join(src, 'token_attn_bf16.hip'), os.path.join(src, 'common.cpp')], check=True)
     lib = ctypes.CDLL(SO)
     v = ctypes.c_void_p
     lib.lime_token_attention_f32.argtypes = [v, v, v, ctypes.c_int64, v, v, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
