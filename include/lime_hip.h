@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LIME_ABI_VERSION 4
+#define LIME_ABI_VERSION 5
 
 typedef enum {
     LIME_OK = 0,
@@ -137,6 +137,41 @@ typedef struct {
 } lime_linear_bf16_args;
 
 int lime_linear_bf16(const lime_linear_bf16_args* args, void* stream);
+
+/*
+ * lime_encoder_ffn_bf16: the feed-forward half of an encoder layer in one launch on the bf16 matrix cores
+ * (newsEncoders.py:244-247 as nn.TransformerEncoderLayer runs it, :316-321 with the token mean pooling):
+ *     y = LayerNorm(x + W2 relu(W1 x + b1) + b2)          out = y (bf16 rows), or with pool32 the fp32 means of 32-row blocks
+ * x: bf16 [M, ldx], the E real columns followed by zero columns up to lime_ffn_bf16_model_columns() (304; E = 300 is carried as
+ * 304, as lime_linear_bf16 produces it).  w1p / w2p: the weights as lime_ffn_pack_bf16 lays them out.  The hidden state stays
+ * in registers and the layer input is read once: against lime_linear_bf16 x 2 the launch moves 0.6 KB instead of 3.8 KB per token
+ * through HBM.  Accumulation, residual and LayerNorm are fp32; b1 is applied in bf16 (it rides in the GEMM).
+ * Built for 289 <= E < 304 and F % 128 == 0; anything else returns LIME_ERR_UNSUPPORTED (use lime_linear_bf16).
+ * m_dev: optional device row count, as in lime_linear_args.
+ */
+typedef struct {
+    const uint16_t* x;    int64_t ldx;
+    const uint16_t* w1p;                    /* lime_ffn_pack_bf16's two outputs (opaque: the kernel's weight-ring slots, */
+    const uint16_t* w2p;                    /* each one contiguous block in the order of its LDS image); 16-byte aligned   */
+    const float* b2;                        /* fp32 [E] */
+    const float* ln_gamma; const float* ln_beta; float ln_eps;     /* fp32 [E] */
+    int32_t pool32;                         /* 1: out is float [M / 32, ldo] (M % 32 == 0); 0: out is bf16 [M, ldo] */
+    void* out;            int64_t ldo;      /* >= 304 columns; the columns behind E come out as zeros */
+    int32_t M, E, F;
+    int32_t reserved;                       /* must be 0 */
+    const int32_t* m_dev;
+} lime_ffn_bf16_args;
+
+int lime_encoder_ffn_bf16(const lime_ffn_bf16_args* args, void* stream);
+
+/* w1 fp32 [F, E] (ld ldw1), b1 fp32 [F], w2 fp32 [E, F] (ld ldw2) -> w1p, w2p: bf16 buffers of lime_ffn_pack_bf16_size(F, 0) and
+ * (F, 1) elements (F * 320 and F * 304). */
+int64_t lime_ffn_pack_bf16_size(int32_t F, int32_t which);
+int lime_ffn_pack_bf16(const float* w1, int64_t ldw1, const float* b1, const float* w2, int64_t ldw2, int32_t E, int32_t F,
+                       uint16_t* w1p, uint16_t* w2p, void* stream);
+
+/* the column count (304) the bf16 encoder-block kernels carry the model dimension in */
+int32_t lime_ffn_bf16_model_columns(void);
 
 /*
  * lime_to_bf16: dst[r, c] = bf16(src[r, c]) for r < rows, c < cols, zero for the padding up to [rows_out, cols_out]

@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_ui
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblime_hip.so')
 
-ABI_VERSION = 4          # LIME_ABI_VERSION of include/lime_hip.h this binding was written against
+ABI_VERSION = 5          # LIME_ABI_VERSION of include/lime_hip.h this binding was written against
 LIME_ACT = {None: 0, 'none': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3}
 
 
@@ -48,6 +48,22 @@ class LinearBf16Args(ctypes.Structure):
         ('act', c_int32),
         ('pool32', c_int32), ('reserved', c_int32),
         ('m_dev', c_void_p), ('c_ids', c_void_p),
+    ]
+
+
+class FfnBf16Args(ctypes.Structure):
+    """lime_ffn_bf16_args of include/lime_hip.h (same field order)."""
+    _fields_ = [
+        ('x', c_void_p), ('ldx', c_int64),
+        ('w1p', c_void_p),
+        ('w2p', c_void_p),
+        ('b2', c_void_p),
+        ('ln_gamma', c_void_p), ('ln_beta', c_void_p), ('ln_eps', c_float),
+        ('pool32', c_int32),
+        ('out', c_void_p), ('ldo', c_int64),
+        ('M', c_int32), ('E', c_int32), ('F', c_int32),
+        ('reserved', c_int32),
+        ('m_dev', c_void_p),
     ]
 
 
@@ -114,6 +130,10 @@ SIGNATURES = {
     'lime_linear_bf16': (c_int32, [ctypes.POINTER(LinearBf16Args), c_void_p]),
     'lime_token_attention_bf16': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32,
                                             c_int32, c_float, c_int32, c_void_p]),
+    'lime_encoder_ffn_bf16': (c_int32, [ctypes.POINTER(FfnBf16Args), c_void_p]),
+    'lime_ffn_pack_bf16': (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    'lime_ffn_bf16_model_columns': (c_int32, []),
+    'lime_ffn_pack_bf16_size': (c_int64, [c_int32, c_int32]),
     'lime_to_bf16': (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64, c_int64, c_int32, c_void_p]),
     'lime_mean_pool_bf16': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
     # training step

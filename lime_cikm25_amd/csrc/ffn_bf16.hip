@@ -1,0 +1,462 @@
+// lime_encoder_ffn_bf16: the feed-forward half of a TransformerEncoderLayer (newsEncoders.py:244-247, 316-321 --
+// linear1, ReLU, linear2, residual, norm2, and the token mean pooling behind the last layer) in ONE launch on the bf16
+// matrix cores.  The 512-wide hidden state never leaves the registers, the layer input is read from HBM once.
+//
+// Why (profiles/r02_notes.md): at bf16 rates the K = 300 encoder GEMMs of gemm_pp_f32.hip are bound by what a CU can pull
+// through its L2 -> LDS path (~21 B/clk/CU on L2 hits, less from HBM): a 128 x 320 x 304 tile stages 287 KB for 6.4k
+// cycles of MFMA work, and linear1 -> linear2 additionally writes and re-reads the hidden state (2 KB per token).  Here
+//   * a workgroup (4 waves, ONE per CU, 160 KB of LDS) keeps a 128-token tile of the layer input STATIONARY in LDS
+//     ([chunk][row][64 bytes], the swizzled image of gemm_pp_f32.hip) and streams only the weights: a ring of four 19 KB
+//     slots filled by LDS-DMA three steps ahead of their use (counted s_waitcnt vmcnt, raw s_barrier: the DMAs stay in
+//     flight across the barriers).  All weight bytes are L2 hits; per tile 622 KB for 20.5k cycles of MFMA work.
+//   * a wave owns 32 tokens x all columns.  A pass computes 128 hidden columns for its tokens (five steps, two 32-deep
+//     k chunks each), applies ReLU, rounds to bf16 IN REGISTER ORDER and feeds them straight back as the B operand of
+//     linear2 (four steps, 304 output columns): the k index of an MFMA is only a summation label, so linear2's weight
+//     columns are stored in the order the hidden registers come out (lime_ffn_pack_bf16) -- the trick of the bf16
+//     attention kernel's P V product.  No LDS round trip, no cross-lane movement.
+//   * linear1's bias rides in the GEMM: the input has zero pad columns (E = 300 carried as 304); the LDS image gets 1.0
+//     in column E and the packed weight holds the bias there.
+//   * residual (the stationary tile), LayerNorm and the 32-token block means are the fp32 epilogue; with `pool32` only
+//     [M / 32, 304] floats are written.
+// Tokens of a wave never meet another wave's: the stationary image needs no barrier, only the weight ring does (one per step).
+#include <type_traits>
+
+#include "lds_dma.h"
+
+using namespace lime_dev;
+
+#ifdef LIME_STAMPS
+// Diagnostic build only (tools/ffn_stamps.py): per-wave s_memtime sums of the step segments; never in liblime_hip.so.
+static unsigned long long* g_ffn_stamp_buf = nullptr;
+extern "C" void lime_debug_set_ffn_stamp_buffer(unsigned long long* p) { g_ffn_stamp_buf = p; }
+#define FSTAMP(i)                                                           \
+    {                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();         \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                 \
+        tsum[i] += t_ - tlast;                                              \
+        tlast = t_;                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+    }
+#else
+#define FSTAMP(i)
+#endif
+
+namespace {
+
+constexpr int BM = 128;                    // tokens per tile (4 waves x 32)
+constexpr int ND = 19, DP = 16 * ND;       // model columns carried: 304
+constexpr int NCH = 10;                    // 32-deep k chunks of the layer input (320 >= 304; the tail is zero-filled)
+constexpr int PW = 128;                    // hidden columns per pass
+constexpr int NT1 = PW / 16;               // linear1 output tiles per pass
+constexpr int SLAB = BM * 64;              // bytes of one chunk of the stationary image
+constexpr int XS_BYTES = NCH * SLAB;       // 81,920
+constexpr int SLOT = DP * 64;              // 19,456: one ring slot (two linear1 weight chunks, or one linear2 chunk)
+constexpr int NSLOT = 4;
+constexpr int CONST_OFF = XS_BYTES + NSLOT * SLOT;
+constexpr int LDS_BYTES = CONST_OFF + 3 * DP * 4;      // + b2, gamma, beta = 163,392 of the CU's 163,840
+constexpr int STEPS = 9;                   // per pass: five linear1 steps, four linear2 steps
+
+struct FfnP {
+    const uint16_t* x; long ldx;
+    const uint16_t* w1p;
+    const uint16_t* w2p;
+    const float* b2; const float* g; const float* beta; float eps;
+    void* out; long ldo;
+    int M, E, F;
+    const int* m_dev;
+#ifdef LIME_STAMPS
+    unsigned long long* stamps;
+#endif
+};
+
+constexpr int step_dmas(int pos) { return pos < 5 ? 4 : 5; }                       // DMA instructions per wave that fill the slot of step `pos`
+constexpr int steady_vm(int pos) { return step_dmas((pos + 1) % STEPS) + step_dmas((pos + 2) % STEPS); }
+
+template <bool POOL>
+__global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(const FfnP p) {
+    // ONE __shared__ object (a second one beside an LDS-DMA target makes hipcc drain vmcnt before every ds_read)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, kg = lane >> 4;
+    int M = p.M;
+    if (p.m_dev) {
+        const int m = __builtin_amdgcn_readfirstlane(*p.m_dev);
+        M = m < M ? (m > 0 ? m : 0) : M;
+    }
+    const int ntiles = (M + BM - 1) / BM;
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    const int NP = p.F / PW;
+    const int E = p.E;
+
+    float* const cs = reinterpret_cast<float*>(lds + CONST_OFF);
+    for (int c = tid; c < DP; c += 256) {
+        cs[c] = c < E ? p.b2[c] : 0.f;
+        cs[DP + c] = c < E ? p.g[c] : 0.f;
+        cs[2 * DP + c] = c < E ? p.beta[c] : 0.f;
+    }
+    __syncthreads();                                   // nothing in flight yet
+
+    // ---- loader: DMA instruction `idx` of an image covers rows 16 idx .. 16 idx + 15; lane l fills row 16 idx + (l >> 2),
+    // physical segment l & 3 = logical segment (l & 3) ^ swz4((l >> 4) & 3)
+    const int srow = lane >> 2;
+    const int lseg = (lane & 3) ^ swz4((lane >> 4) & 3);
+    const __amdgpu_buffer_rsrc_t rs_w1 = make_rsrc(p.w1p), rs_w2 = make_rsrc(p.w2p);
+    const unsigned ldxb = (unsigned)p.ldx * 2u;
+    unsigned char* const ring = lds + XS_BYTES;
+
+    auto kvalid = [&](int c) { return c * 32 + lseg * 8 < DP; };
+    // The packed weights (lime_ffn_pack_bf16) hold every ring slot as ONE contiguous block in the order of its LDS image, so a DMA
+    // instruction reads 1 KB of whole 128-byte lines (rows 608 / 1024 bytes apart would be 64-byte pieces that land on a quarter of
+    // the L2 channels): block + 1024 idx + 64 (row in the instruction) + 16 (logical segment).
+    const unsigned w_lane = (unsigned)srow * 64u + (unsigned)lseg * 16u;
+    // the slot of a linear1 step: weight rows PW pass .. + 127, chunks 2 j and 2 j + 1 -> [2][128 rows][64 B]; 16 instructions, 4 per wave
+    auto issue_w1 = [&](int slot, int pass, int j, int i) {
+        const int idx = 4 * wave + i;
+        dma16(rs_w1, ring + slot * SLOT + idx * 1024, w_lane + (unsigned)idx * 1024u, (pass * NCH + 2 * j) * SLAB);
+    };
+    // the slot of a linear2 step: all DP weight rows, hidden columns 32 (4 pass + kc) .. + 31 -> [304 rows][64 B]; 19 instructions,
+    // 5 per wave (wave 3 repeats the last one: the same bytes to the same place, so that every wave counts alike)
+    auto issue_w2 = [&](int slot, int pass, int kc, int i) {
+        int idx = 5 * wave + i;
+        idx = idx < ND ? idx : ND - 1;
+        dma16(rs_w2, ring + slot * SLOT + idx * 1024, w_lane + (unsigned)idx * 1024u, (NT1 / 2 * pass + kc) * SLOT);
+    };
+    // instruction i of this wave's share of the slot of step position POS
+    auto issue_one = [&](auto pos_c, int slot, int pass, int i) {
+        constexpr int POS = decltype(pos_c)::value;
+        if constexpr (POS < 5) issue_w1(slot, pass, POS, i);
+        else issue_w2(slot, pass, POS - 5, i);
+    };
+    auto issue_step = [&](auto pos_c, int slot, int pass) {
+        constexpr int POS = decltype(pos_c)::value;
+#pragma unroll
+        for (int i = 0; i < step_dmas(POS); ++i) issue_one(pos_c, slot, pass, i);
+    };
+    // this wave's 32 rows of the stationary tile: 2 x NCH instructions
+    auto load_x = [&](int t) {
+        const long row0 = (long)t * BM;
+        const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x + row0 * p.ldx);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rl = 16 * (2 * wave + j) + srow;
+            const unsigned vo = (row0 + rl < M) ? (unsigned)rl * ldxb + (unsigned)lseg * 16u : OOB;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) dma16(rs_x, lds + c * SLAB + (2 * wave + j) * 1024, kvalid(c) ? vo : OOB, c * 64);
+        }
+    };
+
+    // ---- compute state: v_mfma_f32_16x16x32_bf16, a = weight rows (output columns), b = tokens: lane (i, kg) reads ONE
+    // b128 = k 8 kg .. 8 kg + 7 of its row per operand and chunk; the result tile is D^T: lane (token i, kg) holds columns
+    // 16 t + 4 kg + r, r = 0..3
+    const int pseg = (kg ^ swz4((fi >> 2) & 3)) * 16;
+    const int x_off = (32 * wave + fi) * 64 + pseg;                 // + tt * 1024 + c * SLAB
+    const int w_off = fi * 64 + pseg;                               // + t * 1024
+    f32x4 acc1[2][NT1], acc2[2][ND];
+    bf16x8 hb[2][NT1 / 2];
+
+    // A step's MFMAs run in four groups; `part(g)` behind group g issues this wave's DMA instruction g of the slot three steps
+    // ahead (issued all at once behind the barrier, the workgroup's 16-19 instructions queue up in the CU's one address path and
+    // every wave sits in "DMA issue" for a quarter of its time -- s_memtime stamps; spread out, a wave meets an idle path).  The
+    // fragments of group g + 1 are read before the MFMAs of group g (the sched_barriers that pin the DMA issue also keep hipcc
+    // from hoisting those reads).
+    auto compute1 = [&](int slot, int j, auto&& part) {
+        const unsigned char* const sb = ring + slot * SLOT + w_off;
+        constexpr int GT = NT1 / 2;                                // 4 tiles per group: (chunk cc, tile half)
+        bf16x8 af[2][2], wf[2][GT];
+        auto read_group = [&](int g, int buf) {
+            const int cc = g >> 1, th = g & 1;
+            if (th == 0) {
+                const unsigned char* const xb = lds + (2 * j + cc) * SLAB + x_off;
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) af[cc][tt] = *reinterpret_cast<const bf16x8*>(xb + tt * 1024);
+            }
+#pragma unroll
+            for (int t = 0; t < GT; ++t) wf[buf][t] = *reinterpret_cast<const bf16x8*>(sb + cc * 8192 + (th * GT + t) * 1024);
+        };
+        read_group(0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g + 1 < 4) read_group(g + 1, (g + 1) & 1);
+            const int cc = g >> 1, th = g & 1;
+#pragma unroll
+            for (int t = 0; t < GT; ++t)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+                    acc1[tt][th * GT + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g & 1][t], af[cc][tt], acc1[tt][th * GT + t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            part(g);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto compute2 = [&](int slot, int kc, auto&& part) {
+        const unsigned char* const sb = ring + slot * SLOT + w_off;
+        constexpr int GT = 5;                                      // tiles per group (the last has 4)
+        bf16x8 wf[2][GT];
+#pragma unroll
+        for (int t = 0; t < GT; ++t) wf[0][t] = *reinterpret_cast<const bf16x8*>(sb + t * 1024);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int t = 0; t < GT; ++t)
+                if ((g + 1) * GT + t < ND) wf[(g + 1) & 1][t] = *reinterpret_cast<const bf16x8*>(sb + ((g + 1) * GT + t) * 1024);
+#pragma unroll
+            for (int t = 0; t < GT; ++t)
+                if (g * GT + t < ND) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+                        acc2[tt][g * GT + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g & 1][t], hb[tt][kc], acc2[tt][g * GT + t], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            part(g);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    int gs = 0;                                        // steps done: the slot of step s is s & 3
+    bool last = false;
+#ifdef LIME_STAMPS
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+    auto step = [&](auto pos_c, int pass) {
+        constexpr int POS = decltype(pos_c)::value;
+        // the slot of this step has landed (this wave's part); the DMAs of the next two steps stay in flight
+        if (POS == 0 && pass == 0) {
+            wait_vm<0>();                              // ... and the stationary tile
+            if (lane < 32) {                           // 1.0 in column E of this wave's rows: linear1's bias column
+                const int row = 32 * wave + lane;
+                const int koff = E & 31;
+                *reinterpret_cast<unsigned short*>(lds + (E >> 5) * SLAB + row * 64 + (((koff >> 3) ^ swz4((row >> 2) & 3)) * 16) +
+                                                   (koff & 7) * 2) = 0x3F80;
+            }
+        } else if (last && pass == NP - 1 && POS >= STEPS - 2) {
+            wait_vm<0>();                              // the ring runs dry behind the last tile
+        } else {
+            wait_vm<steady_vm(POS)>();
+        }
+        FSTAMP(0)                                      // 0: this wave's DMAs of the step have landed
+        ring_barrier();                                // every wave's part has landed; everyone is done with the slot of step s - 1
+        FSTAMP(1)                                      // 1: barrier
+        constexpr int NPOS = (POS + 3) % STEPS;         // the step whose slot this one refills (free since the barrier)
+        int np = pass + (POS + 3 >= STEPS ? 1 : 0);
+        bool go = true;
+        if (np == NP) { np = 0; go = !last; }
+        const int nslot = (gs + 3) & 3;
+        auto part = [&](int g) {
+            if (!go) return;
+            issue_one(std::integral_constant<int, NPOS>{}, nslot, np, g);
+            if (g == 3 && step_dmas(NPOS) == 5) issue_one(std::integral_constant<int, NPOS>{}, nslot, np, 4);
+        };
+        if constexpr (POS < 5) compute1(gs & 3, POS, part);
+        else compute2(gs & 3, POS - 5, part);
+        __builtin_amdgcn_sched_barrier(0);
+        FSTAMP(POS < 5 ? 3 : 4)                        // 3 / 4: fragment reads + MFMAs + DMA issue, linear1 / linear2 step
+        ++gs;
+    };
+
+    issue_step(std::integral_constant<int, 0>{}, 0, 0);
+    issue_step(std::integral_constant<int, 1>{}, 1, 0);
+    issue_step(std::integral_constant<int, 2>{}, 2, 0);
+    for (; tile < ntiles; tile += gridDim.x) {
+        last = tile + (int)gridDim.x >= ntiles;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the previous tile's residual reads are out of the image
+        load_x(tile);
+        FSTAMP(5)                                      // 5: stationary tile issue
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int t = 0; t < ND; ++t) acc2[tt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int pass = 0; pass < NP; ++pass) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int t = 0; t < NT1; ++t) acc1[tt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            step(std::integral_constant<int, 0>{}, pass);
+            step(std::integral_constant<int, 1>{}, pass);
+            step(std::integral_constant<int, 2>{}, pass);
+            step(std::integral_constant<int, 3>{}, pass);
+            step(std::integral_constant<int, 4>{}, pass);
+            // ReLU, round to bf16: tiles 2 kc and 2 kc + 1 side by side are the lane's 8 k slots of hidden chunk kc
+            // (k = 32 kc + 16 a + 4 kg + r at slot 4 a + r: the order lime_ffn_pack_bf16 gives linear2's weight columns)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int kc = 0; kc < NT1 / 2; ++kc) {
+                    u32x4 h;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const f32x4 v = acc1[tt][2 * kc + a];
+                        h[2 * a] = pack_bf16(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
+                        h[2 * a + 1] = pack_bf16(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+                    }
+                    hb[tt][kc] = __builtin_bit_cast(bf16x8, h);
+                }
+            step(std::integral_constant<int, 5>{}, pass);
+            step(std::integral_constant<int, 6>{}, pass);
+            step(std::integral_constant<int, 7>{}, pass);
+            step(std::integral_constant<int, 8>{}, pass);
+        }
+        FSTAMP(6)                                      // 6: ReLU / pack (and loop overhead)
+        // ---- epilogue: + b2 + residual (the stationary tile, column E is the bias column: not part of it), LayerNorm over the
+        // E real columns (the pad columns are exact zeros: zero weight rows, zero b2 / gamma / beta)
+        const long row0 = (long)tile * BM;
+        float sum[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};
+        const int te = E >> 4, kge = (E & 15) >> 2, re = E & 3;
+#pragma unroll
+        for (int t = 0; t < ND; ++t) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(cs + 16 * t + 4 * kg);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int row = 32 * wave + 16 * tt + fi;
+                const int seg = 2 * (t & 1) + (kg >> 1);
+                f32x4 r = unpack_bf16x4(*reinterpret_cast<const u32x2*>(lds + (t >> 1) * SLAB + row * 64 + ((seg ^ swz4((fi >> 2) & 3)) * 16) +
+                                                                        8 * (kg & 1)));
+                if (t == te && kg == kge) r[re] = 0.f;
+                const f32x4 v = acc2[tt][t] + b + r;
+                acc2[tt][t] = v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { sum[tt] += v[j]; sq[tt] += v[j] * v[j]; }
+            }
+        }
+        float mean[2], rstd[2];
+        const float inv_n = 1.0f / (float)E;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            float s1 = sum[tt], s2 = sq[tt];
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            mean[tt] = s1 * inv_n;
+            rstd[tt] = rsqrtf(fmaxf(s2 * inv_n - mean[tt] * mean[tt], 0.f) + p.eps);
+        }
+        const float* const gs_ = cs + DP + 4 * kg;
+        const float* const es_ = cs + 2 * DP + 4 * kg;
+        if constexpr (POOL) {
+            // block row (row0 + 32 wave) / 32: the column means over this wave's 32 tokens (all valid or all beyond M)
+            const int rl0 = 32 * wave;
+            const __amdgpu_buffer_rsrc_t rs_p = make_rsrc((char*)p.out + ((row0 + rl0) >> 5) * p.ldo * 4);
+            const bool rows_ok = row0 + rl0 < M;
+#pragma unroll
+            for (int t = 0; t < ND; ++t) {
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(gs_ + 16 * t);
+                const f32x4 be = *reinterpret_cast<const f32x4*>(es_ + 16 * t);
+                f32x4 y = (acc2[0][t] - mean[0]) * rstd[0] * ga + be;
+                y += (acc2[1][t] - mean[1]) * rstd[1] * ga + be;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = row16_sum(y[j]) * (1.0f / 32.0f);
+                buf_store4(y, rs_p, (rows_ok && fi == 0) ? (unsigned)(16 * t + 4 * kg) * 4u : OOB, 0);
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t rs_c = make_rsrc((char*)p.out + row0 * p.ldo * 2);
+            unsigned cof[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int rl = 32 * wave + 16 * tt + fi;
+                cof[tt] = (row0 + rl < M) ? (unsigned)rl * (unsigned)p.ldo * 2u + (unsigned)kg * 8u : OOB;
+            }
+#pragma unroll
+            for (int t = 0; t < ND; ++t) {
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(gs_ + 16 * t);
+                const f32x4 be = *reinterpret_cast<const f32x4*>(es_ + 16 * t);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) buf_store4_bf16((acc2[tt][t] - mean[tt]) * rstd[tt] * ga + be, rs_c, cof[tt] + (unsigned)t * 32u, 0);
+            }
+        }
+        FSTAMP(7)                                      // 7: epilogue
+    }
+#ifdef LIME_STAMPS
+    if (p.stamps && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p.stamps[((long)blockIdx.x * 4 + wave) * 8 + i] = tsum[i];
+    }
+#endif
+}
+
+// The weights as the kernel's ring slots (bf16, every slot one contiguous block in the order of its LDS image):
+//   w1p [F / 128 passes][10 chunks][128 rows][32 k]: W1[128 pass + row, 32 chunk + k] for k < E, b1 at k = E, zero behind (K = 320);
+//   w2p [F / 32 chunks][304 rows][32]: zero rows n >= E; position 8 kg + 4 a + r of a row holds W2[n, 32 chunk + 16 a + 4 kg + r] --
+//   the order in which the MFMA result registers of two neighbouring 16-column tiles (a = 0, 1) of the hidden state sit in a lane.
+__global__ void ffn_pack_kernel(const float* __restrict__ w1, long ldw1, const float* __restrict__ b1, const float* __restrict__ w2, long ldw2,
+                                int E, int F, uint16_t* __restrict__ w1p, uint16_t* __restrict__ w2p) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n1 = (long)F * (NCH * 32), n2 = (long)F * DP;
+    auto bf = [](float v) { return (uint16_t)(pack_bf16(v, 0.f) & 0xFFFFu); };
+    if (i < n1) {
+        const int kk = (int)(i & 31), row = (int)((i >> 5) % PW), c = (int)((i / (32 * PW)) % NCH), pass = (int)(i / (32L * PW * NCH));
+        const int n = PW * pass + row, k = 32 * c + kk;
+        w1p[i] = k < E ? bf(w1[n * ldw1 + k]) : (k == E ? bf(b1[n]) : (uint16_t)0);
+    } else if (i < n1 + n2) {
+        const long o = i - n1;
+        const int s_ = (int)(o & 31), n = (int)((o >> 5) % DP), blk = (int)(o / (32 * DP));
+        const int kg = s_ >> 3, a = (s_ >> 2) & 1, r = s_ & 3;
+        w2p[o] = n < E ? bf(w2[n * ldw2 + 32 * blk + 16 * a + 4 * kg + r]) : (uint16_t)0;
+    }
+}
+
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+}  // namespace
+
+extern "C" int lime_ffn_pack_bf16(const float* w1, int64_t ldw1, const float* b1, const float* w2, int64_t ldw2, int32_t E, int32_t F,
+                                  uint16_t* w1p, uint16_t* w2p, void* stream) {
+    LIME_REQUIRE(w1 && b1 && w2 && w1p && w2p, LIME_ERR_BAD_ARG, "lime_ffn_pack_bf16: NULL pointer");
+    LIME_REQUIRE(E > 0 && E < DP && E >= DP - 15 && F > 0 && F % PW == 0, LIME_ERR_UNSUPPORTED,
+                 "lime_ffn_pack_bf16: built for %d <= E < %d (E = %d) and F a multiple of %d (F = %d)", DP - 15, DP, E, PW, F);
+    LIME_REQUIRE(ldw1 >= E && ldw2 >= F, LIME_ERR_BAD_ARG, "lime_ffn_pack_bf16: leading dimension < row");
+    const long n = (long)F * (NCH * 32) + (long)F * DP;
+    hipLaunchKernelGGL(ffn_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w1, (long)ldw1, b1, w2, (long)ldw2,
+                       E, F, w1p, w2p);
+    return lime_check_launch("lime_ffn_pack_bf16");
+}
+
+extern "C" int32_t lime_ffn_bf16_model_columns(void) { return DP; }
+extern "C" int64_t lime_ffn_pack_bf16_size(int32_t F, int32_t which) { return which == 0 ? (int64_t)F * (NCH * 32) : (int64_t)F * DP; }
+
+extern "C" int lime_encoder_ffn_bf16(const lime_ffn_bf16_args* a, void* stream) {
+    LIME_REQUIRE(a != nullptr, LIME_ERR_BAD_ARG, "lime_encoder_ffn_bf16: args is NULL");
+    LIME_REQUIRE(a->x && a->w1p && a->w2p && a->b2 && a->ln_gamma && a->ln_beta && a->out, LIME_ERR_BAD_ARG, "lime_encoder_ffn_bf16: NULL pointer");
+    LIME_REQUIRE(a->M >= 0 && a->E > 0 && a->E < DP && a->E >= DP - 15 && a->F > 0 && a->F % PW == 0, LIME_ERR_UNSUPPORTED,
+                 "lime_encoder_ffn_bf16: built for %d <= E < %d (E = %d: one spare zero column carries linear1's bias) and F a multiple of %d (F = %d)",
+                 DP - 15, DP, a->E, PW, a->F);
+    LIME_REQUIRE(a->ldx >= DP && a->ldx % 8 == 0 && (uintptr_t)a->x % 16 == 0, LIME_ERR_BAD_ARG,
+                 "lime_encoder_ffn_bf16: x rows must hold %d bf16 columns, 16-byte aligned (ldx %% 8 == 0)", DP);
+    LIME_REQUIRE((uintptr_t)a->w1p % 16 == 0 && (uintptr_t)a->w2p % 16 == 0, LIME_ERR_BAD_ARG,
+                 "lime_encoder_ffn_bf16: packed weights must be 16-byte aligned (see lime_ffn_pack_bf16)");
+    LIME_REQUIRE(a->pool32 == 0 || a->pool32 == 1, LIME_ERR_BAD_ARG, "lime_encoder_ffn_bf16: pool32 must be 0 / 1");
+    if (a->pool32)
+        LIME_REQUIRE(a->M % 32 == 0 && a->ldo >= DP && a->ldo % 4 == 0 && (uintptr_t)a->out % 16 == 0, LIME_ERR_BAD_ARG,
+                     "lime_encoder_ffn_bf16: pool32 needs M %% 32 == 0 and fp32 out rows of >= %d columns, 16-byte aligned", DP);
+    else
+        LIME_REQUIRE(a->ldo >= DP && a->ldo % 4 == 0 && (uintptr_t)a->out % 8 == 0, LIME_ERR_BAD_ARG,
+                     "lime_encoder_ffn_bf16: bf16 out rows of >= %d columns, 8-byte aligned", DP);
+    const long lim = 0x7FFFFFF0L;
+    LIME_REQUIRE(128L * a->ldx * 2 < lim && (long)a->F * 320 * 2 < lim && 128L * a->ldo * 4 < lim,
+                 LIME_ERR_UNSUPPORTED, "lime_encoder_ffn_bf16: operand too large for 32-bit offsets");
+    if (a->M == 0) return LIME_OK;
+    FfnP p;
+    p.x = a->x; p.ldx = a->ldx; p.w1p = a->w1p; p.w2p = a->w2p;
+    p.b2 = a->b2; p.g = a->ln_gamma; p.beta = a->ln_beta; p.eps = a->ln_eps;
+    p.out = a->out; p.ldo = a->ldo; p.M = a->M; p.E = a->E; p.F = a->F; p.m_dev = a->m_dev;
+#ifdef LIME_STAMPS
+    p.stamps = g_ffn_stamp_buf;
+#endif
+    const long ntiles = ((long)a->M + BM - 1) / BM;
+    long nwg = num_cus();
+    if (nwg > ntiles) nwg = ntiles;
+    hipStream_t s = (hipStream_t)stream;
+    if (a->pool32) hipLaunchKernelGGL((ffn_bf16_kernel<true>), dim3((unsigned)nwg), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((ffn_bf16_kernel<false>), dim3((unsigned)nwg), dim3(256), 0, s, p);
+    return lime_check_launch("lime_encoder_ffn_bf16");
+}

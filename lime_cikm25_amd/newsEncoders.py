@@ -574,6 +574,15 @@ def compact_applicable(ids, table, transformer, nhead):
             ids.dtype == torch.int32 and ids.is_contiguous())
 
 
+FUSED_FFN = os.environ.get('LIME_BF16_FUSED_FFN', '1') != '0'        # 0: linear1 / linear2 as two lime_linear_bf16 launches (A/B runs)
+
+
+def _ffn_fused_applicable(layer, E, EP):
+    """lime_encoder_ffn_bf16 is built for the reference's encoder shape: E = 300 carried as 304, hidden width a multiple of 128."""
+    return (FUSED_FFN and EP == ops.ffn_model_columns() and EP - 15 <= E < EP and layer.linear1.out_features % 128 == 0 and
+            layer.linear1.bias is not None and layer.linear2.bias is not None)
+
+
 def encode_tokens_bf16(ids, table_bf16, pe, transformer, nhead, pooled_out):
     """encode_tokens + mean pool on the bf16 matrix cores (BASELINE config 3).
 
@@ -611,10 +620,18 @@ def encode_tokens_bf16(ids, table_bf16, pe, transformer, nhead, pooled_out):
                                  res_period=S, ln=ln1, ln_eps=layer.norm1.eps, ln_count=E, n_alg=E, k_alg=E)
         else:
             x1 = ops.linear_bf16(attn, w_o, padv(sa.out_proj.bias), res=x, res_kind=3, ln=ln1, ln_eps=layer.norm1.eps, ln_count=E, n_alg=E, k_alg=E)
-        h = ops.linear_bf16(x1, ops.to_bf16(layer.linear1.weight, cols_out=EP), layer.linear1.bias, act='relu', k_alg=E)
         last = li == len(transformer.layers) - 1
-        if last and transformer.norm is None:
-            # token mean pooling in the epilogue: fp32 means over 32-token blocks, [M * S / 32, EP]
+        pool = last and transformer.norm is None              # token mean pooling in the epilogue: fp32 means over 32-token blocks
+        if _ffn_fused_applicable(layer, E, EP):
+            # linear1 + ReLU + linear2 + residual + norm2 in ONE launch: the hidden state stays in registers (csrc/ffn_bf16.hip)
+            w1p, w2p = ops.ffn_pack_bf16(layer.linear1.weight, layer.linear1.bias, layer.linear2.weight)
+            y = ops.encoder_ffn_bf16(x1, w1p, w2p, layer.linear2.bias, (layer.norm2.weight, layer.norm2.bias), layer.norm2.eps, E, pool32=pool)
+            if pool:
+                return ops.mean_pool(y[:, :E], M, S // 32, out=pooled_out)
+            x = y
+            continue
+        h = ops.linear_bf16(x1, ops.to_bf16(layer.linear1.weight, cols_out=EP), layer.linear1.bias, act='relu', k_alg=E)
+        if pool:
             blocks = ops.linear_bf16(h, ops.to_bf16(layer.linear2.weight, rows_out=EP), padv(layer.linear2.bias), res=x1, res_kind=3,
                                      ln=(padv(layer.norm2.weight), padv(layer.norm2.bias)), ln_eps=layer.norm2.eps, ln_count=E,
                                      pool32=True, n_alg=E)
@@ -657,10 +674,15 @@ def encode_tokens_bf16_compact(ids, table_bf16, pe, transformer, nhead, pooled_o
     x1 = ops.linear_bf16(attn, w_o, padv(sa.out_proj.bias), res=table_bf16, res_kind=2, res_ids=cmp.ids_c, res_pe=pe_p, res_period=S,
                          ln=(padv(layer.norm1.weight), padv(layer.norm1.bias)), ln_eps=layer.norm1.eps, ln_count=E, n_alg=E, k_alg=E,
                          m_dev=cmp.n_rows)
-    h = ops.linear_bf16(x1, ops.to_bf16(layer.linear1.weight, cols_out=EP), layer.linear1.bias, act='relu', k_alg=E, m_dev=cmp.n_rows)
-    blocks = ops.linear_bf16(h, ops.to_bf16(layer.linear2.weight, rows_out=EP), padv(layer.linear2.bias), res=x1, res_kind=3,
-                             ln=(padv(layer.norm2.weight), padv(layer.norm2.bias)), ln_eps=layer.norm2.eps, ln_count=E, pool32=True,
-                             n_alg=E, m_dev=cmp.n_rows)                         # fp32 [cap / 32, EP] block means
+    if _ffn_fused_applicable(layer, E, EP):
+        w1p, w2p = ops.ffn_pack_bf16(layer.linear1.weight, layer.linear1.bias, layer.linear2.weight)
+        blocks = ops.encoder_ffn_bf16(x1, w1p, w2p, layer.linear2.bias, (layer.norm2.weight, layer.norm2.bias), layer.norm2.eps, E,
+                                      pool32=True, m_dev=cmp.n_rows)           # fp32 [cap / 32, EP] block means
+    else:
+        h = ops.linear_bf16(x1, ops.to_bf16(layer.linear1.weight, cols_out=EP), layer.linear1.bias, act='relu', k_alg=E, m_dev=cmp.n_rows)
+        blocks = ops.linear_bf16(h, ops.to_bf16(layer.linear2.weight, rows_out=EP), padv(layer.linear2.bias), res=x1, res_kind=3,
+                                 ln=(padv(layer.norm2.weight), padv(layer.norm2.bias)), ln_eps=layer.norm2.eps, ln_count=E, pool32=True,
+                                 n_alg=E, m_dev=cmp.n_rows)
     pooled_c = ops.mean_pool(blocks[:, :E], M + 1, S // 32)
     ops.gather_rows(cmp.seq_inv, pooled_c, pooled_out)
     return None

@@ -584,6 +584,61 @@ def linear_bf16(a, w, bias=None, act=None, out=None, a_ids=None, res=None, res_k
     return out
 
 
+def ffn_model_columns():
+    """The column count (304) ``encoder_ffn_bf16`` carries the model dimension in."""
+    return int(_lib.load().lime_ffn_bf16_model_columns())
+
+
+def ffn_pack_bf16(w1, b1, w2):
+    """``lime_ffn_pack_bf16``: linear1 / linear2 weights (fp32 [F, E], [F], [E, F]) -> the bf16 operands of ``encoder_ffn_bf16``."""
+    lib = _lib.load()
+    _mat(w1, 'w1')
+    _mat(w2, 'w2')
+    F, E = w1.shape
+    if tuple(w2.shape) != (E, F):
+        raise ValueError('w2 must be [%d, %d]' % (E, F))
+    _vec(b1, 'b1', F)
+    w1p = torch.empty(int(lib.lime_ffn_pack_bf16_size(F, 0)), dtype=torch.bfloat16, device=w1.device)
+    w2p = torch.empty(int(lib.lime_ffn_pack_bf16_size(F, 1)), dtype=torch.bfloat16, device=w1.device)
+    check(lib.lime_ffn_pack_bf16(_p(w1), _ld(w1), _p(b1), _p(w2), _ld(w2), E, F, _p(w1p), _p(w2p), _stream()), 'lime_ffn_pack_bf16')
+    return w1p, w2p
+
+
+def encoder_ffn_bf16(x, w1p, w2p, b2, ln, ln_eps, E, pool32=False, m_dev=None, out=None):
+    """``lime_encoder_ffn_bf16``: LayerNorm(x + W2 relu(W1 x + b1) + b2) in one launch; x bf16 [M, 304] (E real columns).
+    pool32: fp32 [M / 32, 304] means over 32-row blocks, else bf16 [M, 304]."""
+    lib = _lib.load()
+    _mat(x, 'x', dtype=torch.bfloat16)
+    _vec(w1p, 'w1p', dtype=torch.bfloat16)
+    _vec(w2p, 'w2p', dtype=torch.bfloat16)
+    M, DP = x.shape
+    F = w2p.numel() // ffn_model_columns()
+    if DP != ffn_model_columns() or w1p.numel() != int(lib.lime_ffn_pack_bf16_size(F, 0)) or w2p.numel() != int(lib.lime_ffn_pack_bf16_size(F, 1)):
+        raise ValueError('x [M, %d] and the two buffers of ffn_pack_bf16 expected' % ffn_model_columns())
+    if pool32 and M % 32:
+        raise ValueError('pool32 needs M %% 32 == 0 (M = %d)' % M)
+    rows_out, odt = (M // 32, torch.float32) if pool32 else (M, torch.bfloat16)
+    if out is None:
+        out = torch.empty((rows_out, DP), dtype=odt, device=x.device)
+    _mat(out, 'out', dtype=odt)
+    if tuple(out.shape) != (rows_out, DP):
+        raise ValueError('out must be [%d, %d]' % (rows_out, DP))
+    args = _lib.FfnBf16Args()
+    args.x, args.ldx = x.data_ptr(), _ld(x)
+    args.w1p, args.w2p = w1p.data_ptr(), w2p.data_ptr()
+    args.b2 = _vec(b2, 'b2', E).data_ptr()
+    args.ln_gamma = _vec(ln[0], 'ln gamma', E).data_ptr()
+    args.ln_beta = _vec(ln[1], 'ln beta', E).data_ptr()
+    args.ln_eps = ln_eps
+    args.pool32 = 1 if pool32 else 0
+    args.out, args.ldo = out.data_ptr(), _ld(out)
+    args.M, args.E, args.F = M, E, F
+    if m_dev is not None:
+        args.m_dev = _vec(m_dev, 'm_dev', 1, dtype=torch.int32).data_ptr()
+    check(lib.lime_encoder_ffn_bf16(ctypes.byref(args), _stream()), 'lime_encoder_ffn_bf16')
+    return out
+
+
 def mean_pool_bf16(x, n_seq, S, dim, out=None):
     lib = _lib.load()
     _mat(x, 'x', dtype=torch.bfloat16)

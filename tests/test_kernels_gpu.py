@@ -580,6 +580,58 @@ def test_linear_bf16_encoder_layer_gemms(ops, M, S):
     check(pooled, x2[:n_seq * S, :E].float().cpu().view(n_seq, S, E).mean(dim=1), what='bf16 mean pool')
 
 
+def _ffn_case(M, F, seed):
+    E, EP = 300, 304
+    x = torch.zeros(M, EP, dtype=torch.bfloat16)
+    x[:, :E] = bf(rnd(M, E, seed=seed, scale=1.5))
+    w1, b1 = rnd(F, E, seed=seed + 1, scale=0.06), rnd(F, seed=seed + 2)
+    w2, b2 = rnd(E, F, seed=seed + 3, scale=0.05), rnd(E, seed=seed + 4)
+    g, be = rnd(E, seed=seed + 5) + 1.5, rnd(E, seed=seed + 6)
+    xf = x[:, :E].float()
+    h = bf(torch.relu(xf @ bf(w1).float().t() + bf(b1).float())).float()          # b1 rides in the GEMM: applied in bf16
+    want = O.layer_norm(xf + h @ bf(w2).float().t() + b2, g, be)
+    return x, (w1, b1, w2, b2, g, be), want
+
+
+@pytest.mark.parametrize('M,F', [(128, 512), (4096, 512), (4128, 512), (1000, 256), (33, 128), (36000, 512)])
+def test_encoder_ffn_bf16(ops, M, F):
+    """linear1 + ReLU + linear2 + residual + LayerNorm in one launch against the same arithmetic in torch (bf16 operands, fp32
+    accumulation), rows and pooled block means; row counts that end inside a tile / a wave, one tile per workgroup and several."""
+    E = 300
+    x, (w1, b1, w2, b2, g, be), want = _ffn_case(M, F, seed=40)
+    w1p, w2p = ops.ffn_pack_bf16(dev(w1), dev(b1), dev(w2))
+    # the packed layouts: w1p [F / 128][10 chunks][128 rows][32 k] (K = 320: W1, b1 at k = E, zeros), w2p [F / 32][304 rows][32]
+    w1v = w1p.cpu().view(F // 128, 10, 128, 32).permute(0, 2, 1, 3).reshape(F, 320)
+    assert torch.equal(w1v[:, :E].view(torch.int16), bf(w1).view(torch.int16)) and torch.equal(w1v[:, E].view(torch.int16), bf(b1).view(torch.int16))
+    assert (w1v[:, E + 1:] == 0).all()
+    w2v = w2p.cpu().view(F // 32, 304, 4, 2, 4).permute(1, 0, 3, 2, 4).reshape(304, F)          # [n][block][a][kg][r]
+    assert torch.equal(w2v[:E].view(torch.int16), bf(w2).view(torch.int16)) and (w2v[E:] == 0).all()
+    got = ops.encoder_ffn_bf16(dev(x), w1p, w2p, dev(b2), (dev(g), dev(be)), 1e-5, E)
+    assert got.dtype == torch.bfloat16 and got.shape == (M, 304) and (got[:, E:] == 0).all()
+    check(got[:, :E].float(), bf(want).float(), tol=BF_TOL, what='fused bf16 ffn rows %s' % ((M, F),))
+    mb = M // 32 * 32
+    if mb:
+        blocks = ops.encoder_ffn_bf16(dev(x[:mb]), w1p, w2p, dev(b2), (dev(g), dev(be)), 1e-5, E, pool32=True)
+        assert blocks.dtype == torch.float32 and blocks.shape == (mb // 32, 304) and (blocks[:, E:] == 0).all()
+        check(blocks[:, :E], want[:mb].view(mb // 32, 32, E).mean(dim=1), tol=2e-3, what='fused bf16 ffn block means %s' % ((M, F),))
+
+
+def test_encoder_ffn_bf16_device_row_count_and_refusals(ops):
+    E, F, M = 300, 512, 4096
+    x, (w1, b1, w2, b2, g, be), want = _ffn_case(M, F, seed=50)
+    w1p, w2p = ops.ffn_pack_bf16(dev(w1), dev(b1), dev(w2))
+    out = torch.full((M // 32, 304), 7.0, device='cuda')
+    m_dev = torch.tensor([1056], dtype=torch.int32, device='cuda')
+    ops.encoder_ffn_bf16(dev(x), w1p, w2p, dev(b2), (dev(g), dev(be)), 1e-5, E, pool32=True, m_dev=m_dev, out=out)
+    check(out[:33, :E], want[:1056].view(33, 32, E).mean(dim=1), tol=2e-3, what='fused ffn, device row count')
+    assert (out[33:] == 7.0).all()
+    from lime_cikm25_amd._lib import LimeHipError
+    with pytest.raises(LimeHipError):
+        ops.ffn_pack_bf16(dev(rnd(500, E)), dev(rnd(500)), dev(rnd(E, 500)))           # F % 128
+    with pytest.raises(LimeHipError):
+        ops.ffn_pack_bf16(dev(rnd(512, 256)), dev(rnd(512)), dev(rnd(256, 512)))       # E outside 289..303
+
+
 @pytest.mark.parametrize('S', [32, 64, 128, 256])
 def test_token_attention_bf16(ops, S):
     n_seq, h, hd = (23 if S <= 128 else 3), 10, 30

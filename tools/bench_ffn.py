@@ -1,0 +1,59 @@
+"""Time lime_encoder_ffn_bf16 against the two lime_linear_bf16 launches it replaces (body-chunk shape of BASELINE config 3).
+
+    python tools/bench_ffn.py [rows]
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from lime_cikm25_amd import ops  # noqa: E402
+
+
+def timed(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n
+
+
+def main():
+    M = int(sys.argv[1]) if len(sys.argv) > 1 else 360448
+    E, EP, F = 300, 304, 512
+    g = torch.Generator().manual_seed(0)
+    rnd = lambda *s: ((torch.rand(*s, generator=g) * 2 - 1) * 0.1).cuda()
+    x = torch.zeros(M, EP, dtype=torch.bfloat16, device='cuda')
+    x[:, :E] = rnd(M, E).to(torch.bfloat16)
+    w1, b1, w2, b2 = rnd(F, E), rnd(F), rnd(E, F), rnd(E)
+    gam, bet = rnd(E) + 1, rnd(E)
+    padv = lambda v: torch.cat([v, v.new_zeros(EP - E)])
+    w1b, w2b = ops.to_bf16(w1, cols_out=EP), ops.to_bf16(w2, rows_out=EP)
+    w1p, w2p = ops.ffn_pack_bf16(w1, b1, w2)
+    ln = (gam, bet)
+    lnp = (padv(gam), padv(bet))
+    b2p = padv(b2)
+
+    def two():
+        h = ops.linear_bf16(x, w1b, b1, act='relu', k_alg=E)
+        return ops.linear_bf16(h, w2b, b2p, res=x, res_kind=3, ln=lnp, ln_eps=1e-5, ln_count=E, pool32=True, n_alg=E)
+
+    def fused():
+        return ops.encoder_ffn_bf16(x, w1p, w2p, b2, ln, 1e-5, E, pool32=True)
+
+    a, b = two(), fused()
+    print('max |two - fused| = %.3e (mean |two| %.3e)' % ((a - b).abs().max().item(), a.abs().mean().item()))
+    t2, tf = timed(two), timed(fused)
+    flops = 2.0 * M * (E * F * 2)
+    print('rows %d   two launches %.1f us (%.0f TF)   fused %.1f us (%.0f TF = %.3f of 2.5 PF)' %
+          (M, t2, flops / t2 / 1e6, tf, flops / tf / 1e6, flops / tf / 1e6 / 2500))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,62 @@
+"""Diagnostic: where a workgroup of lime_encoder_ffn_bf16 spends its cycles (s_memtime stamps, LIME_STAMPS build of ffn_bf16.hip).
+
+    python tools/ffn_stamps.py [rows]
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from lime_cikm25_amd import _lib, ops  # noqa: E402
+
+SO = os.path.join(ROOT, 'tools', 'probes', 'liblime_ffn_stamps.so')
+SEG = ['dma wait', 'barrier', 'dma issue', 'linear1 reads+mfma', 'linear2 reads+mfma', 'tile issue', 'relu/pack', 'epilogue']
+
+
+def main():
+    src = os.path.join(ROOT, 'lime_cikm25_amd', 'csrc')
+    subprocess.run(['hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', '-DLIME_STAMPS', '-o', SO,
+                    os.path.join(src, 'ffn_bf16.hip'), os.path.join(src, 'common.cpp')], check=True)
+    lib = ctypes.CDLL(SO)
+    lib.lime_encoder_ffn_bf16.restype = ctypes.c_int32
+    lib.lime_encoder_ffn_bf16.argtypes = [ctypes.POINTER(_lib.FfnBf16Args), ctypes.c_void_p]
+    lib.lime_debug_set_ffn_stamp_buffer.argtypes = [ctypes.c_void_p]
+    M = int(sys.argv[1]) if len(sys.argv) > 1 else 360448
+    E, EP, F = 300, 304, 512
+    g = torch.Generator().manual_seed(0)
+    rnd = lambda *s: ((torch.rand(*s, generator=g) * 2 - 1) * 0.1).cuda()
+    x = torch.zeros(M, EP, dtype=torch.bfloat16, device='cuda')
+    x[:, :E] = rnd(M, E).to(torch.bfloat16)
+    w1, b1, w2, b2 = rnd(F, E), rnd(F), rnd(E, F), rnd(E)
+    gam, bet = rnd(E) + 1, rnd(E)
+    w1p, w2p = ops.ffn_pack_bf16(w1, b1, w2)
+    out = torch.empty((M // 32, EP), device='cuda')
+    a = _lib.FfnBf16Args()
+    a.x, a.ldx, a.w1p, a.w2p = x.data_ptr(), EP, w1p.data_ptr(), w2p.data_ptr()
+    a.b2, a.ln_gamma, a.ln_beta, a.ln_eps, a.pool32 = b2.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-5, 1
+    a.out, a.ldo, a.M, a.E, a.F = out.data_ptr(), EP, M, E, F
+    buf = torch.zeros(256 * 4 * 8, dtype=torch.int64, device='cuda')
+    lib.lime_debug_set_ffn_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):
+        assert lib.lime_encoder_ffn_bf16(ctypes.byref(a), st) == 0
+    torch.cuda.synchronize()
+    buf.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    lib.lime_encoder_ffn_bf16(ctypes.byref(a), st)
+    e1.record()
+    torch.cuda.synchronize()
+    t = buf.view(-1, 8).double()
+    t = t[t.sum(dim=1) > 0]
+    share = t.sum(dim=0) / t.sum()
+    print('rows %d  %.1f us  waves %d  wave total %.0f s_memtime ticks (100 MHz)' % (M, e0.elapsed_time(e1) * 1e3, t.shape[0], t.sum(dim=1).mean().item()))
+    print('  '.join('%s %.1f%%' % (s, 100 * v) for s, v in zip(SEG, share.tolist())))
+    lib.lime_debug_set_ffn_stamp_buffer(None)
+
+
+if __name__ == '__main__':
+    main()
