@@ -70,6 +70,14 @@ struct FfnP {
 #endif
 };
 
+// The lane id, recomputed where it is called (the opaque zero keeps hipcc from hoisting it -- and everything derived from it -- out
+// of the tile loop, where the values would sit in registers through all 36 steps or be spilled: scratch reloads wait vmcnt(0)).
+__device__ __forceinline__ int lane_here() {
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+}
+
 constexpr int step_dmas(int pos) { return pos < 5 ? 4 : 5; }                       // DMA instructions per wave that fill the slot of step `pos`
 constexpr int steady_vm(int pos) { return step_dmas((pos + 1) % STEPS) + step_dmas((pos + 2) % STEPS); }
 
@@ -107,19 +115,24 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(const FfnP p) {
     const unsigned ldxb = (unsigned)p.ldx * 2u;
     unsigned char* const ring = lds + XS_BYTES;
 
-    auto kvalid = [&](int c) { return c * 32 + lseg * 8 < DP; };
     // The packed weights (lime_ffn_pack_bf16) hold every ring slot as ONE contiguous block in the order of its LDS image, so a DMA
     // instruction reads 1 KB of whole 128-byte lines (rows 608 / 1024 bytes apart would be 64-byte pieces that land on a quarter of
     // the L2 channels): block + 1024 idx + 64 (row in the instruction) + 16 (logical segment).
     const unsigned w_lane = (unsigned)srow * 64u + (unsigned)lseg * 16u;
     // the slot of a linear1 step: weight rows PW pass .. + 127, chunks 2 j and 2 j + 1 -> [2][128 rows][64 B]; 16 instructions, 4 per wave
     auto issue_w1 = [&](int slot, int pass, int j, int i) {
+#if defined(LIME_FFN_ABLATE) && LIME_FFN_ABLATE == 2       // tools/ffn_stamps.py: no weight traffic (results are garbage)
+        return;
+#endif
         const int idx = 4 * wave + i;
         dma16(rs_w1, ring + slot * SLOT + idx * 1024, w_lane + (unsigned)idx * 1024u, (pass * NCH + 2 * j) * SLAB);
     };
     // the slot of a linear2 step: all DP weight rows, hidden columns 32 (4 pass + kc) .. + 31 -> [304 rows][64 B]; 19 instructions,
     // 5 per wave (wave 3 repeats the last one: the same bytes to the same place, so that every wave counts alike)
     auto issue_w2 = [&](int slot, int pass, int kc, int i) {
+#if defined(LIME_FFN_ABLATE) && LIME_FFN_ABLATE == 2
+        return;
+#endif
         int idx = 5 * wave + i;
         idx = idx < ND ? idx : ND - 1;
         dma16(rs_w2, ring + slot * SLOT + idx * 1024, w_lane + (unsigned)idx * 1024u, (NT1 / 2 * pass + kc) * SLOT);
@@ -139,12 +152,14 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(const FfnP p) {
     auto load_x = [&](int t) {
         const long row0 = (long)t * BM;
         const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(p.x + row0 * p.ldx);
+        const int ln = lane_here();                    // recompute the offsets here: hoisted out of the tile loop they end up spilled
+        const int srow_ = ln >> 2, lseg_ = (ln & 3) ^ swz4((ln >> 4) & 3);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int rl = 16 * (2 * wave + j) + srow;
-            const unsigned vo = (row0 + rl < M) ? (unsigned)rl * ldxb + (unsigned)lseg * 16u : OOB;
+            const int rl = 16 * (2 * wave + j) + srow_;
+            const unsigned vo = (row0 + rl < M) ? (unsigned)rl * ldxb + (unsigned)lseg_ * 16u : OOB;
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) dma16(rs_x, lds + c * SLAB + (2 * wave + j) * 1024, kvalid(c) ? vo : OOB, c * 64);
+            for (int c = 0; c < NCH; ++c) dma16(rs_x, lds + c * SLAB + (2 * wave + j) * 1024, (c * 32 + lseg_ * 8 < DP) ? vo : OOB, c * 64);
         }
     };
 
@@ -157,12 +172,35 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(const FfnP p) {
     f32x4 acc1[2][NT1], acc2[2][ND];
     bf16x8 hb[2][NT1 / 2];
 
-    // A step's MFMAs run in four groups; `part(g)` behind group g issues this wave's DMA instruction g of the slot three steps
-    // ahead (issued all at once behind the barrier, the workgroup's 16-19 instructions queue up in the CU's one address path and
-    // every wave sits in "DMA issue" for a quarter of its time -- s_memtime stamps; spread out, a wave meets an idle path).  The
-    // fragments of group g + 1 are read before the MFMAs of group g (the sched_barriers that pin the DMA issue also keep hipcc
-    // from hoisting those reads).
-    auto compute1 = [&](int slot, int j, auto&& part) {
+    // A step's MFMAs run in four groups; `part(g)` behind group g issues this wave's DMA instruction g of the slot that has just
+    // come free (issued all at once behind the barrier, the workgroup's 16-19 instructions queue up in the CU's one address path
+    // and every wave sits in "DMA issue" for a quarter of its time -- s_memtime stamps; spread out, a wave meets an idle path).
+    // The fragments of group g + 1 are read before the MFMAs of group g (the sched_barriers that pin the DMA issue also keep
+    // hipcc from hoisting those reads) -- and those of the NEXT step's first group before this step's last MFMAs: a slot is
+    // published one barrier before the step that consumes it, so the reads cross the barrier and no step starts with an
+    // exposed LDS round trip.  nw / nx carry them over.
+    bf16x8 nw[4], nx[2];
+    // first-group fragments of the step at position NPOS from `slot`; `with_x`: also the stationary fragments of its first chunk
+    auto prefetch = [&](auto npos_c, int slot, bool with_x) {
+        constexpr int NPOS = decltype(npos_c)::value;
+        const unsigned char* const sb = ring + slot * SLOT + w_off;
+        if constexpr (NPOS < 5) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) nw[t] = *reinterpret_cast<const bf16x8*>(sb + t * 1024);
+            if (with_x) {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) nx[tt] = *reinterpret_cast<const bf16x8*>(lds + (2 * NPOS) * SLAB + x_off + tt * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) nw[t] = *reinterpret_cast<const bf16x8*>(sb + t * 1024);
+        }
+    };
+    auto compute1 = [&](int slot, int j, bool have_x, auto&& part, auto&& tail) {
+#if defined(LIME_FFN_ABLATE) && LIME_FFN_ABLATE == 1       // tools/ffn_stamps.py: no fragment reads, no MFMAs
+        for (int g = 0; g < 4; ++g) part(g);
+        return;
+#endif
         const unsigned char* const sb = ring + slot * SLOT + w_off;
         constexpr int GT = NT1 / 2;                                // 4 tiles per group: (chunk cc, tile half)
         bf16x8 af[2][2], wf[2][GT];
@@ -176,38 +214,65 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(const FfnP p) {
 #pragma unroll
             for (int t = 0; t < GT; ++t) wf[buf][t] = *reinterpret_cast<const bf16x8*>(sb + cc * 8192 + (th * GT + t) * 1024);
         };
-        read_group(0, 0);
+#pragma unroll
+        for (int t = 0; t < GT; ++t) wf[0][t] = nw[t];
+        if (have_x) {
+            af[0][0] = nx[0];
+            af[0][1] = nx[1];
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) af[0][tt] = *reinterpret_cast<const bf16x8*>(lds + (2 * j) * SLAB + x_off + tt * 1024);
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (g + 1 < 4) read_group(g + 1, (g + 1) & 1);
+            else tail();
             const int cc = g >> 1, th = g & 1;
 #pragma unroll
             for (int t = 0; t < GT; ++t)
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
+                for (int tt = 0; tt < 2; ++tt) {
+#if defined(LIME_FFN_ABLATE) && LIME_FFN_ABLATE == 3       // fragment reads, no MFMAs
+                    acc1[tt][th * GT + t][0] += __builtin_bit_cast(f32x4, wf[g & 1][t])[0] + __builtin_bit_cast(f32x4, af[cc][tt])[0];
+#else
                     acc1[tt][th * GT + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g & 1][t], af[cc][tt], acc1[tt][th * GT + t], 0, 0, 0);
+#endif
+                }
             __builtin_amdgcn_sched_barrier(0);
             part(g);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto compute2 = [&](int slot, int kc, auto&& part) {
+    auto compute2 = [&](int slot, int kc, auto&& part, auto&& tail) {
+#if defined(LIME_FFN_ABLATE) && LIME_FFN_ABLATE == 1
+        for (int g = 0; g < 5; ++g) part(g);
+        return;
+#endif
         const unsigned char* const sb = ring + slot * SLOT + w_off;
-        constexpr int GT = 5;                                      // tiles per group (the last has 4)
+        constexpr int GT = 4, NG = (ND + GT - 1) / GT;             // five groups of 4, 4, 4, 4, 3 tiles
         bf16x8 wf[2][GT];
 #pragma unroll
-        for (int t = 0; t < GT; ++t) wf[0][t] = *reinterpret_cast<const bf16x8*>(sb + t * 1024);
+        for (int t = 0; t < GT; ++t) wf[0][t] = nw[t];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) {
 #pragma unroll
-            for (int t = 0; t < GT; ++t)
-                if ((g + 1) * GT + t < ND) wf[(g + 1) & 1][t] = *reinterpret_cast<const bf16x8*>(sb + ((g + 1) * GT + t) * 1024);
+                for (int t = 0; t < GT; ++t)
+                    if ((g + 1) * GT + t < ND) wf[(g + 1) & 1][t] = *reinterpret_cast<const bf16x8*>(sb + ((g + 1) * GT + t) * 1024);
+            } else {
+                tail();
+            }
 #pragma unroll
             for (int t = 0; t < GT; ++t)
                 if (g * GT + t < ND) {
 #pragma unroll
-                    for (int tt = 0; tt < 2; ++tt)
+                    for (int tt = 0; tt < 2; ++tt) {
+#if defined(LIME_FFN_ABLATE) && LIME_FFN_ABLATE == 3
+                        acc2[tt][g * GT + t][0] += __builtin_bit_cast(f32x4, wf[g & 1][t])[0];
+#else
                         acc2[tt][g * GT + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[g & 1][t], hb[tt][kc], acc2[tt][g * GT + t], 0, 0, 0);
+#endif
+                    }
                 }
             __builtin_amdgcn_sched_barrier(0);
             part(g);
@@ -215,7 +280,10 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(const FfnP p) {
         }
     };
 
-    int gs = 0;                                        // steps done: the slot of step s is s & 3
+    // Step s reads slot s & 3.  In front of it: this wave's part of slot s + 1 has landed (counted wait: the DMAs of step s + 2
+    // stay in flight), then the barrier -- behind it slot s + 1 is complete for everyone (it is read from the end of this step
+    // on) and slot s - 1 is free: the DMAs of step s + 3 go there, between this step's MFMA groups.
+    int gs = 0;
     bool last = false;
 #ifdef LIME_STAMPS
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -224,11 +292,14 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(const FfnP p) {
 #endif
     auto step = [&](auto pos_c, int pass) {
         constexpr int POS = decltype(pos_c)::value;
-        // the slot of this step has landed (this wave's part); the DMAs of the next two steps stay in flight
-        if (POS == 0 && pass == 0) {
-            wait_vm<0>();                              // ... and the stationary tile
-            if (lane < 32) {                           // 1.0 in column E of this wave's rows: linear1's bias column
-                const int row = 32 * wave + lane;
+        constexpr int NPOS = (POS + 1) % STEPS;         // the next step
+        constexpr int FPOS = (POS + 3) % STEPS;         // the step whose slot this one refills
+        const bool tile_start = POS == 0 && pass == 0;
+        if (tile_start) {
+            wait_vm<0>();                              // the stationary tile (issued in front of the previous tile's epilogue)
+            const int lp = lane_here();
+            if (lp < 32) {                             // 1.0 in column E of this wave's rows: linear1's bias column
+                const int row = 32 * wave + lp;
                 const int koff = E & 31;
                 *reinterpret_cast<unsigned short*>(lds + (E >> 5) * SLAB + row * 64 + (((koff >> 3) ^ swz4((row >> 2) & 3)) * 16) +
                                                    (koff & 7) * 2) = 0x3F80;
@@ -236,23 +307,26 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(const FfnP p) {
         } else if (last && pass == NP - 1 && POS >= STEPS - 2) {
             wait_vm<0>();                              // the ring runs dry behind the last tile
         } else {
-            wait_vm<steady_vm(POS)>();
+            wait_vm<step_dmas((POS + 2) % STEPS)>();
         }
-        FSTAMP(0)                                      // 0: this wave's DMAs of the step have landed
-        ring_barrier();                                // every wave's part has landed; everyone is done with the slot of step s - 1
+        FSTAMP(0)                                      // 0: this wave's DMAs of the next step have landed
+        ring_barrier();
         FSTAMP(1)                                      // 1: barrier
-        constexpr int NPOS = (POS + 3) % STEPS;         // the step whose slot this one refills (free since the barrier)
-        int np = pass + (POS + 3 >= STEPS ? 1 : 0);
+        int fp = pass + (POS + 3 >= STEPS ? 1 : 0);
         bool go = true;
-        if (np == NP) { np = 0; go = !last; }
-        const int nslot = (gs + 3) & 3;
+        if (fp == NP) { fp = 0; go = !last; }
+        const int fslot = (gs + 3) & 3;
+        constexpr int NGRP = POS < 5 ? 4 : 5;           // MFMA groups of this step; the refilled slot takes 4 or 5 instructions
         auto part = [&](int g) {
             if (!go) return;
-            issue_one(std::integral_constant<int, NPOS>{}, nslot, np, g);
-            if (g == 3 && step_dmas(NPOS) == 5) issue_one(std::integral_constant<int, NPOS>{}, nslot, np, 4);
+            if (g < step_dmas(FPOS)) issue_one(std::integral_constant<int, FPOS>{}, fslot, fp, g);
+            if (g == NGRP - 1 && NGRP < step_dmas(FPOS)) issue_one(std::integral_constant<int, FPOS>{}, fslot, fp, NGRP);
         };
-        if constexpr (POS < 5) compute1(gs & 3, POS, part);
-        else compute2(gs & 3, POS - 5, part);
+        // the next step's first fragments; its stationary fragments too while it stays inside this tile
+        const bool nx_ok = NPOS != 0 || pass + 1 < NP;
+        auto tail = [&]() { prefetch(std::integral_constant<int, NPOS>{}, (gs + 1) & 3, nx_ok); };
+        if constexpr (POS < 5) compute1(gs & 3, POS, !tile_start, part, tail);
+        else compute2(gs & 3, POS - 5, part, tail);
         __builtin_amdgcn_sched_barrier(0);
         FSTAMP(POS < 5 ? 3 : 4)                        // 3 / 4: fragment reads + MFMAs + DMA issue, linear1 / linear2 step
         ++gs;
@@ -261,11 +335,12 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(const FfnP p) {
     issue_step(std::integral_constant<int, 0>{}, 0, 0);
     issue_step(std::integral_constant<int, 1>{}, 1, 0);
     issue_step(std::integral_constant<int, 2>{}, 2, 0);
+    load_x(tile);
+    wait_vm<step_dmas(1) + step_dmas(2) + 2 * NCH>();     // slot 0
+    ring_barrier();
+    prefetch(std::integral_constant<int, 0>{}, 0, false);
     for (; tile < ntiles; tile += gridDim.x) {
         last = tile + (int)gridDim.x >= ntiles;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the previous tile's residual reads are out of the image
-        load_x(tile);
-        FSTAMP(5)                                      // 5: stationary tile issue
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -301,27 +376,44 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(const FfnP p) {
             step(std::integral_constant<int, 8>{}, pass);
         }
         FSTAMP(6)                                      // 6: ReLU / pack (and loop overhead)
-        // ---- epilogue: + b2 + residual (the stationary tile, column E is the bias column: not part of it), LayerNorm over the
-        // E real columns (the pad columns are exact zeros: zero weight rows, zero b2 / gamma / beta)
+
+        // + b2 + residual (this wave's rows of the stationary tile; column E is the bias column: not part of it) -- first, so that
+        // the NEXT tile can stream into the image while the rest of the epilogue runs (every CU asks HBM for its 80 KB at about
+        // the same time: ~9k cycles if nothing covers them).  LayerNorm over the E real columns (the pad columns are exact
+        // zeros: zero weight rows, zero b2 / gamma / beta).
         const long row0 = (long)tile * BM;
-        float sum[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};
         const int te = E >> 4, kge = (E & 15) >> 2, re = E & 3;
+        const int le = lane_here();                    // as in load_x: epilogue-only offsets are computed here, not carried through the tile
+        const int fi_ = le & 15, kg_ = le >> 4;
+        const unsigned char* const rbase = lds + (32 * wave + fi_) * 64 + 8 * (kg_ & 1);
+        const int rswz = swz4((fi_ >> 2) & 3), rsg = kg_ >> 1;
+        const float* const cs_ = cs + 4 * kg_;
 #pragma unroll
         for (int t = 0; t < ND; ++t) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(cs + 16 * t + 4 * kg);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(cs_ + 16 * t);
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                const int row = 32 * wave + 16 * tt + fi;
-                const int seg = 2 * (t & 1) + (kg >> 1);
-                f32x4 r = unpack_bf16x4(*reinterpret_cast<const u32x2*>(lds + (t >> 1) * SLAB + row * 64 + ((seg ^ swz4((fi >> 2) & 3)) * 16) +
-                                                                        8 * (kg & 1)));
-                if (t == te && kg == kge) r[re] = 0.f;
-                const f32x4 v = acc2[tt][t] + b + r;
-                acc2[tt][t] = v;
+                const int seg = 2 * (t & 1) + rsg;
+                f32x4 r = unpack_bf16x4(*reinterpret_cast<const u32x2*>(rbase + (t >> 1) * SLAB + tt * 1024 + ((seg ^ rswz) * 16)));
+                if (t == te && kg_ == kge) r[re] = 0.f;
+                acc2[tt][t] += b + r;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the image has been read ... before the DMAs overwrite those rows
+        if (!last) load_x(tile + (int)gridDim.x);
+        FSTAMP(5)                                      // 5: residual added, next tile issued
+#if defined(LIME_FFN_ABLATE) && LIME_FFN_ABLATE == 5       // no LayerNorm / pooling / stores
+        if (p.eps != 12345.f) continue;
+#endif
+        float sum[2] = {0.f, 0.f}, sq[2] = {0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < ND; ++t)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const f32x4 v = acc2[tt][t];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { sum[tt] += v[j]; sq[tt] += v[j] * v[j]; }
             }
-        }
         float mean[2], rstd[2];
         const float inv_n = 1.0f / (float)E;
 #pragma unroll
@@ -332,8 +424,8 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(const FfnP p) {
             mean[tt] = s1 * inv_n;
             rstd[tt] = rsqrtf(fmaxf(s2 * inv_n - mean[tt] * mean[tt], 0.f) + p.eps);
         }
-        const float* const gs_ = cs + DP + 4 * kg;
-        const float* const es_ = cs + 2 * DP + 4 * kg;
+        const float* const gs_ = cs_ + DP;
+        const float* const es_ = cs_ + 2 * DP;
         if constexpr (POOL) {
             // block row (row0 + 32 wave) / 32: the column means over this wave's 32 tokens (all valid or all beyond M)
             const int rl0 = 32 * wave;
@@ -347,15 +439,15 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(const FfnP p) {
                 y += (acc2[1][t] - mean[1]) * rstd[1] * ga + be;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) y[j] = row16_sum(y[j]) * (1.0f / 32.0f);
-                buf_store4(y, rs_p, (rows_ok && fi == 0) ? (unsigned)(16 * t + 4 * kg) * 4u : OOB, 0);
+                buf_store4(y, rs_p, (rows_ok && fi_ == 0) ? (unsigned)(16 * t + 4 * kg_) * 4u : OOB, 0);
             }
         } else {
             const __amdgpu_buffer_rsrc_t rs_c = make_rsrc((char*)p.out + row0 * p.ldo * 2);
             unsigned cof[2];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                const int rl = 32 * wave + 16 * tt + fi;
-                cof[tt] = (row0 + rl < M) ? (unsigned)rl * (unsigned)p.ldo * 2u + (unsigned)kg * 8u : OOB;
+                const int rl = 32 * wave + 16 * tt + fi_;
+                cof[tt] = (row0 + rl < M) ? (unsigned)rl * (unsigned)p.ldo * 2u + (unsigned)kg_ * 8u : OOB;
             }
 #pragma unroll
             for (int t = 0; t < ND; ++t) {

@@ -17,13 +17,22 @@ SEG = ['dma wait', 'barrier', 'dma issue', 'linear1 reads+mfma', 'linear2 reads+
 
 
 def main():
+    for name, flags in (('stamps', ['-DLIME_STAMPS']), ('plain', []), ('no compute', ['-DLIME_FFN_ABLATE=1']), ('no weight DMA', ['-DLIME_FFN_ABLATE=2']),
+                        ('reads, no MFMA', ['-DLIME_FFN_ABLATE=3']), ('no LN epilogue', ['-DLIME_FFN_ABLATE=5'])):
+        run(name, flags)
+
+
+def run(name, flags):
     src = os.path.join(ROOT, 'lime_cikm25_amd', 'csrc')
-    subprocess.run(['hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', '-DLIME_STAMPS', '-o', SO,
-                    os.path.join(src, 'ffn_bf16.hip'), os.path.join(src, 'common.cpp')], check=True)
-    lib = ctypes.CDLL(SO)
+    so = SO.replace('.so', '_%s.so' % name.replace(' ', '_'))
+    subprocess.run(['hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', '-o', so,
+                    os.path.join(src, 'ffn_bf16.hip'), os.path.join(src, 'common.cpp')] + flags, check=True)
+    lib = ctypes.CDLL(so)
+    stamps = '-DLIME_STAMPS' in flags
     lib.lime_encoder_ffn_bf16.restype = ctypes.c_int32
     lib.lime_encoder_ffn_bf16.argtypes = [ctypes.POINTER(_lib.FfnBf16Args), ctypes.c_void_p]
-    lib.lime_debug_set_ffn_stamp_buffer.argtypes = [ctypes.c_void_p]
+    if stamps:
+        lib.lime_debug_set_ffn_stamp_buffer.argtypes = [ctypes.c_void_p]
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 360448
     E, EP, F = 300, 304, 512
     g = torch.Generator().manual_seed(0)
@@ -39,23 +48,27 @@ def main():
     a.b2, a.ln_gamma, a.ln_beta, a.ln_eps, a.pool32 = b2.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1e-5, 1
     a.out, a.ldo, a.M, a.E, a.F = out.data_ptr(), EP, M, E, F
     buf = torch.zeros(256 * 4 * 8, dtype=torch.int64, device='cuda')
-    lib.lime_debug_set_ffn_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+    if stamps:
+        lib.lime_debug_set_ffn_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for _ in range(2):
+    for _ in range(4):
         assert lib.lime_encoder_ffn_bf16(ctypes.byref(a), st) == 0
     torch.cuda.synchronize()
     buf.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    lib.lime_encoder_ffn_bf16(ctypes.byref(a), st)
+    for _ in range(5):
+        lib.lime_encoder_ffn_bf16(ctypes.byref(a), st)
     e1.record()
     torch.cuda.synchronize()
+    if not stamps:
+        print('%-14s rows %d  %.1f us' % (name, M, e0.elapsed_time(e1) * 1e3 / 5))
+        return
     t = buf.view(-1, 8).double()
     t = t[t.sum(dim=1) > 0]
     share = t.sum(dim=0) / t.sum()
-    print('rows %d  %.1f us  waves %d  wave total %.0f s_memtime ticks (100 MHz)' % (M, e0.elapsed_time(e1) * 1e3, t.shape[0], t.sum(dim=1).mean().item()))
+    print('stamps         rows %d  %.1f us  waves %d  wave total %.0f s_memtime ticks' % (M, e0.elapsed_time(e1) * 1e3 / 5, t.shape[0], t.sum(dim=1).mean().item()))
     print('  '.join('%s %.1f%%' % (s, 100 * v) for s, v in zip(SEG, share.tolist())))
-    lib.lime_debug_set_ffn_stamp_buffer(None)
 
 
 if __name__ == '__main__':
