@@ -170,6 +170,40 @@ int64_t lime_ffn_pack_bf16_size(int32_t F, int32_t which);
 int lime_ffn_pack_bf16(const float* w1, int64_t ldw1, const float* b1, const float* w2, int64_t ldw2, int32_t E, int32_t F,
                        uint16_t* w1p, uint16_t* w2p, void* stream);
 
+/*
+ * lime_encoder_block_bf16: everything of an encoder layer behind the attention core in one launch
+ * (nn.TransformerEncoderLayer as newsEncoders.py:244-247, 316-321 run it):
+ *     x1 = LayerNorm1(res + add_rows + attn Wo^T)          y = LayerNorm2(x1 + W2 relu(W1 x1 + b1) + b2)
+ * attn: bf16 [M, lda] (the E real columns + zero columns up to 304, as lime_token_attention_bf16 writes it with out_cols = 304).
+ * res (bf16 rows of 304 columns): res_kind 2 = the word table [res_rows, ldr] gathered by res_ids[M] (layer 0), res_kind 3 = the layer
+ * input [M, ldr].  add_rows: fp32 [add_period, ld_add], row r % add_period is added to token r -- out_proj's bias, with the positional
+ * rows added to it where the residual is the bare word rows (add_period = S), or the bias alone (add_period = 1).
+ * x1 is rounded to bf16 (it feeds the bf16 GEMM and is the second residual, exactly as when lime_linear_bf16 stores it) and never
+ * leaves the CU: the attention tile, the residual rows and x1 share one stationary LDS image.  out / pool32 / m_dev as in
+ * lime_encoder_ffn_bf16.  w0p: lime_oproj_pack_bf16's output; ln1_* fp32 [E], 16-byte aligned.
+ */
+typedef struct {
+    const uint16_t* attn; int64_t lda;
+    const uint16_t* w0p;
+    const float* add_rows; int64_t ld_add; int32_t add_period;
+    int32_t res_kind;
+    const uint16_t* res;  int64_t ldr;  int64_t res_rows;
+    const int32_t* res_ids;
+    const float* ln1_gamma; const float* ln1_beta; float ln1_eps;
+    int32_t pool32;
+    const uint16_t* w1p;  const uint16_t* w2p;  const float* b2;
+    const float* ln2_gamma; const float* ln2_beta; float ln2_eps;
+    int32_t M, E, F;
+    void* out;            int64_t ldo;
+    const int32_t* m_dev;
+} lime_encoder_block_bf16_args;
+
+int lime_encoder_block_bf16(const lime_encoder_block_bf16_args* args, void* stream);
+
+/* out_proj weight fp32 [E, E] (ld ldw) -> wp: bf16 buffer of lime_oproj_pack_bf16_size() elements (the kernel's ring slots) */
+int64_t lime_oproj_pack_bf16_size(void);
+int lime_oproj_pack_bf16(const float* w, int64_t ldw, int32_t E, uint16_t* wp, void* stream);
+
 /* the column count (304) the bf16 encoder-block kernels carry the model dimension in */
 int32_t lime_ffn_bf16_model_columns(void);
 

@@ -67,6 +67,25 @@ class FfnBf16Args(ctypes.Structure):
     ]
 
 
+class EncoderBlockBf16Args(ctypes.Structure):
+    """lime_encoder_block_bf16_args of include/lime_hip.h (same field order)."""
+    _fields_ = [
+        ('attn', c_void_p), ('lda', c_int64),
+        ('w0p', c_void_p),
+        ('add_rows', c_void_p), ('ld_add', c_int64), ('add_period', c_int32),
+        ('res_kind', c_int32),
+        ('res', c_void_p), ('ldr', c_int64), ('res_rows', c_int64),
+        ('res_ids', c_void_p),
+        ('ln1_gamma', c_void_p), ('ln1_beta', c_void_p), ('ln1_eps', c_float),
+        ('pool32', c_int32),
+        ('w1p', c_void_p), ('w2p', c_void_p), ('b2', c_void_p),
+        ('ln2_gamma', c_void_p), ('ln2_beta', c_void_p), ('ln2_eps', c_float),
+        ('M', c_int32), ('E', c_int32), ('F', c_int32),
+        ('out', c_void_p), ('ldo', c_int64),
+        ('m_dev', c_void_p),
+    ]
+
+
 class CopyDesc(ctypes.Structure):
     """lime_copy_desc of include/lime_hip.h."""
     _fields_ = [('src', c_void_p), ('dst', c_void_p), ('bytes', c_int64)]
@@ -132,6 +151,9 @@ SIGNATURES = {
                                             c_int32, c_float, c_int32, c_void_p]),
     'lime_encoder_ffn_bf16': (c_int32, [ctypes.POINTER(FfnBf16Args), c_void_p]),
     'lime_ffn_pack_bf16': (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    'lime_encoder_block_bf16': (c_int32, [ctypes.POINTER(EncoderBlockBf16Args), c_void_p]),
+    'lime_oproj_pack_bf16_size': (c_int64, []),
+    'lime_oproj_pack_bf16': (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     'lime_ffn_bf16_model_columns': (c_int32, []),
     'lime_ffn_pack_bf16_size': (c_int64, [c_int32, c_int32]),
     'lime_to_bf16': (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64, c_int64, c_int32, c_void_p]),

@@ -575,6 +575,7 @@ def compact_applicable(ids, table, transformer, nhead):
 
 
 FUSED_FFN = os.environ.get('LIME_BF16_FUSED_FFN', '1') != '0'        # 0: linear1 / linear2 as two lime_linear_bf16 launches (A/B runs)
+FUSED_BLOCK = FUSED_FFN and os.environ.get('LIME_BF16_FUSED_BLOCK', '1') != '0'     # 0: out_proj + norm1 as its own launch
 
 
 def _ffn_fused_applicable(layer, E, EP):
@@ -612,16 +613,30 @@ def encode_tokens_bf16(ids, table_bf16, pe, transformer, nhead, pooled_out):
         else:
             qkv = ops.linear_bf16(x, w_in_b, b_in, n_alg=3 * E, k_alg=E)
         attn = ops.token_attention_bf16(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, 1.0 / math.sqrt(hd), out_cols=EP)
+        last = li == len(transformer.layers) - 1
+        pool = last and transformer.norm is None              # token mean pooling in the epilogue: fp32 means over 32-token blocks
+        if li == 0:
+            pe_p = torch.cat([pe[:S], pe.new_zeros(S, EP - E)], dim=1)
+        if FUSED_BLOCK and _ffn_fused_applicable(layer, E, EP) and E % 4 == 0:
+            # everything behind the attention core in ONE launch (csrc/ffn_bf16.hip): out_proj + residual + norm1 written into the
+            # stationary LDS tile the feed-forward half then reads
+            w1p, w2p = ops.ffn_pack_bf16(layer.linear1.weight, layer.linear1.bias, layer.linear2.weight)
+            res_kw = (dict(res=table_bf16, res_kind=2, res_ids=flat, add_rows=pe[:S] + sa.out_proj.bias) if li == 0 else
+                      dict(res=x, res_kind=3, add_rows=sa.out_proj.bias.view(1, E)))
+            y = ops.encoder_block_bf16(attn, ops.oproj_pack_bf16(sa.out_proj.weight), ln1=(layer.norm1.weight, layer.norm1.bias),
+                                       ln1_eps=layer.norm1.eps, w1p=w1p, w2p=w2p, b2=layer.linear2.bias, ln2=(layer.norm2.weight, layer.norm2.bias),
+                                       ln2_eps=layer.norm2.eps, E=E, pool32=pool, **res_kw)
+            if pool:
+                return ops.mean_pool(y[:, :E], M, S // 32, out=pooled_out)
+            x = y
+            continue
         w_o = ops.to_bf16(sa.out_proj.weight, rows_out=EP, cols_out=EP)
         ln1 = (padv(layer.norm1.weight), padv(layer.norm1.bias))
         if li == 0:
-            pe_p = torch.cat([pe[:S], pe.new_zeros(S, EP - E)], dim=1)
             x1 = ops.linear_bf16(attn, w_o, padv(sa.out_proj.bias), res=table_bf16, res_kind=2, res_ids=flat, res_pe=pe_p,
                                  res_period=S, ln=ln1, ln_eps=layer.norm1.eps, ln_count=E, n_alg=E, k_alg=E)
         else:
             x1 = ops.linear_bf16(attn, w_o, padv(sa.out_proj.bias), res=x, res_kind=3, ln=ln1, ln_eps=layer.norm1.eps, ln_count=E, n_alg=E, k_alg=E)
-        last = li == len(transformer.layers) - 1
-        pool = last and transformer.norm is None              # token mean pooling in the epilogue: fp32 means over 32-token blocks
         if _ffn_fused_applicable(layer, E, EP):
             # linear1 + ReLU + linear2 + residual + norm2 in ONE launch: the hidden state stays in registers (csrc/ffn_bf16.hip)
             w1p, w2p = ops.ffn_pack_bf16(layer.linear1.weight, layer.linear1.bias, layer.linear2.weight)
@@ -669,8 +684,17 @@ def encode_tokens_bf16_compact(ids, table_bf16, pe, transformer, nhead, pooled_o
                     c_ids=cmp.tok_rows, n_alg=3 * E, k_alg=E)
     attn = ops.token_attention_rows_bf16(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], cmp.row_map, cmp.n_compact, M + 1, S, nhead, hd,
                                          1.0 / math.sqrt(hd), out_cols=EP)
-    w_o = ops.to_bf16(sa.out_proj.weight, rows_out=EP, cols_out=EP)
     pe_p = torch.cat([pe[:S], pe.new_zeros(S, EP - E)], dim=1)
+    if FUSED_BLOCK and _ffn_fused_applicable(layer, E, EP) and E % 4 == 0:
+        w1p, w2p = ops.ffn_pack_bf16(layer.linear1.weight, layer.linear1.bias, layer.linear2.weight)
+        blocks = ops.encoder_block_bf16(attn, ops.oproj_pack_bf16(sa.out_proj.weight), pe[:S] + sa.out_proj.bias, (layer.norm1.weight, layer.norm1.bias),
+                                        layer.norm1.eps, res=table_bf16, res_kind=2, res_ids=cmp.ids_c, w1p=w1p,
+                                        w2p=w2p, b2=layer.linear2.bias, ln2=(layer.norm2.weight, layer.norm2.bias), ln2_eps=layer.norm2.eps,
+                                        E=E, pool32=True, m_dev=cmp.n_rows)     # fp32 [cap / 32, EP] block means
+        pooled_c = ops.mean_pool(blocks[:, :E], M + 1, S // 32)
+        ops.gather_rows(cmp.seq_inv, pooled_c, pooled_out)
+        return None
+    w_o = ops.to_bf16(sa.out_proj.weight, rows_out=EP, cols_out=EP)
     x1 = ops.linear_bf16(attn, w_o, padv(sa.out_proj.bias), res=table_bf16, res_kind=2, res_ids=cmp.ids_c, res_pe=pe_p, res_period=S,
                          ln=(padv(layer.norm1.weight), padv(layer.norm1.bias)), ln_eps=layer.norm1.eps, ln_count=E, n_alg=E, k_alg=E,
                          m_dev=cmp.n_rows)

@@ -639,6 +639,75 @@ def encoder_ffn_bf16(x, w1p, w2p, b2, ln, ln_eps, E, pool32=False, m_dev=None, o
     return out
 
 
+def oproj_pack_bf16(w):
+    """``lime_oproj_pack_bf16``: out_proj weight (fp32 [E, E]) -> the bf16 ring slots of ``encoder_block_bf16``."""
+    lib = _lib.load()
+    _mat(w, 'w')
+    E = w.shape[0]
+    if w.shape[1] != E:
+        raise ValueError('w must be square')
+    wp = torch.empty(int(lib.lime_oproj_pack_bf16_size()), dtype=torch.bfloat16, device=w.device)
+    check(lib.lime_oproj_pack_bf16(_p(w), _ld(w), E, _p(wp), _stream()), 'lime_oproj_pack_bf16')
+    return wp
+
+
+def _aligned16(t):
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
+def encoder_block_bf16(attn, w0p, add_rows, ln1, ln1_eps, res, res_kind, w1p, w2p, b2, ln2, ln2_eps, E, res_ids=None, pool32=False, m_dev=None,
+                       out=None):
+    """``lime_encoder_block_bf16``: out_proj + residual + norm1 + linear1 + ReLU + linear2 + residual + norm2 (+ 32-row block means) in
+    one launch.  attn bf16 [M, 304]; res_kind 2: res = bf16 table gathered by res_ids, 3: res = bf16 rows [M, 304]; add_rows fp32
+    [period, >= E]: out_proj's bias (+ the positional rows), row r % period goes to token r."""
+    lib = _lib.load()
+    _mat(attn, 'attn', dtype=torch.bfloat16)
+    _mat(res, 'res', dtype=torch.bfloat16)
+    _mat(add_rows, 'add_rows')
+    M, DP = attn.shape
+    F = w2p.numel() // ffn_model_columns()
+    if DP != ffn_model_columns() or res.shape[1] != DP:
+        raise ValueError('attn and res must have %d columns' % ffn_model_columns())
+    if add_rows.shape[1] < E:
+        raise ValueError('add_rows must have >= E columns')
+    if (w0p.numel() != int(lib.lime_oproj_pack_bf16_size()) or w1p.numel() != int(lib.lime_ffn_pack_bf16_size(F, 0)) or
+            w2p.numel() != int(lib.lime_ffn_pack_bf16_size(F, 1))):
+        raise ValueError('w0p / w1p / w2p must come from oproj_pack_bf16 / ffn_pack_bf16')
+    if pool32 and M % 32:
+        raise ValueError('pool32 needs M %% 32 == 0 (M = %d)' % M)
+    rows_out, odt = (M // 32, torch.float32) if pool32 else (M, torch.bfloat16)
+    if out is None:
+        out = torch.empty((rows_out, DP), dtype=odt, device=attn.device)
+    _mat(out, 'out', dtype=odt)
+    if tuple(out.shape) != (rows_out, DP):
+        raise ValueError('out must be [%d, %d]' % (rows_out, DP))
+    keep = [_aligned16(_vec(ln1[0], 'ln1 gamma', E)), _aligned16(_vec(ln1[1], 'ln1 beta', E))]
+    args = _lib.EncoderBlockBf16Args()
+    args.attn, args.lda = attn.data_ptr(), _ld(attn)
+    args.w0p = _vec(w0p, 'w0p', dtype=torch.bfloat16).data_ptr()
+    args.add_rows, args.ld_add, args.add_period = add_rows.data_ptr(), _ld(add_rows), add_rows.shape[0]
+    args.ln1_gamma, args.ln1_beta, args.ln1_eps = keep[0].data_ptr(), keep[1].data_ptr(), ln1_eps
+    args.res_kind = res_kind
+    args.res, args.ldr, args.res_rows = res.data_ptr(), _ld(res), res.shape[0]
+    if res_kind == 2:
+        args.res_ids = _vec(res_ids, 'res_ids', M, dtype=torch.int32).data_ptr()
+    elif res_kind == 3:
+        if res.shape[0] < M:
+            raise ValueError('res has too few rows')
+    else:
+        raise ValueError('res_kind must be 2 or 3')
+    args.pool32 = 1 if pool32 else 0
+    args.w1p, args.w2p = _vec(w1p, 'w1p', dtype=torch.bfloat16).data_ptr(), _vec(w2p, 'w2p', dtype=torch.bfloat16).data_ptr()
+    args.b2 = _vec(b2, 'b2', E).data_ptr()
+    args.ln2_gamma, args.ln2_beta, args.ln2_eps = _vec(ln2[0], 'ln2 gamma', E).data_ptr(), _vec(ln2[1], 'ln2 beta', E).data_ptr(), ln2_eps
+    args.M, args.E, args.F = M, E, F
+    args.out, args.ldo = out.data_ptr(), _ld(out)
+    if m_dev is not None:
+        args.m_dev = _vec(m_dev, 'm_dev', 1, dtype=torch.int32).data_ptr()
+    check(lib.lime_encoder_block_bf16(ctypes.byref(args), _stream()), 'lime_encoder_block_bf16')
+    return out
+
+
 def mean_pool_bf16(x, n_seq, S, dim, out=None):
     lib = _lib.load()
     _mat(x, 'x', dtype=torch.bfloat16)

@@ -616,6 +616,47 @@ def test_encoder_ffn_bf16(ops, M, F):
         check(blocks[:, :E], want[:mb].view(mb // 32, 32, E).mean(dim=1), tol=2e-3, what='fused bf16 ffn block means %s' % ((M, F),))
 
 
+@pytest.mark.parametrize('M,S,kind', [(4096, 128, 2), (4128, 32, 2), (1000, 128, 3), (36000, 128, 2)])
+def test_encoder_block_bf16(ops, M, S, kind):
+    """out_proj + residual + norm1 + the feed-forward half in one launch against the same arithmetic in torch: the gathered
+    (word rows + positional rows) and the dense residual, rows and pooled block means."""
+    E, EP, F, V = 300, 304, 512, 700
+    x, (w1, b1, w2, b2, g2, be2), _ = _ffn_case(8, F, seed=60)
+    attn = torch.zeros(M, EP, dtype=torch.bfloat16)
+    attn[:, :E] = bf(rnd(M, E, seed=61))
+    w0, b0 = rnd(E, E, seed=62, scale=0.06), rnd(E, seed=63)
+    g1, be1 = rnd(E, seed=64) + 1.5, rnd(E, seed=65)
+    if kind == 2:
+        table = torch.zeros(V, EP, dtype=torch.bfloat16)
+        table[:, :E] = bf(rnd(V, E, seed=66))
+        ids = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(67), dtype=torch.int32)
+        pe = rnd(S, E, seed=68)
+        res_f = table[ids.long(), :E].float() + pe[torch.arange(M) % S]
+        kw = dict(res=dev(table), res_kind=2, res_ids=dev(ids), add_rows=dev(pe + b0))
+    else:
+        xr = torch.zeros(M, EP, dtype=torch.bfloat16)
+        xr[:, :E] = bf(rnd(M, E, seed=69))
+        res_f = xr[:, :E].float()
+        kw = dict(res=dev(xr), res_kind=3, add_rows=dev(b0.view(1, E)))
+    x1 = bf(O.layer_norm(res_f + attn[:, :E].float() @ bf(w0).float().t() + b0, g1, be1)).float()
+    h = bf(torch.relu(x1 @ bf(w1).float().t() + bf(b1).float())).float()
+    want = O.layer_norm(x1 + h @ bf(w2).float().t() + b2, g2, be2)
+    w0p = ops.oproj_pack_bf16(dev(w0))
+    w0v = w0p.cpu().view(10, 304, 32).permute(1, 0, 2).reshape(304, 320)
+    assert torch.equal(w0v[:E, :E].view(torch.int16), bf(w0).view(torch.int16)) and (w0v[E:] == 0).all() and (w0v[:, E:] == 0).all()
+    w1p, w2p = ops.ffn_pack_bf16(dev(w1), dev(b1), dev(w2))
+    common = dict(w1p=w1p, w2p=w2p, b2=dev(b2), ln2=(dev(g2), dev(be2)), ln2_eps=1e-5, E=E)
+    common.update(ln1=(dev(g1), dev(be1)), ln1_eps=1e-5)
+    got = ops.encoder_block_bf16(dev(attn), w0p, **kw, **common)
+    assert got.dtype == torch.bfloat16 and got.shape == (M, 304) and (got[:, E:] == 0).all()
+    check(got[:, :E].float(), bf(want).float(), tol=2 * BF_TOL, what='fused bf16 block rows %s' % ((M, S, kind),))
+    mb = M // 32 * 32
+    kwb = {k: (v[:mb] if k in ('res_ids',) or (k == 'res' and kind == 3) else v) for k, v in kw.items()}
+    blocks = ops.encoder_block_bf16(dev(attn[:mb]), w0p, pool32=True, **kwb, **common)
+    assert blocks.dtype == torch.float32 and blocks.shape == (mb // 32, 304) and (blocks[:, E:] == 0).all()
+    check(blocks[:, :E], want[:mb].view(mb // 32, 32, E).mean(dim=1), tol=4e-3, what='fused bf16 block means %s' % ((M, S, kind),))
+
+
 def test_encoder_ffn_bf16_device_row_count_and_refusals(ops):
     E, F, M = 300, 512, 4096
     x, (w1, b1, w2, b2, g, be), want = _ffn_case(M, F, seed=50)

@@ -47,6 +47,28 @@ def main():
     def fused():
         return ops.encoder_ffn_bf16(x, w1p, w2p, b2, ln, 1e-5, E, pool32=True)
 
+    V, S = 60000, 128
+    table = torch.zeros(V, EP, dtype=torch.bfloat16, device='cuda')
+    table[:, :E] = rnd(V, E).to(torch.bfloat16)
+    ids = torch.randint(0, V, (M,), generator=g, dtype=torch.int32).cuda()
+    pe_p = torch.zeros(S, EP, device='cuda')
+    pe_p[:, :E] = rnd(S, E)
+    w0, b0, g1, be1 = rnd(E, E), rnd(E), rnd(E) + 1, rnd(E)
+    w0b, w0p = ops.to_bf16(w0, rows_out=EP, cols_out=EP), ops.oproj_pack_bf16(w0)
+    add = pe_p[:, :E] + b0
+
+    def oproj():
+        return ops.linear_bf16(x, w0b, padv(b0), res=table, res_kind=2, res_ids=ids, res_pe=pe_p, res_period=S, ln=(padv(g1), padv(be1)),
+                               ln_eps=1e-5, ln_count=E, n_alg=E, k_alg=E)
+
+    def block():
+        return ops.encoder_block_bf16(x, w0p, add, (g1, be1), 1e-5, res=table, res_kind=2, res_ids=ids, w1p=w1p, w2p=w2p,
+                                      b2=b2, ln2=ln, ln2_eps=1e-5, E=E, pool32=True)
+
+    x1 = oproj()
+    ref = ops.encoder_ffn_bf16(x1, w1p, w2p, b2, ln, 1e-5, E, pool32=True)
+    print('max |out_proj + ffn - block| = %.3e' % (ref - block()).abs().max().item())
+    print('out_proj alone %.1f us   block %.1f us' % (timed(oproj), timed(block)))
     a, b = two(), fused()
     print('max |two - fused| = %.3e (mean |two| %.3e)' % ((a - b).abs().max().item(), a.abs().mean().item()))
     t2, tf = timed(two), timed(fused)
