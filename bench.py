@@ -273,7 +273,8 @@ def roofline(by_kernel, workload, steps):
         tj = json.load(open(tfile))
         traffic = tj.get(name, {}).get('hbm_bytes_per_launch')
         source = tj.get('_source', 'profiles/traffic.json')
-    is_bf16 = name.startswith('gemm_pp_kernel<') and name.split(', ')[4].startswith('true')   # <NTL, LN, RELU, RES, BF, ...>
+    is_bf16 = ((name.startswith('gemm_pp_kernel<') and name.split(', ')[4].startswith('true')) or     # <NTL, LN, RELU, RES, BF, ...>
+               name.startswith('ffn_bf16_kernel<'))                                                    # the fused bf16 encoder block
     peak = PEAK_BF16_MFMA_TFLOPS if is_bf16 else PEAK_F32_MFMA_TFLOPS
     return {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
             'frac': round(ach / peak, 4), 'frac_padded': round(flp / sec / 1e12 / peak, 4),

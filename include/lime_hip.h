@@ -204,6 +204,30 @@ int lime_encoder_block_bf16(const lime_encoder_block_bf16_args* args, void* stre
 int64_t lime_oproj_pack_bf16_size(void);
 int lime_oproj_pack_bf16(const float* w, int64_t ldw, int32_t E, uint16_t* wp, void* stream);
 
+/*
+ * lime_inproj_bf16: the q / k / v projection in front of lime_token_attention_bf16, activation-stationary (csrc/inproj_bf16.hip):
+ *     out[c_ids[r] or r, n] = bf16( a[a_ids[r] or r, :] . w[n, :] + add_rows[(c_ids[r] or r) % add_period, n] ),   n < N
+ * a: bf16 rows of K valid columns (the word table gathered by a_ids, or the layer input); wp: lime_inproj_pack_bf16's output for the
+ * fp32 weight [N, K] with the heads already padded to 32 columns (lime_pad_heads_f32), N a multiple of 320, K <= 320, K % 8 == 0;
+ * add_rows fp32 [add_period, >= N]: bias, or positional rows x weight + bias (the linear identity of SURVEY section 7).
+ * The same operation as lime_linear_bf16 with c_ids (that kernel remains for other shapes); this one reads the tile once for all
+ * N columns.  a_rows / out_rows: the row counts of a and out (32-bit offset checks).  m_dev: optional device row count.
+ */
+typedef struct {
+    const uint16_t* a;   int64_t lda;  int64_t a_rows;  const int32_t* a_ids;
+    const uint16_t* wp;
+    const float* add_rows; int64_t ld_add; int32_t add_period;
+    int32_t M, N, K;
+    int32_t reserved;
+    const int32_t* c_ids;
+    uint16_t* out;       int64_t ldo;  int64_t out_rows;
+    const int32_t* m_dev;
+} lime_inproj_bf16_args;
+
+int lime_inproj_bf16(const lime_inproj_bf16_args* args, void* stream);
+int64_t lime_inproj_pack_bf16_size(int32_t N);
+int lime_inproj_pack_bf16(const float* w, int64_t ldw, int32_t N, int32_t K, uint16_t* wp, void* stream);
+
 /* the column count (304) the bf16 encoder-block kernels carry the model dimension in */
 int32_t lime_ffn_bf16_model_columns(void);
 

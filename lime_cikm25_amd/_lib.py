@@ -86,6 +86,20 @@ class EncoderBlockBf16Args(ctypes.Structure):
     ]
 
 
+class InprojBf16Args(ctypes.Structure):
+    """lime_inproj_bf16_args of include/lime_hip.h (same field order)."""
+    _fields_ = [
+        ('a', c_void_p), ('lda', c_int64), ('a_rows', c_int64), ('a_ids', c_void_p),
+        ('wp', c_void_p),
+        ('add_rows', c_void_p), ('ld_add', c_int64), ('add_period', c_int32),
+        ('M', c_int32), ('N', c_int32), ('K', c_int32),
+        ('reserved', c_int32),
+        ('c_ids', c_void_p),
+        ('out', c_void_p), ('ldo', c_int64), ('out_rows', c_int64),
+        ('m_dev', c_void_p),
+    ]
+
+
 class CopyDesc(ctypes.Structure):
     """lime_copy_desc of include/lime_hip.h."""
     _fields_ = [('src', c_void_p), ('dst', c_void_p), ('bytes', c_int64)]
@@ -154,6 +168,9 @@ SIGNATURES = {
     'lime_encoder_block_bf16': (c_int32, [ctypes.POINTER(EncoderBlockBf16Args), c_void_p]),
     'lime_oproj_pack_bf16_size': (c_int64, []),
     'lime_oproj_pack_bf16': (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    'lime_inproj_bf16': (c_int32, [ctypes.POINTER(InprojBf16Args), c_void_p]),
+    'lime_inproj_pack_bf16_size': (c_int64, [c_int32]),
+    'lime_inproj_pack_bf16': (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     'lime_ffn_bf16_model_columns': (c_int32, []),
     'lime_ffn_pack_bf16_size': (c_int64, [c_int32, c_int32]),
     'lime_to_bf16': (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64, c_int64, c_int32, c_void_p]),

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(const FfnP p) {
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const long row = row0 + 32 * wave + 16 * tt + fi_;
-                pof[tt] = (unsigned)(row % p.res_period) * (unsigned)(p.ldpe * 4) + (unsigned)kg_ * 16u;
+                pof[tt] = ((unsigned)row % (unsigned)p.res_period) * (unsigned)(p.ldpe * 4) + (unsigned)kg_ * 16u;      // 32-bit: rows < 2^31
             }
             f32x4 pe[2][ND];
             auto load_add_rows = [&](int t0, int t1) {
@@ -521,6 +521,7 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(const FfnP p) {
             step(std::integral_constant<int, TP_FFN + 2>{}, pass);
             step(std::integral_constant<int, TP_FFN + 3>{}, pass);
             step(std::integral_constant<int, TP_FFN + 4>{}, pass);
+            mfma_settle();
             // ReLU, round to bf16: tiles 2 kc and 2 kc + 1 side by side are the lane's 8 k slots of hidden chunk kc
             // (k = 32 kc + 16 a + 4 kg + r at slot 4 a + r: the order lime_ffn_pack_bf16 gives linear2's weight columns)
 #pragma unroll
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(const FfnP p) {
                     u32x4 h;
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
-                        const f32x4 v = acc1[tt][2 * kc + a];
+                        const f32x4 v = acc_read4(acc1[tt][2 * kc + a]);
                         h[2 * a] = pack_bf16(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
                         h[2 * a + 1] = pack_bf16(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
                     }
@@ -554,6 +555,8 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(const FfnP p) {
         const unsigned char* const rbase = lds + (32 * wave + fi_) * 64 + 8 * (kg_ & 1);
         const int rswz = swz4((fi_ >> 2) & 3), rsg = kg_ >> 1;
         const float* const cs_ = cs + 4 * kg_;
+        f32x4 val[2][ND];                              // the accumulators leave the AccVGPRs here (lds_dma.h, acc_read)
+        mfma_settle();
 #pragma unroll
         for (int t = 0; t < ND; ++t) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(cs_ + 16 * t);
@@ -562,7 +565,7 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(const FfnP p) {
                 const int seg = 2 * (t & 1) + rsg;
                 f32x4 r = unpack_bf16x4(*reinterpret_cast<const u32x2*>(rbase + (t >> 1) * SLAB + tt * 1024 + ((seg ^ rswz) * 16)));
                 if (t == te && kg_ == kge) r[re] = 0.f;
-                acc2[tt][t] += b + r;
+                val[tt][t] = acc_read4(acc2[tt][t]) + b + r;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the image has been read ... before the DMAs overwrite those rows
@@ -576,7 +579,7 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(const FfnP p) {
         for (int t = 0; t < ND; ++t)
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                const f32x4 v = acc2[tt][t];
+                const f32x4 v = val[tt][t];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { sum[tt] += v[j]; sq[tt] += v[j] * v[j]; }
             }
@@ -601,8 +604,8 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(const FfnP p) {
             for (int t = 0; t < ND; ++t) {
                 const f32x4 ga = *reinterpret_cast<const f32x4*>(gs_ + 16 * t);
                 const f32x4 be = *reinterpret_cast<const f32x4*>(es_ + 16 * t);
-                f32x4 y = (acc2[0][t] - mean[0]) * rstd[0] * ga + be;
-                y += (acc2[1][t] - mean[1]) * rstd[1] * ga + be;
+                f32x4 y = (val[0][t] - mean[0]) * rstd[0] * ga + be;
+                y += (val[1][t] - mean[1]) * rstd[1] * ga + be;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) y[j] = row16_sum(y[j]) * (1.0f / 32.0f);
                 buf_store4(y, rs_p, (rows_ok && fi_ == 0) ? (unsigned)(16 * t + 4 * kg_) * 4u : OOB, 0);
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(const FfnP p) {
                 const f32x4 ga = *reinterpret_cast<const f32x4*>(gs_ + 16 * t);
                 const f32x4 be = *reinterpret_cast<const f32x4*>(es_ + 16 * t);
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) buf_store4_bf16((acc2[tt][t] - mean[tt]) * rstd[tt] * ga + be, rs_c, cof[tt] + (unsigned)t * 32u, 0);
+                for (int tt = 0; tt < 2; ++tt) buf_store4_bf16((val[tt][t] - mean[tt]) * rstd[tt] * ga + be, rs_c, cof[tt] + (unsigned)t * 32u, 0);
             }
         }
         FSTAMP(7)                                      // 7: epilogue

@@ -35,6 +35,22 @@ __device__ __forceinline__ void ring_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// One accumulator register -> a VGPR, HERE.  Left to itself hipcc copies every accumulator of a kernel out of the AccVGPRs in front
+// of the first VALU use (160 copies ahead of a store epilogue: the VGPR file overflows and loop-carried values go to scratch);
+// the "a" constraint keeps the value in its AccVGPR until this instruction.  The caller puts mfma_settle() between the last MFMA
+// and the first of these: inline asm is outside the compiler's MFMA hazard bookkeeping.
+__device__ __forceinline__ float acc_read(float a) {
+    float v;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+    return v;
+}
+__device__ __forceinline__ f32x4 acc_read4(const f32x4& a) { return f32x4{acc_read(a[0]), acc_read(a[1]), acc_read(a[2]), acc_read(a[3])}; }
+__device__ __forceinline__ void mfma_settle() {        // > the 16 cycles of a v_mfma_f32_16x16x32_bf16 plus its write-back
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // Swizzle of the [row][four 16-byte segments] image: physical segment = logical ^ swz4((row >> 2) & 3) -- conflict free for
 // the ds_read_b128 fragment reads of the 16x16 MFMA lane layout (gemm_pp_f32.hip has the derivation).
 __device__ __forceinline__ int swz4(int q) { return (0x78 >> (2 * q)) & 3; }

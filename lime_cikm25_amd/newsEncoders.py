@@ -578,6 +578,11 @@ FUSED_FFN = os.environ.get('LIME_BF16_FUSED_FFN', '1') != '0'        # 0: linear
 FUSED_BLOCK = FUSED_FFN and os.environ.get('LIME_BF16_FUSED_BLOCK', '1') != '0'     # 0: out_proj + norm1 as its own launch
 
 
+def _inproj_applicable(N, K):
+    """lime_inproj_bf16: q / k / v columns in passes of 320 (ten heads padded to 32), K <= 320."""
+    return FUSED_FFN and N % 320 == 0 and K <= 320 and K % 8 == 0
+
+
 def _ffn_fused_applicable(layer, E, EP):
     """lime_encoder_ffn_bf16 is built for the reference's encoder shape: E = 300 carried as 304, hidden width a multiple of 128."""
     return (FUSED_FFN and EP == ops.ffn_model_columns() and EP - 15 <= E < EP and layer.linear1.out_features % 128 == 0 and
@@ -606,12 +611,19 @@ def encode_tokens_bf16(ids, table_bf16, pe, transformer, nhead, pooled_out):
         sa = layer.self_attn
         w_in = ops.pad_heads(sa.in_proj_weight, 3 * nhead, hd, 32)                  # fp32 [3W, E]
         b_in = ops.pad_heads(sa.in_proj_bias, 3 * nhead, hd, 32)
-        w_in_b = ops.to_bf16(w_in, cols_out=EP)
-        if li == 0:
+        if _inproj_applicable(3 * W, EP):
+            # activation-stationary q / k / v projection (csrc/inproj_bf16.hip): the tile is read once for all 3 W columns
+            w_in_p = ops.inproj_pack_bf16(w_in, EP)
+            qkv = torch.empty((M * S, 3 * W), dtype=torch.bfloat16, device=dev)
+            if li == 0:
+                ops.inproj_bf16(table_bf16, w_in_p, ops.linear(pe[:S], w_in, b_in), 3 * W, qkv, a_ids=flat)     # + positional term + bias
+            else:
+                ops.inproj_bf16(x, w_in_p, b_in.view(1, -1), 3 * W, qkv)
+        elif li == 0:
             pew = ops.linear(pe[:S], w_in, b_in)                                     # fp32 [S, 3W]: positional term + bias
-            qkv = ops.linear_bf16(table_bf16, w_in_b, None, a_ids=flat, res=pew, res_kind=1, res_mod=S, n_alg=3 * E, k_alg=E)
+            qkv = ops.linear_bf16(table_bf16, ops.to_bf16(w_in, cols_out=EP), None, a_ids=flat, res=pew, res_kind=1, res_mod=S, n_alg=3 * E, k_alg=E)
         else:
-            qkv = ops.linear_bf16(x, w_in_b, b_in, n_alg=3 * E, k_alg=E)
+            qkv = ops.linear_bf16(x, ops.to_bf16(w_in, cols_out=EP), b_in, n_alg=3 * E, k_alg=E)
         attn = ops.token_attention_bf16(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, 1.0 / math.sqrt(hd), out_cols=EP)
         last = li == len(transformer.layers) - 1
         pool = last and transformer.norm is None              # token mean pooling in the epilogue: fp32 means over 32-token blocks
@@ -675,13 +687,18 @@ def encode_tokens_bf16_compact(ids, table_bf16, pe, transformer, nhead, pooled_o
     cmp = ops.compact_sequences(ids)
     w_in = ops.pad_heads(sa.in_proj_weight, 3 * nhead, hd, 32)
     b_in = ops.pad_heads(sa.in_proj_bias, 3 * nhead, hd, 32)
-    w_in_b = ops.to_bf16(w_in, cols_out=EP)
     pew = ops.linear(pe[:S], w_in, b_in)                                       # fp32 [S, 3W]
     qkv = torch.empty((cap + S, 3 * W), dtype=torch.bfloat16, device=dev)
     zeros = torch.zeros(S, dtype=torch.int32, device=dev)
-    ops.linear_bf16(table_bf16, w_in_b, None, a_ids=zeros, res=pew, res_kind=1, res_mod=S, out=qkv[cap:])
-    ops.linear_bf16(table_bf16, w_in_b, None, a_ids=cmp.tok_ids, res=pew, res_kind=1, res_mod=S, out=qkv[:cap], m_dev=cmp.n_live_tokens,
-                    c_ids=cmp.tok_rows, n_alg=3 * E, k_alg=E)
+    if _inproj_applicable(3 * W, EP):
+        w_in_p = ops.inproj_pack_bf16(w_in, EP)
+        ops.inproj_bf16(table_bf16, w_in_p, pew, 3 * W, qkv[cap:], a_ids=zeros)
+        ops.inproj_bf16(table_bf16, w_in_p, pew, 3 * W, qkv[:cap], a_ids=cmp.tok_ids, c_ids=cmp.tok_rows, m_dev=cmp.n_live_tokens)
+    else:
+        w_in_b = ops.to_bf16(w_in, cols_out=EP)
+        ops.linear_bf16(table_bf16, w_in_b, None, a_ids=zeros, res=pew, res_kind=1, res_mod=S, out=qkv[cap:])
+        ops.linear_bf16(table_bf16, w_in_b, None, a_ids=cmp.tok_ids, res=pew, res_kind=1, res_mod=S, out=qkv[:cap], m_dev=cmp.n_live_tokens,
+                        c_ids=cmp.tok_rows, n_alg=3 * E, k_alg=E)
     attn = ops.token_attention_rows_bf16(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], cmp.row_map, cmp.n_compact, M + 1, S, nhead, hd,
                                          1.0 / math.sqrt(hd), out_cols=EP)
     pe_p = torch.cat([pe[:S], pe.new_zeros(S, EP - E)], dim=1)

@@ -635,7 +635,60 @@ def encoder_ffn_bf16(x, w1p, w2p, b2, ln, ln_eps, E, pool32=False, m_dev=None, o
     args.M, args.E, args.F = M, E, F
     if m_dev is not None:
         args.m_dev = _vec(m_dev, 'm_dev', 1, dtype=torch.int32).data_ptr()
+    if PROFILE is not None:                        # bench.py: as ONE GEMM of the two layers' FLOPs: 2 M E (2 F)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.lime_encoder_ffn_bf16(ctypes.byref(args), _stream()), 'lime_encoder_ffn_bf16')
+        e1.record()
+        m_run = M if m_dev is None else min(M, int(m_dev.item()))
+        PROFILE.append(('ffn_bf16_kernel<%s, false>' % ('true' if pool32 else 'false'), m_run, 2 * F, E, 2 * F, e0, e1))
+        return out
     check(lib.lime_encoder_ffn_bf16(ctypes.byref(args), _stream()), 'lime_encoder_ffn_bf16')
+    return out
+
+
+def inproj_pack_bf16(w, K):
+    """``lime_inproj_pack_bf16``: in_proj weight (fp32 [N, E], heads padded to 32 columns: N % 320 == 0) -> the bf16 ring slots of
+    ``inproj_bf16``; K: the column count of the bf16 operand rows (E rounded up to 8; the columns beyond E get zero weights)."""
+    lib = _lib.load()
+    _mat(w, 'w')
+    N = w.shape[0]
+    if w.shape[1] > K:
+        raise ValueError('K must cover the weight columns')
+    wp = torch.empty(int(lib.lime_inproj_pack_bf16_size(N)), dtype=torch.bfloat16, device=w.device)
+    check(lib.lime_inproj_pack_bf16(_p(w), _ld(w), N, w.shape[1], _p(wp), _stream()), 'lime_inproj_pack_bf16')
+    return wp
+
+
+def inproj_bf16(a, wp, add_rows, N, out, a_ids=None, c_ids=None, m_dev=None):
+    """``lime_inproj_bf16``: out[c_ids[r] or r] = bf16(a[a_ids[r] or r] . w^T + add_rows[(c_ids[r] or r) % period]); a bf16 [*, K]."""
+    lib = _lib.load()
+    _mat(a, 'a', dtype=torch.bfloat16)
+    _mat(out, 'out', dtype=torch.bfloat16)
+    _mat(add_rows, 'add_rows')
+    K = a.shape[1]
+    M = a_ids.numel() if a_ids is not None else a.shape[0]
+    if out.shape[1] != N or add_rows.shape[1] < N or wp.numel() != int(lib.lime_inproj_pack_bf16_size(N)):
+        raise ValueError('out must have N columns, add_rows >= N columns, wp must come from inproj_pack_bf16')
+    args = _lib.InprojBf16Args()
+    args.a, args.lda, args.a_rows = a.data_ptr(), _ld(a), a.shape[0]
+    args.a_ids = _vec(a_ids, 'a_ids', dtype=torch.int32).data_ptr() if a_ids is not None else None
+    args.wp = _vec(wp, 'wp', dtype=torch.bfloat16).data_ptr()
+    args.add_rows, args.ld_add, args.add_period = add_rows.data_ptr(), _ld(add_rows), add_rows.shape[0]
+    args.M, args.N, args.K = M, N, K
+    args.c_ids = _vec(c_ids, 'c_ids', M, dtype=torch.int32).data_ptr() if c_ids is not None else None
+    args.out, args.ldo, args.out_rows = out.data_ptr(), _ld(out), out.shape[0]
+    if m_dev is not None:
+        args.m_dev = _vec(m_dev, 'm_dev', 1, dtype=torch.int32).data_ptr()
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.lime_inproj_bf16(ctypes.byref(args), _stream()), 'lime_inproj_bf16')
+        e1.record()
+        m_run = M if m_dev is None else min(M, int(m_dev.item()))
+        PROFILE.append(('inproj_bf16_kernel', m_run, N, K // 8 * 8 - (4 if K == 304 else 0), N * 30 // 32, e0, e1))
+        return out
+    check(lib.lime_inproj_bf16(ctypes.byref(args), _stream()), 'lime_inproj_bf16')
     return out
 
 
@@ -704,6 +757,14 @@ def encoder_block_bf16(attn, w0p, add_rows, ln1, ln1_eps, res, res_kind, w1p, w2
     args.out, args.ldo = out.data_ptr(), _ld(out)
     if m_dev is not None:
         args.m_dev = _vec(m_dev, 'm_dev', 1, dtype=torch.int32).data_ptr()
+    if PROFILE is not None:                        # bench.py: as ONE GEMM of the block's FLOPs: 2 M (E E + 2 E F) = 2 M E (E + 2 F)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.lime_encoder_block_bf16(ctypes.byref(args), _stream()), 'lime_encoder_block_bf16')
+        e1.record()
+        m_run = M if m_dev is None else min(M, int(m_dev.item()))
+        PROFILE.append(('ffn_bf16_kernel<%s, true>' % ('true' if pool32 else 'false'), m_run, DP + 2 * F, E, E + 2 * F, e0, e1))
+        return out
     check(lib.lime_encoder_block_bf16(ctypes.byref(args), _stream()), 'lime_encoder_block_bf16')
     return out
 

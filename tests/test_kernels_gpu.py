@@ -580,6 +580,41 @@ def test_linear_bf16_encoder_layer_gemms(ops, M, S):
     check(pooled, x2[:n_seq * S, :E].float().cpu().view(n_seq, S, E).mean(dim=1), what='bf16 mean pool')
 
 
+@pytest.mark.parametrize('M,S,compact', [(4096, 128, False), (4200, 32, False), (36001, 128, True), (130, 128, True)])
+def test_inproj_bf16(ops, M, S, compact):
+    """The activation-stationary q / k / v projection against the same arithmetic in torch: gathered word rows, the fp32 periodic
+    rows indexed by the OUTPUT row, rows scattered by c_ids (compacted batch) or in place; row counts that end inside a tile."""
+    V, E, EP, N = 700, 300, 304, 960
+    table = torch.zeros(V, EP, dtype=torch.bfloat16)
+    table[:, :E] = bf(rnd(V, E, seed=70))
+    ids = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(71), dtype=torch.int32)
+    w = rnd(N, E, seed=72, scale=0.06)
+    add = rnd(S, N, seed=73)
+    cap = M + 77 if compact else M
+    c_ids = torch.randperm(cap, generator=torch.Generator().manual_seed(74))[:M].to(torch.int32) if compact else None
+    orow = c_ids.long() if compact else torch.arange(M)
+    want = table[ids.long(), :E].float() @ bf(w).float().t() + add[orow % S]
+    wp = ops.inproj_pack_bf16(dev(w), EP)
+    # packed [pass][chunk][320 rows][32 k]; row 16 t + 4 kg + q of a pass is output column 32 (t >> 1) + 8 kg + 4 (t & 1) + q
+    wv = wp.cpu().view(N // 320, 10, 10, 2, 4, 4, 32).permute(0, 2, 4, 3, 5, 1, 6).reshape(N, 320)      # [pass][t >> 1][kg][t & 1][q] x [chunk][k]
+    assert torch.equal(wv[:, :E].view(torch.int16), bf(w).view(torch.int16)) and (wv[:, E:] == 0).all()
+    out = torch.full((cap, N), 3.0, dtype=torch.bfloat16, device='cuda')
+    ops.inproj_bf16(dev(table), wp, dev(add), N, out, a_ids=dev(ids), c_ids=dev(c_ids))
+    got = out.cpu()
+    check(got[orow].float(), bf(want).float(), tol=BF_TOL, what='inproj bf16 %s' % ((M, S, compact),))
+    if compact:
+        untouched = torch.ones(cap, dtype=torch.bool)
+        untouched[orow] = False
+        assert (got[untouched] == 3.0).all()
+    # a device-side row count: only the first rows are produced
+    m_dev = torch.tensor([M // 2 + 3], dtype=torch.int32, device='cuda')
+    out2 = torch.full((cap, N), 3.0, dtype=torch.bfloat16, device='cuda')
+    ops.inproj_bf16(dev(table), wp, dev(add), N, out2, a_ids=dev(ids), c_ids=dev(c_ids), m_dev=m_dev)
+    g2 = out2.cpu()
+    k = M // 2 + 3
+    assert torch.equal(g2[orow[:k]].view(torch.int16), got[orow[:k]].view(torch.int16)) and (g2[orow[k:]] == 3.0).all()
+
+
 def _ffn_case(M, F, seed):
     E, EP = 300, 304
     x = torch.zeros(M, EP, dtype=torch.bfloat16)

@@ -69,6 +69,25 @@ def main():
     ref = ops.encoder_ffn_bf16(x1, w1p, w2p, b2, ln, 1e-5, E, pool32=True)
     print('max |out_proj + ffn - block| = %.3e' % (ref - block()).abs().max().item())
     print('out_proj alone %.1f us   block %.1f us' % (timed(oproj), timed(block)))
+    # in_proj: 220k live tokens scattered into a 360k-row qkv buffer
+    Ml, N = 220160, 960
+    w_in = rnd(N, E)
+    pew = rnd(S, N)
+    tok = torch.randint(0, V, (Ml,), generator=g, dtype=torch.int32).cuda()
+    rows = torch.sort(torch.randperm(M, generator=g)[:Ml]).values.to(torch.int32).cuda()
+    qkv = torch.empty((M, N), dtype=torch.bfloat16, device='cuda')
+    w_in_b, w_in_p = ops.to_bf16(w_in, cols_out=EP), ops.inproj_pack_bf16(w_in, EP)
+    old_in = lambda: ops.linear_bf16(table, w_in_b, None, a_ids=tok, res=pew, res_kind=1, res_mod=S, out=qkv, c_ids=rows, n_alg=3 * E, k_alg=E)
+    new_in = lambda: ops.inproj_bf16(table, w_in_p, pew, N, qkv, a_ids=tok, c_ids=rows)
+    old_in()
+    ref_q = qkv.clone()
+    qkv.zero_()
+    new_in()
+    print('in_proj max |old - new| = %.3e' % (ref_q.float() - qkv.float()).abs().max().item())
+    t_o, t_n = timed(old_in), timed(new_in)
+    fl = 2.0 * Ml * 900 * E
+    print('in_proj rows %d   gemm_pp %.1f us (%.0f TF)   activation-stationary %.1f us (%.0f TF = %.3f of 2.5 PF)' %
+          (Ml, t_o, fl / t_o / 1e6, t_n, fl / t_n / 1e6, fl / t_n / 1e6 / 2500))
     a, b = two(), fused()
     print('max |two - fused| = %.3e (mean |two| %.3e)' % ((a - b).abs().max().item(), a.abs().mean().item()))
     t2, tf = timed(two), timed(fused)
