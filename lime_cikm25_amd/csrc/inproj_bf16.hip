@@ -256,7 +256,8 @@ __global__ __launch_bounds__(256, 1) void inproj_bf16_kernel(const InP p) {
                         if (row < M) {
                             const unsigned orow = p.c_ids ? (unsigned)cid_cur[tt] : (unsigned)row;       // 32-bit: a 64-bit % is a long routine
                             pof[tt] = (orow % (unsigned)p.period) * (unsigned)(p.ld_add * 4) + (unsigned)kg_ * 32u;
-                            cof[tt] = orow * (unsigned)(p.ldo * 2) + (unsigned)kg_ * 16u;
+                            // scattered rows: offsets from the base of out; rows in place: from the tile's first row (any M)
+                            cof[tt] = (p.c_ids ? orow : (unsigned)(row - row0)) * (unsigned)(p.ldo * 2) + (unsigned)kg_ * 16u;
                         } else {
                             pof[tt] = OOB;
                             cof[tt] = OOB;
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void inproj_bf16_kernel(const InP p) {
             if (lastp && !last) issue_x(n_voff, NCH - 1);
             mfma_settle();
             // pass epilogue: + the fp32 rows, bf16, to row c_ids[r]
-            const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(p.out);
+            const __amdgpu_buffer_rsrc_t rs_c = make_rsrc(p.c_ids ? p.out : p.out + row0 * p.ldo);
 #pragma unroll
             for (int b = 0; b < NEB; ++b) {
                 if (b + 1 < NEB) load_add(b + 1);
@@ -354,8 +355,9 @@ extern "C" int lime_inproj_bf16(const lime_inproj_bf16_args* a, void* stream) {
                  "lime_inproj_bf16: add_rows must be fp32 [add_period >= 1, >= N], 16-byte aligned rows");
     LIME_REQUIRE(a->ldo >= a->N && a->ldo % 4 == 0 && (uintptr_t)a->out % 8 == 0, LIME_ERR_BAD_ARG, "lime_inproj_bf16: out rows must be 8-byte aligned");
     const long lim = 0x7FFFFFF0L;
-    LIME_REQUIRE((long)a->a_rows * a->lda * 2 < lim && (long)a->out_rows * a->ldo * 2 < lim && (long)a->add_period * a->ld_add * 4 < lim &&
-                 (long)a->N * 320 * 2 < lim, LIME_ERR_UNSUPPORTED, "lime_inproj_bf16: operand too large for 32-bit offsets");
+    LIME_REQUIRE((long)a->a_rows * a->lda * 2 < lim && (long)(a->c_ids ? a->out_rows : 128) * a->ldo * 2 < lim &&
+                 (long)a->add_period * a->ld_add * 4 < lim && (long)a->N * 320 * 2 < lim && (long)a->M * 4 < lim, LIME_ERR_UNSUPPORTED,
+                 "lime_inproj_bf16: operand too large for 32-bit offsets (a rows x lda, scattered out rows x ldo < 2 GB)");
     LIME_REQUIRE(a->a_ids || a->a_rows >= a->M, LIME_ERR_BAD_ARG, "lime_inproj_bf16: a has fewer rows than M");
     LIME_REQUIRE(a->c_ids || a->out_rows >= a->M, LIME_ERR_BAD_ARG, "lime_inproj_bf16: out has fewer rows than M");
     if (a->M == 0) return LIME_OK;

@@ -615,6 +615,25 @@ def test_inproj_bf16(ops, M, S, compact):
     assert torch.equal(g2[orow[:k]].view(torch.int16), got[orow[:k]].view(torch.int16)) and (g2[orow[k:]] == 3.0).all()
 
 
+def test_inproj_bf16_more_than_2gb_of_rows(ops):
+    """Rows written in place are addressed from their tile's first row: an output beyond 2 GB (the dense config-3 pass) works."""
+    V, E, EP, N, S = 500, 300, 304, 960, 128
+    M = 1_200_000 // S * S                                       # x 1,920 bytes = 2.3 GB
+    g = torch.Generator(device='cuda').manual_seed(5)
+    table = torch.zeros(V, EP, dtype=torch.bfloat16, device='cuda')
+    table[:, :E] = ((torch.rand(V, E, generator=g, device='cuda') * 2 - 1)).to(torch.bfloat16)
+    ids = torch.randint(0, V, (M,), generator=g, device='cuda', dtype=torch.int32)
+    w = (torch.rand(N, E, generator=g, device='cuda') * 2 - 1) * 0.06
+    add = torch.rand(S, N, generator=g, device='cuda') * 2 - 1
+    out = torch.empty((M, N), dtype=torch.bfloat16, device='cuda')
+    ops.inproj_bf16(table, ops.inproj_pack_bf16(w, EP), add, N, out, a_ids=ids)
+    for lo in (0, M // 2 - 77, M - 4096):
+        rows = torch.arange(lo, lo + 4096, device='cuda')
+        want = table[ids[rows].long(), :E].float() @ w.to(torch.bfloat16).float().t() + add[rows % S]
+        check(out[rows].float(), want.to(torch.bfloat16).float().cpu(), tol=BF_TOL, what='inproj rows %d..' % lo)
+    del out
+
+
 def _ffn_case(M, F, seed):
     E, EP = 300, 304
     x = torch.zeros(M, EP, dtype=torch.bfloat16)
