@@ -33,7 +33,7 @@ def main():
     ap.add_argument('--txt', required=True)
     a = ap.parse_args()
     f, w = read(a.fetch_csv, 'FETCH_SIZE'), read(a.write_csv, 'WRITE_SIZE')
-    res, lines = {}, ['# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/bench_kernels.py --iters 1 at the config-2 shapes',
+    res, lines = {}, ['# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/collect_profiles.sh) of `python bench.py --plain --steps 3 --warmup 2`',
                       '# values: KiB per dispatch as reported; hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- on gfx950 FETCH_SIZE',
                       '# reports half the bytes of a wide (16 B / lane) streaming read (MI355X_MICROARCH.md, HBM section).',
                       '# Per kernel the launches are listed in order (title shape first, then body shape; warm-up launch included).']
