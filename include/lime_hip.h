@@ -289,8 +289,11 @@ int lime_token_attention_rows_f32(const float* q, const float* k, const float* v
  *   seq_inv  [n_seq]          compact index of every sequence; all-padding sequences share ONE representative (index n_live)
  *   ids_c    [(n_seq + 1) S]  ids in compact order (representative: zeros)
  *   row_map  [(n_seq + 1) S]  compact token row -> its q/k/v row: itself when live, pad_base + t for a padding token
- *   tok_ids / tok_rows [(n_seq + 1) S]  ids and compact rows of the live tokens, in (compact sequence, position) order
- *   counts   [4]              n_live + 1, (n_live + 1) S, live tokens, n_live   (device memory: lime_linear_args.m_dev, n_seq_dev)
+ *   tok_ids / tok_rows [(n_seq + 1) S]  ids and compact rows of the live tokens, in (compact sequence, position) order; behind them S
+ *                             more entries (id 0 -> row pad_base + t): the padding rows themselves, for callers that produce them
+ *                             in the same in_proj launch (counts[4] rows)
+ *   counts   [5]              n_live + 1, (n_live + 1) S, live tokens, n_live, live tokens + S   (device memory: the m_dev /
+ *                             n_seq_dev arguments of the other entry points)
  * Ordered and deterministic (no atomics).  work: lime_compact_sequences_workspace(n_seq) int32 words.
  */
 int lime_compact_sequences(const int32_t* ids, int32_t n_seq, int32_t S, int32_t pad_base, int32_t* seq_inv, int32_t* ids_c,

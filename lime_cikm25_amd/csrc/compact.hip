@@ -15,7 +15,9 @@
 //   row_map  [(n_seq + 1) S]   compact token row -> its q/k/v row: itself when live, pad_base + t when padding
 //   tok_ids  [(n_seq + 1) S]   the live tokens' ids, compacted in (compact sequence, position) order
 //   tok_rows [(n_seq + 1) S]   the compact token row of each of them
-//   counts   [4]               n_c = n_live + 1, n_c * S, number of live tokens, n_live
+//   counts   [5]               n_c = n_live + 1, n_c * S, number of live tokens, n_live, live tokens + S
+// Behind the live tokens tok_ids / tok_rows carry S more entries (id 0 -> row pad_base + t): the padding rows themselves, so that
+// ONE in_proj launch over counts[4] rows produces the live rows and the table the row map points the padding tokens at.
 // Everything is ordered and deterministic (no atomics): a single-workgroup scan over the per-sequence counts between two
 // wide passes.
 #include "common.h"
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(1024) void seq_scan_kernel(const int* __restrict__ 
         counts[1] = (n_live + 1) * S;
         counts[2] = n_tok;
         counts[3] = n_live;
+        counts[4] = n_tok + S;
     }
 }
 
@@ -105,6 +108,10 @@ __global__ __launch_bounds__(256) void seq_emit_kernel(const int* __restrict__ i
             const int row = cs * S + t;
             ids_c[row] = id;
             row_map[row] = live ? row : pad_base + t;
+            if (cs == n_c - 1) {                       // the representative: its offset is the end of the live list
+                tok_ids[base + t] = 0;
+                tok_rows[base + t] = pad_base + t;
+            }
             if (live) {
                 const int k = base + __popcll(m & ((1ull << lane) - 1ull));
                 tok_ids[k] = id;

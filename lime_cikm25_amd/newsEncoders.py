@@ -689,12 +689,12 @@ def encode_tokens_bf16_compact(ids, table_bf16, pe, transformer, nhead, pooled_o
     b_in = ops.pad_heads(sa.in_proj_bias, 3 * nhead, hd, 32)
     pew = ops.linear(pe[:S], w_in, b_in)                                       # fp32 [S, 3W]
     qkv = torch.empty((cap + S, 3 * W), dtype=torch.bfloat16, device=dev)
-    zeros = torch.zeros(S, dtype=torch.int32, device=dev)
     if _inproj_applicable(3 * W, EP):
-        w_in_p = ops.inproj_pack_bf16(w_in, EP)
-        ops.inproj_bf16(table_bf16, w_in_p, pew, 3 * W, qkv[cap:], a_ids=zeros)
-        ops.inproj_bf16(table_bf16, w_in_p, pew, 3 * W, qkv[:cap], a_ids=cmp.tok_ids, c_ids=cmp.tok_rows, m_dev=cmp.n_live_tokens)
+        # one launch: the live tokens and, behind them in the token list, the S padding rows the row map points at
+        ops.inproj_bf16(table_bf16, ops.inproj_pack_bf16(w_in, EP), pew, 3 * W, qkv, a_ids=cmp.tok_ids, c_ids=cmp.tok_rows,
+                        m_dev=cmp.n_tokens_and_pad_rows)
     else:
+        zeros = torch.zeros(S, dtype=torch.int32, device=dev)
         w_in_b = ops.to_bf16(w_in, cols_out=EP)
         ops.linear_bf16(table_bf16, w_in_b, None, a_ids=zeros, res=pew, res_kind=1, res_mod=S, out=qkv[cap:])
         ops.linear_bf16(table_bf16, w_in_b, None, a_ids=cmp.tok_ids, res=pew, res_kind=1, res_mod=S, out=qkv[:cap], m_dev=cmp.n_live_tokens,

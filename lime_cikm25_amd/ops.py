@@ -227,6 +227,7 @@ class Compacted:
     n_compact = property(lambda self: self.counts[0:1])      # device counts as 1-element views (m_dev / n_seq_dev arguments)
     n_rows = property(lambda self: self.counts[1:2])
     n_live_tokens = property(lambda self: self.counts[2:3])
+    n_tokens_and_pad_rows = property(lambda self: self.counts[4:5])     # live tokens + the S padding-row entries behind them in tok_ids / tok_rows
 
 
 def compact_sequences(ids, pad_base=None):
@@ -240,13 +241,13 @@ def compact_sequences(ids, pad_base=None):
     c = Compacted()
     c.n_seq, c.S, c.cap = n_seq, S, cap
     dev = ids.device
-    buf = torch.empty(n_seq + 4 * cap + 4 + int(lib.lime_compact_sequences_workspace(n_seq)), dtype=torch.int32, device=dev)
+    buf = torch.empty(n_seq + 4 * cap + 8 + int(lib.lime_compact_sequences_workspace(n_seq)), dtype=torch.int32, device=dev)
     c.seq_inv = buf[:n_seq]
     o = n_seq
     c.ids_c, c.row_map, c.tok_ids, c.tok_rows = (buf[o + i * cap:o + (i + 1) * cap] for i in range(4))
     o += 4 * cap
-    c.counts = buf[o:o + 4]
-    work = buf[o + 4:]
+    c.counts = buf[o:o + 5]
+    work = buf[o + 8:]
     c.seq_src = work[n_seq:2 * n_seq + 1]          # compact -> original sequence (-1: the all-padding representative)
     check(lib.lime_compact_sequences(_p(ids), n_seq, S, cap if pad_base is None else pad_base, _p(c.seq_inv), _p(c.ids_c), _p(c.row_map),
                                      _p(c.tok_ids), _p(c.tok_rows), _p(c.counts), _p(work), _stream()), 'lime_compact_sequences')

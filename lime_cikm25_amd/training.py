@@ -372,7 +372,7 @@ def _dedup_sequences(ids):
     if not newsEncoders.DEDUP or ids.shape[0] < 64:
         return None
     cmp = ops.compact_sequences(ids)
-    n_c, _, _, n_live = (int(v) for v in cmp.counts.tolist())          # one host read per encoder call (the step is eager)
+    n_c, _, _, n_live = (int(v) for v in cmp.counts[:4].tolist())      # one host read per encoder call (the step is eager)
     if n_c >= ids.shape[0]:
         return None                                                    # nothing repeats
     return cmp, n_c, n_live

@@ -49,7 +49,10 @@ def test_compact_sequences_against_numpy(n_seq, S, p_empty):
     c = ops.compact_sequences(torch.from_numpy(ids).cuda())
     inv, ids_c, row_map, tok_ids, tok_rows, n_live = np_compact(ids)
     counts = c.counts.cpu().numpy()
-    assert counts.tolist() == [n_live + 1, (n_live + 1) * S, len(tok_ids), n_live]
+    assert counts.tolist() == [n_live + 1, (n_live + 1) * S, len(tok_ids), n_live, len(tok_ids) + S]
+    # behind the live tokens: the S padding rows themselves (id 0 -> row pad_base + t)
+    assert (c.tok_ids.cpu().numpy()[len(tok_ids):len(tok_ids) + S] == 0).all()
+    assert np.array_equal(c.tok_rows.cpu().numpy()[len(tok_ids):len(tok_ids) + S], c.cap + np.arange(S))
     assert np.array_equal(c.seq_inv.cpu().numpy(), inv)
     n = (n_live + 1) * S
     assert np.array_equal(c.ids_c.cpu().numpy()[:n], ids_c.reshape(-1))
