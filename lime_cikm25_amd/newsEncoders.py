@@ -670,7 +670,7 @@ def encode_tokens_bf16(ids, table_bf16, pe, transformer, nhead, pooled_out):
     return ops.mean_pool_bf16(x, M, S, E, out=pooled_out)
 
 
-def encode_tokens_bf16_compact(ids, table_bf16, pe, transformer, nhead, pooled_out):
+def encode_tokens_bf16_compact(ids, table_bf16, pe, transformer, nhead, pooled_out, shared=None):
     """``encode_tokens_bf16`` on the compacted batch (see ``encode_tokens_compact``): live sequences + one all-padding
     representative through the layer, in_proj over the live tokens, the row-map bf16 attention.  The S padding rows come from
     the same bf16 GEMM kernel as the live rows (lime_linear_bf16 takes any M)."""
@@ -685,12 +685,35 @@ def encode_tokens_bf16_compact(ids, table_bf16, pe, transformer, nhead, pooled_o
     cap = (M + 1) * S
     padv = lambda v: torch.cat([v, v.new_zeros(EP - E)])
     cmp = ops.compact_sequences(ids)
-    w_in = ops.pad_heads(sa.in_proj_weight, 3 * nhead, hd, 32)
-    b_in = ops.pad_heads(sa.in_proj_bias, 3 * nhead, hd, 32)
-    pew = ops.linear(pe[:S], w_in, b_in)                                       # fp32 [S, 3W]
+    fused = FUSED_BLOCK and _ffn_fused_applicable(layer, E, EP) and E % 4 == 0 and _inproj_applicable(3 * W, EP)
+    if fused and shared is not None and 'w_in_p' in shared:
+        # the passes of one forward over the same encoder share the packed weights (`shared`: a dict that lives for one forward)
+        w_in_p, pew, w0p, w1p, w2p, add_rows = (shared[k] for k in ('w_in_p', 'pew', 'w0p', 'w1p', 'w2p', 'add_rows'))
+    else:
+        w_in = ops.pad_heads(sa.in_proj_weight, 3 * nhead, hd, 32)
+        b_in = ops.pad_heads(sa.in_proj_bias, 3 * nhead, hd, 32)
+        pew = ops.linear(pe[:S], w_in, b_in)                                   # fp32 [S, 3W]
+        if fused:
+            w_in_p = ops.inproj_pack_bf16(w_in, EP)
+            w1p, w2p = ops.ffn_pack_bf16(layer.linear1.weight, layer.linear1.bias, layer.linear2.weight)
+            w0p, add_rows = ops.oproj_pack_bf16(sa.out_proj.weight), pe[:S] + sa.out_proj.bias
+            if shared is not None:
+                shared.update(w_in_p=w_in_p, pew=pew, w0p=w0p, w1p=w1p, w2p=w2p, add_rows=add_rows)
     qkv = torch.empty((cap + S, 3 * W), dtype=torch.bfloat16, device=dev)
+    if fused:
+        # three launches: in_proj (the live tokens and, behind them in the token list, the S padding rows the row map points at),
+        # attention, and everything behind it
+        ops.inproj_bf16(table_bf16, w_in_p, pew, 3 * W, qkv, a_ids=cmp.tok_ids, c_ids=cmp.tok_rows, m_dev=cmp.n_tokens_and_pad_rows)
+        attn = ops.token_attention_rows_bf16(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], cmp.row_map, cmp.n_compact, M + 1, S, nhead, hd,
+                                             1.0 / math.sqrt(hd), out_cols=EP)
+        blocks = ops.encoder_block_bf16(attn, w0p, add_rows, (layer.norm1.weight, layer.norm1.bias), layer.norm1.eps, res=table_bf16,
+                                        res_kind=2, res_ids=cmp.ids_c, w1p=w1p, w2p=w2p, b2=layer.linear2.bias,
+                                        ln2=(layer.norm2.weight, layer.norm2.bias), ln2_eps=layer.norm2.eps, E=E, pool32=True,
+                                        m_dev=cmp.n_rows)                       # fp32 [cap / 32, EP] block means
+        pooled_c = ops.mean_pool(blocks[:, :E], M + 1, S // 32)
+        ops.gather_rows(cmp.seq_inv, pooled_c, pooled_out)
+        return None
     if _inproj_applicable(3 * W, EP):
-        # one launch: the live tokens and, behind them in the token list, the S padding rows the row map points at
         ops.inproj_bf16(table_bf16, ops.inproj_pack_bf16(w_in, EP), pew, 3 * W, qkv, a_ids=cmp.tok_ids, c_ids=cmp.tok_rows,
                         m_dev=cmp.n_tokens_and_pad_rows)
     else:
@@ -850,11 +873,15 @@ class CROWN(NewsEncoder):
             for half, (ids, pos, tr, S) in enumerate(encoders):
                 step = step_of(S)
                 with torch.cuda.stream(side if half == 0 else main):
+                    shared = {}                                # packed weights of this encoder, for the passes of this forward
                     for m0 in range(0, M, step):
                         m1 = min(M, m0 + step)
                         if bf16:
-                            enc_b = encode_tokens_bf16_compact if compact_applicable_bf16(ids[m0:m1], tr, self.head_num, E) else encode_tokens_bf16
-                            enc_b(ids[m0:m1], table_b, pos.table(), tr, self.head_num, xin[half * M + m0:half * M + m1, :E])
+                            if compact_applicable_bf16(ids[m0:m1], tr, self.head_num, E):
+                                encode_tokens_bf16_compact(ids[m0:m1], table_b, pos.table(), tr, self.head_num,
+                                                           xin[half * M + m0:half * M + m1, :E], shared=shared)
+                            else:
+                                encode_tokens_bf16(ids[m0:m1], table_b, pos.table(), tr, self.head_num, xin[half * M + m0:half * M + m1, :E])
                             continue
                         if compact_applicable(ids[m0:m1], table, tr, self.head_num):
                             encode_tokens_compact(ids[m0:m1], table, pos.table(), tr, self.head_num,

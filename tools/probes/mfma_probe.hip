@@ -116,6 +116,37 @@ __global__ __launch_bounds__(256) void k_rand_bf16(float* out, const float* rnd,
     for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+// V4b: the two 16x16 bf16 shapes: v_mfma_f32_16x16x16_bf16 (4 bf16 per lane and operand: what ONE b128 fragment of a 16-deep fp32
+// chunk splits into) and v_mfma_f32_16x16x32_bf16 (8 per lane) -- is the k = 16 form issued at the k = 32 form's FLOP rate?
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <int K32>
+__global__ __launch_bounds__(256) void k_rand_bf16_16(float* out, const float* rnd, int iters) {
+    f32x4 acc[16];
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 a[4], b[4];
+    for (int u = 0; u < 4; ++u)
+        for (int e = 0; e < 8; ++e) {
+            a[u][e] = (__bf16)rnd[(threadIdx.x * 64 + u * 8 + e) & 4095];
+            b[u][e] = (__bf16)rnd[(threadIdx.x * 64 + 32 + u * 8 + e) & 4095];
+        }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (K32) {
+                    acc[4 * u + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b[i], acc[4 * u + i], 0, 0, 0);
+                } else {
+                    const bf16x4 a4 = {a[u][0], a[u][1], a[u][2], a[u][3]}, b4 = {b[i][0], b[i][1], b[i][2], b[i][3]};
+                    acc[4 * u + i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a4), __builtin_bit_cast(s16x4, b4), acc[4 * u + i], 0, 0, 0);
+                }
+            }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) for (int r = 0; r < 4; ++r) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
 // V5: 16x16x4 fp32 with random operands (is the small tile cheaper or dearer in power?)
 __global__ __launch_bounds__(256) void k_rand16(float* out, const float* rnd, int iters) {
     f32x4 acc[8];
@@ -182,6 +213,15 @@ int main() {
                 printf("rand32 %s reps=%3d: %.2f TF   %.0f s_memtime cycles per wave loop, %.1f us per launch\n", zero ? "zeros " : "random", reps,
                        (double)blocks * 4 * it2 * 32 * 4096 / t / 1e12, mean, t * 1e6);
             }
+        }
+        {
+            const int blocks = 1024, it2 = 4000;
+            double t = time_it([&] { hipLaunchKernelGGL(k_rand_bf16_16<0>, dim3(blocks), dim3(256), 0, 0, out, rnd, it2); }, 100);
+            printf("bf16 16x16x16 random sustained: %.1f TF  (%.1f cycles per MFMA at 2.4 GHz)\n", (double)blocks * 4 * it2 * 16 * 8192 / t / 1e12,
+                   t * 2.4e9 / ((double)blocks / 256 * it2 * 16));
+            t = time_it([&] { hipLaunchKernelGGL(k_rand_bf16_16<1>, dim3(blocks), dim3(256), 0, 0, out, rnd, it2); }, 100);
+            printf("bf16 16x16x32 random sustained: %.1f TF  (%.1f cycles per MFMA at 2.4 GHz)\n", (double)blocks * 4 * it2 * 16 * 16384 / t / 1e12,
+                   t * 2.4e9 / ((double)blocks / 256 * it2 * 16));
         }
         for (int zero = 1; zero >= 0; --zero) {
             const int blocks = 1024, it2 = 4000;
