@@ -76,11 +76,10 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, float* lds_base,
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // bf16 <-> fp32 (round to nearest even; inputs are finite on this path)
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-    unsigned a = __builtin_bit_cast(unsigned, lo), b = __builtin_bit_cast(unsigned, hi);
-    a += 0x7FFFu + ((a >> 16) & 1u);
-    b += 0x7FFFu + ((b >> 16) & 1u);
-    return (a >> 16) | (b & 0xFFFF0000u);
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {       // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 __device__ __forceinline__ f32x4 unpack_bf16x4(u32x2 v) {
     f32x4 r;

@@ -32,11 +32,10 @@ struct AttnB {
     const int* n_seq_dev;    // MAP: optional device-side sequence count
 };
 
-__device__ __forceinline__ unsigned pack2(float lo, float hi) {          // two floats -> two bf16 (round to nearest even)
-    unsigned a = __builtin_bit_cast(unsigned, lo), b = __builtin_bit_cast(unsigned, hi);
-    a += 0x7FFFu + ((a >> 16) & 1u);
-    b += 0x7FFFu + ((b >> 16) & 1u);
-    return (a >> 16) | (b & 0xFFFF0000u);
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {          // two floats -> two bf16 (round to nearest even): one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 
 template <int NT, bool MAP = false>
