@@ -1,4 +1,4 @@
-// lime_encoder_ffn_bf16: the feed-forward half of a TransformerEncoderLayer (newsEncoders.py:244-247, 316-321 --
+// lime_encoder_ffn_bf16 / lime_encoder_block_bf16: the feed-forward half of a TransformerEncoderLayer (newsEncoders.py:244-247, 316-321 --
 // linear1, ReLU, linear2, residual, norm2, and the token mean pooling behind the last layer) in ONE launch on the bf16
 // matrix cores.  The 512-wide hidden state never leaves the registers, the layer input is read from HBM once.
 //
@@ -19,6 +19,12 @@
 //   * residual (the stationary tile), LayerNorm and the 32-token block means are the fp32 epilogue; with `pool32` only
 //     [M / 32, 304] floats are written.
 // Tokens of a wave never meet another wave's: the stationary image needs no barrier, only the weight ring does (one per step).
+//
+// lime_encoder_block_bf16 (the OPROJ instantiations) puts out_proj + residual + norm1 in front: the image first holds the
+// attention output of the tile; ten more steps stream out_proj's weight; behind each of them the residual rows (word rows by
+// id, or the layer input) follow the attention output into the SAME image chunk by chunk; the epilogue adds them and the fp32
+// add_rows (bias + positional rows, fetched two steps ahead), applies LayerNorm and writes the bf16 result back over the image:
+// the feed-forward half's input and residual, which therefore never exists in HBM.
 #include <type_traits>
 
 #include "lds_dma.h"
