@@ -80,6 +80,18 @@ def _side_stream(device, which=0):
     return _SIDE[key]
 
 
+_ZERO_IDS = {}
+
+
+def _zero_ids(n, device):
+    """n zero word ids (the padding word), allocated once per device and never written: a forward does not pay a fill launch for them."""
+    key = (device.type, device.index)
+    z = _ZERO_IDS.get(key)
+    if z is None or z.numel() < n:
+        z = _ZERO_IDS[key] = torch.zeros(max(n, 512), dtype=torch.int32, device=device)
+    return z[:n]
+
+
 def _cat_rows(ts):
     """torch.cat(ts, dim=0) -- as a VIEW when the pieces already sit back to back in one storage (the Model's packed
     graph inputs are laid out that way), so the per-forward concatenation of candidates and history costs no kernel."""
@@ -537,8 +549,7 @@ def compact_prepare(ids, table, pe, transformer, nhead):
     b_in = ops.pad_heads(sa.in_proj_bias, 3 * nhead, hd, 32)
     pew = ops.linear(pe[:S], w_in, b_in)                                       # [S, 3W]: positional term + bias
     qkv = torch.empty((cap + S, 3 * W), dtype=torch.float32, device=ids.device)
-    zeros = torch.zeros(S, dtype=torch.int32, device=ids.device)
-    ops.linear(table, w_in, None, a_ids=zeros, res=pew, res_mod=S, out=qkv[cap:])                     # the S padding rows
+    ops.linear(table, w_in, None, a_ids=_zero_ids(S, ids.device), res=pew, res_mod=S, out=qkv[cap:])   # the S padding rows
     return cmp, w_in, pew, qkv
 
 
@@ -717,7 +728,7 @@ def encode_tokens_bf16_compact(ids, table_bf16, pe, transformer, nhead, pooled_o
         ops.inproj_bf16(table_bf16, ops.inproj_pack_bf16(w_in, EP), pew, 3 * W, qkv, a_ids=cmp.tok_ids, c_ids=cmp.tok_rows,
                         m_dev=cmp.n_tokens_and_pad_rows)
     else:
-        zeros = torch.zeros(S, dtype=torch.int32, device=dev)
+        zeros = _zero_ids(S, dev)
         w_in_b = ops.to_bf16(w_in, cols_out=EP)
         ops.linear_bf16(table_bf16, w_in_b, None, a_ids=zeros, res=pew, res_kind=1, res_mod=S, out=qkv[cap:])
         ops.linear_bf16(table_bf16, w_in_b, None, a_ids=cmp.tok_ids, res=pew, res_kind=1, res_mod=S, out=qkv[:cap], m_dev=cmp.n_live_tokens,
