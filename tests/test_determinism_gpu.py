@@ -54,3 +54,41 @@ def test_training_step_is_bitwise_reproducible():
         flats.append(ts.flat.clone())
     assert losses[:3] == losses[3:]
     assert torch.equal(flats[0], flats[1])
+
+
+def test_bf16_encoder_kernels_repeat_bit_for_bit():
+    """The LDS-DMA ring kernels of the bf16 layer (counted vmcnt waits, slots refilled behind barriers, image chunks refilled behind
+    the steps that read them) launched 40 times on the same inputs, other work in between: every output must come back with the
+    same bits -- a slot or an image chunk read before it has landed would show here."""
+    V, E, EP, F, S, M = 3000, 300, 304, 512, 128, 33 * 1024
+    g = torch.Generator(device='cuda').manual_seed(3)
+    rnd = lambda *s, sc=1.0: (torch.rand(*s, generator=g, device='cuda') * 2 - 1) * sc
+    table = torch.zeros(V, EP, dtype=torch.bfloat16, device='cuda')
+    table[:, :E] = rnd(V, E).to(torch.bfloat16)
+    ids = torch.randint(0, V, (M,), generator=g, device='cuda', dtype=torch.int32)
+    live = M * 5 // 8
+    rows = torch.sort(torch.randperm(M, generator=g, device='cuda')[:live]).values.to(torch.int32)
+    w_in, pew = rnd(960, E, sc=0.06), rnd(S, 960)
+    attn = torch.zeros(M, EP, dtype=torch.bfloat16, device='cuda')
+    attn[:, :E] = rnd(M, E).to(torch.bfloat16)
+    w0, w1, b1, w2, b2 = rnd(E, E, sc=0.06), rnd(F, E, sc=0.06), rnd(F), rnd(E, F, sc=0.05), rnd(E)
+    g1, be1, g2, be2, add = rnd(E) + 1.5, rnd(E), rnd(E) + 1.5, rnd(E), rnd(S, E)
+    w_in_p, w0p = ops.inproj_pack_bf16(w_in, EP), ops.oproj_pack_bf16(w0)
+    w1p, w2p = ops.ffn_pack_bf16(w1, b1, w2)
+    scratch = torch.empty(64 << 20, dtype=torch.uint8, device='cuda')
+
+    def run():
+        qkv = torch.zeros((M, 960), dtype=torch.bfloat16, device='cuda')
+        ops.inproj_bf16(table, w_in_p, pew, 960, qkv, a_ids=ids[:live], c_ids=rows)
+        blk = ops.encoder_block_bf16(attn, w0p, add, (g1, be1), 1e-5, res=table, res_kind=2, res_ids=ids, w1p=w1p, w2p=w2p, b2=b2,
+                                     ln2=(g2, be2), ln2_eps=1e-5, E=E, pool32=True)
+        ffn = ops.encoder_ffn_bf16(attn, w1p, w2p, b2, (g2, be2), 1e-5, E)
+        return qkv, blk, ffn
+
+    first = run()
+    for it in range(40):
+        scratch.random_(0, 255)                     # other kernels in between: cache contents and clocks differ from launch to launch
+        again = run()
+        for name, a, b in zip(('in_proj', 'block', 'feed-forward'), first, again):
+            assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a.view(torch.int32),
+                               b.view(torch.int16) if b.dtype == torch.bfloat16 else b.view(torch.int32)), '%s, launch %d' % (name, it)
