@@ -650,13 +650,27 @@ int lime_linear_pp(const lime_linear_args* a, hipStream_t s) {
     if (res == 2) return LIME_PP_NOT_APPLICABLE;
     // the tile width (256 / 320) that pads N least
     const int pad5 = (a->N + 319) / 320 * 320 - a->N, pad4 = (a->N + 255) / 256 * 256 - a->N;
-    if (!tail_ok(pad5 < pad4 ? 320 : 256)) return LIME_PP_NOT_APPLICABLE;
-    if (pad5 < pad4) {
-        if (res == 1) return launch<10, false, false, 1>(p, s);
-        return relu ? launch<10, false, true, 0>(p, s) : launch<10, false, false, 0>(p, s);
+    if (tail_ok(pad5 < pad4 ? 320 : 256)) {
+        if (pad5 < pad4) {
+            if (res == 1) return launch<10, false, false, 1>(p, s);
+            return relu ? launch<10, false, true, 0>(p, s) : launch<10, false, false, 0>(p, s);
+        }
+        if (res == 1) return launch<8, false, false, 1>(p, s);
+        return relu ? launch<8, false, true, 0>(p, s) : launch<8, false, false, 0>(p, s);
     }
-    if (res == 1) return launch<8, false, false, 1>(p, s);
-    return relu ? launch<8, false, true, 0>(p, s) : launch<8, false, false, 0>(p, s);
+    // N whose last 256 / 320-column block would be too narrow (N = 400, 1200, 200 of the layers around the encoders at large
+    // batch): 19-tile (304) or 13-tile (208) slabs of the same loaders -- the trimmed tiles are simply not computed
+    const int pad304 = (a->N + 303) / 304 * 304 - a->N, pad208 = (a->N + 207) / 208 * 208 - a->N;
+    const bool ok304 = tail_ok(304), ok208 = tail_ok(208);
+    if (ok304 && (!ok208 || pad304 <= pad208)) {
+        if (res == 1) return launch<10, false, false, 1, false, false, false, false, 1>(p, s);
+        return relu ? launch<10, false, true, 0, false, false, false, false, 1>(p, s) : launch<10, false, false, 0, false, false, false, false, 1>(p, s);
+    }
+    if (ok208) {
+        if (res == 1) return launch<8, false, false, 1, false, false, false, false, 3>(p, s);
+        return relu ? launch<8, false, true, 0, false, false, false, false, 3>(p, s) : launch<8, false, false, 0, false, false, false, false, 3>(p, s);
+    }
+    return LIME_PP_NOT_APPLICABLE;
 }
 
 // ---- bf16 operands (BASELINE config 3: bf16 MFMA, fp32 accumulate / LayerNorm) ------------------------------------------

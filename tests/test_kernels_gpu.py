@@ -145,6 +145,27 @@ def test_linear_pp_plain(ops, M, N, K, act):
     check(got2, torch.relu(a @ w.t()) if act == 'relu' else a @ w.t(), what='pp linear, no bias')
 
 
+@pytest.mark.parametrize('M,N,K,width', [(5000, 400, 400, 208), (4500, 1200, 352, 304), (4096, 160, 400, 208), (6001, 400, 900, 208),
+                                         (4200, 860, 64, 304), (4100, 560, 300, 304), (70400, 400, 400, 208)])
+def test_linear_pp_trimmed_slabs(ops, M, N, K, width):
+    """N whose last 256 / 320-column block would be too narrow runs on 19-tile (304) / 13-tile (208) slabs of the big-M kernel:
+    plain, ReLU and dense-residual epilogues, the columns behind N untouched."""
+    a, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3), rnd(M, N, seed=4)
+    trim = {304: ', 1>', 208: ', 3>'}[width]
+    for act in (None, 'relu'):
+        want = a @ w.t() + b
+        got = ops.linear(dev(a), dev(w), dev(b), act=act)
+        assert last_kernel().startswith('gemm_pp_kernel') and last_kernel().endswith(trim), last_kernel()
+        check(got, torch.relu(want) if act == 'relu' else want, what='pp trimmed %s' % ((M, N, K, act),))
+    got = ops.linear(dev(a), dev(w), None, res=dev(r))
+    assert last_kernel().startswith('gemm_pp_kernel') and last_kernel().endswith(trim), last_kernel()
+    check(got, r + a @ w.t(), what='pp trimmed + residual')
+    big = torch.full((M, N + 24), 7.0, device='cuda')
+    ops.linear(dev(a), dev(w), dev(b), out=big[:, :N])
+    assert (big[:, N:] == 7.0).all()
+    check(big[:, :N], a @ w.t() + b, what='pp trimmed, strided out')
+
+
 @pytest.mark.parametrize('M,N,K', [(4096, 300, 300), (5001, 300, 512), (4500, 320, 64), (4100, 288, 300), (9000, 260, 100)])
 def test_linear_pp_residual_layernorm(ops, M, N, K):
     a, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3), rnd(M, N, seed=4)
