@@ -420,6 +420,18 @@ int lime_lifetime_score_f32(const float* user, const float* news, const float* r
 /* lime_row_scale_f32: out[r, :] = scale[r] * x[r, :]   (layers.py:84 when use_residual_connection is off) */
 int lime_row_scale_f32(const float* x, const float* scale, float* out, int64_t rows, int32_t D, void* stream);
 
+/*
+ * The masked title encoder (newsEncoders.py:566-595, LIME-MHSA-CROWN) on a compacted batch.  lime_mhsa_live_ids: ids_eff = ids with
+ * -1 in the first position of every all-zero sequence whose key mask is NOT the padding news' mask (first position set,
+ * corpus.py:476-477): such a sequence must be encoded, and the sentinel makes lime_compact_sequences count it as live.
+ * lime_mhsa_compact_mask: behind lime_compact_sequences -- ids_c[e] = max(ids_c[e], 0) (the sentinel back to the padding word) and
+ * mask_c[cs, t] = mask[seq_src[cs], t] (a compact slot without a source sequence gets the padding news' mask); n_compact_slots =
+ * n_seq + 1.  mask / mask_c: uint8, non-zero = attend.
+ */
+int lime_mhsa_live_ids(const int32_t* ids, const uint8_t* mask, int32_t n_seq, int32_t T, int32_t* ids_eff, void* stream);
+int lime_mhsa_compact_mask(int32_t* ids_c, const int32_t* seq_src, const uint8_t* mask, int32_t n_compact_slots, int32_t T,
+                           uint8_t* mask_c, void* stream);
+
 /* lime_fuse_rows_f32: LIME's fusion_method 'add' (gate == NULL: out = a + b) and 'gated' (out = gate * a + (1 - gate) * b),
  * newsEncoders.py:154-159; [rows, cols] matrices with leading dimensions. */
 int lime_fuse_rows_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* gate, int64_t ldg, float* out, int64_t ldo,

@@ -121,6 +121,41 @@ __global__ __launch_bounds__(256) void bucketize_kernel(const float* __restrict_
     }
 }
 
+// The masked title encoder (newsEncoders.py:566-595) on a compacted batch: a sequence repeats the all-padding representative when its
+// ids are all zero AND its mask is the padding news' mask (first position set, corpus.py:476-477); an all-zero sequence under any
+// other mask must be encoded -- it gets a sentinel (-1) in its first id so that lime_compact_sequences counts it as live.
+// One wave per sequence.
+__global__ __launch_bounds__(256) void mhsa_live_ids_kernel(const int* __restrict__ ids, const unsigned char* __restrict__ mask, int n, int T,
+                                                             int* __restrict__ ids_eff) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n) return;
+    bool allz = true, padmask = true;
+    for (int t = lane; t < T; t += 64) {
+        allz = allz && ids[(long)s * T + t] == 0;
+        padmask = padmask && ((mask[(long)s * T + t] != 0) == (t == 0));
+    }
+    const bool odd = (__ballot(!allz) == 0ull) && (__ballot(!padmask) != 0ull);
+    for (int t = lane; t < T; t += 64) {
+        const int id = ids[(long)s * T + t];
+        ids_eff[(long)s * T + t] = (t == 0 && odd) ? -1 : id;
+    }
+}
+// ... and behind the compaction: the sentinel back to the padding word, the key mask in compact order (a compact slot without a
+// source sequence -- the representative, unused slots -- carries the padding news' mask)
+__global__ __launch_bounds__(256) void mhsa_compact_mask_kernel(int* __restrict__ ids_c, const int* __restrict__ seq_src,
+                                                                 const unsigned char* __restrict__ mask, long total, int T,
+                                                                 unsigned char* __restrict__ mask_c) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long cs = e / T;
+        const int t = (int)(e - cs * T);
+        const int src = seq_src[cs];
+        mask_c[e] = src < 0 ? (unsigned char)(t == 0) : (unsigned char)(mask[(long)src * T + t] != 0);
+        const int id = ids_c[e];
+        if (id < 0) ids_c[e] = 0;
+    }
+}
+
 // LIME's 'add' / 'gated' fusion (newsEncoders.py:154-159): out = a + b, or gate * a + (1 - gate) * b
 __global__ __launch_bounds__(256) void fuse_rows_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
                                                          const float* __restrict__ gate, long ldg, float* __restrict__ out, long ldo,
@@ -744,6 +779,24 @@ extern "C" int lime_bucketize_f32(const float* x, int32_t* out, int64_t n, void*
     if (n == 0) return LIME_OK;
     hipLaunchKernelGGL(bucketize_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, out, (long)n);
     return lime_check_launch("lime_bucketize_f32");
+}
+
+extern "C" int lime_mhsa_live_ids(const int32_t* ids, const uint8_t* mask, int32_t n_seq, int32_t T, int32_t* ids_eff, void* stream) {
+    LIME_REQUIRE(ids && mask && ids_eff, LIME_ERR_BAD_ARG, "lime_mhsa_live_ids: NULL pointer");
+    LIME_REQUIRE(n_seq >= 0 && T > 0, LIME_ERR_BAD_ARG, "lime_mhsa_live_ids: bad dims");
+    if (n_seq == 0) return LIME_OK;
+    hipLaunchKernelGGL(mhsa_live_ids_kernel, dim3((unsigned)((n_seq + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ids, mask, n_seq, T, ids_eff);
+    return lime_check_launch("lime_mhsa_live_ids");
+}
+
+extern "C" int lime_mhsa_compact_mask(int32_t* ids_c, const int32_t* seq_src, const uint8_t* mask, int32_t n_compact_slots, int32_t T,
+                                      uint8_t* mask_c, void* stream) {
+    LIME_REQUIRE(ids_c && seq_src && mask && mask_c, LIME_ERR_BAD_ARG, "lime_mhsa_compact_mask: NULL pointer");
+    LIME_REQUIRE(n_compact_slots >= 0 && T > 0, LIME_ERR_BAD_ARG, "lime_mhsa_compact_mask: bad dims");
+    const long total = (long)n_compact_slots * T;
+    if (total == 0) return LIME_OK;
+    hipLaunchKernelGGL(mhsa_compact_mask_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, ids_c, seq_src, mask, total, T, mask_c);
+    return lime_check_launch("lime_mhsa_compact_mask");
 }
 
 extern "C" int lime_fuse_rows_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* gate, int64_t ldg, float* out,

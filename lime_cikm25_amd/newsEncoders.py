@@ -932,15 +932,14 @@ class MHSA(NewsEncoder):
         n, T = ids.shape
         mha = self.multiheadAttention
         dev = ids.device
-        e0 = torch.arange(T, device=dev) == 0                                     # the padding news' mask (no host scalar: graph capture)
-        mask = mask.bool()
-        odd = (ids == 0).all(dim=1) & ~(mask == e0).all(dim=1)                   # all-zero ids under a different mask: live
-        ids_eff = ids.clone()
-        ids_eff[:, 0] = torch.where(odd, torch.full_like(ids[:, 0], -1), ids[:, 0])            # a sentinel makes them count as live
-        cmp = ops.compact_sequences(ids_eff)
-        ids_c = cmp.ids_c.clamp(min=0)                                           # the sentinel back to the padding word
-        src = cmp.seq_src.long()                                                 # compact -> original sequence, -1: no source
-        mask_c = torch.where((src < 0).unsqueeze(1), e0.unsqueeze(0), mask[src.clamp(min=0)]).contiguous()
+        if mask.dtype not in (torch.bool, torch.uint8):
+            mask = mask.bool()
+        mask = mask.contiguous()
+        # all-zero ids under a mask that is not the padding news' mask: live (a sentinel in the first id); behind the compaction the
+        # sentinel goes back to the padding word and the key mask is gathered into compact order -- two launches (they were ~18 torch ops)
+        cmp = ops.compact_sequences(ops.mhsa_live_ids(ids, mask))
+        mask_c = ops.mhsa_compact_mask(cmp, mask)
+        ids_c = cmp.ids_c
         qkv = mha.project(table=self.word_embedding.weight, ids=ids_c, m_dev=cmp.n_rows)
         c = mha.attend(qkv, n + 1, T, mask_c, n_seq_dev=cmp.n_compact)
         hidden = ops.linear(c, self.attention.affine1.weight, self.attention.affine1.bias, act='tanh', m_dev=cmp.n_rows)

@@ -295,6 +295,25 @@ def bucketize(x, cuts=None):
     return out
 
 
+def mhsa_live_ids(ids, mask):
+    """``lime_mhsa_live_ids``: ids int32 [n, T], mask bool/uint8 [n, T] -> ids with the -1 sentinel of all-zero sequences that must be encoded."""
+    lib = _lib.load()
+    n, T = ids.shape
+    m = _mask_u8(mask, 'mask')
+    out = torch.empty_like(ids)
+    check(lib.lime_mhsa_live_ids(_p(ids), _p(m), n, T, _p(out), _stream()), 'lime_mhsa_live_ids')
+    return out
+
+
+def mhsa_compact_mask(cmp, mask):
+    """``lime_mhsa_compact_mask``: clamps ``cmp.ids_c`` in place and returns the key mask in compact order, uint8 [(n_seq + 1), S]."""
+    lib = _lib.load()
+    m = _mask_u8(mask, 'mask')
+    mask_c = torch.empty((cmp.n_seq + 1, cmp.S), dtype=torch.uint8, device=cmp.ids_c.device)
+    check(lib.lime_mhsa_compact_mask(_p(cmp.ids_c), _p(cmp.seq_src), _p(m), cmp.n_seq + 1, cmp.S, _p(mask_c), _stream()), 'lime_mhsa_compact_mask')
+    return mask_c
+
+
 def fuse_rows(a, b, gate=None, out=None):
     """LIME's 'add' / 'gated' fusion (newsEncoders.py:154-159): a + b, or gate * a + (1 - gate) * b; [rows, cols] matrices."""
     lib = _lib.load()

@@ -218,3 +218,36 @@ def test_mhsa_model_with_and_without_dedup(monkeypatch):
     want = O.model_forward(sd, cfg, batch)
     print('MHSA dedup vs dense %.2e, vs oracle %.2e' % (e, rel_err(got.numpy(), want.numpy())))
     assert torch.isfinite(got).all() and e < 2e-6 and rel_err(got.numpy(), want.numpy()) < 1e-3
+
+
+@pytest.mark.parametrize('n,T', [(300, 32), (65, 20), (7, 130)])
+def test_mhsa_compaction_helpers_against_torch(n, T):
+    """lime_mhsa_live_ids / lime_mhsa_compact_mask against the tensor formulation they replace: the -1 sentinel of all-zero sequences
+    under a mask that is not the padding news' mask, the clamped compact ids and the key mask in compact order."""
+    g = torch.Generator().manual_seed(n + T)
+    ids = torch.randint(1, 50, (n, T), generator=g, dtype=torch.int32)
+    mask = torch.rand(n, T, generator=g) < 0.7
+    kind = torch.randint(0, 4, (n,), generator=g)
+    e0 = torch.arange(T) == 0
+    for s in range(n):
+        if kind[s] == 0:                    # the padding news: zero ids, first position set
+            ids[s] = 0
+            mask[s] = e0
+        elif kind[s] == 1:                  # zero ids under another mask: must stay live
+            ids[s] = 0
+            mask[s, 0] = False if T > 1 else True
+            mask[s, -1] = True
+    ids_d, mask_d = ids.cuda(), mask.cuda()
+    odd = (ids == 0).all(dim=1) & ~(mask == e0).all(dim=1)
+    want_eff = ids.clone()
+    want_eff[:, 0] = torch.where(odd, torch.full_like(ids[:, 0], -1), ids[:, 0])
+    eff = ops.mhsa_live_ids(ids_d, mask_d)
+    assert torch.equal(eff.cpu(), want_eff)
+    c = ops.compact_sequences(eff)
+    want_ids_c = c.ids_c.clone().clamp(min=0)
+    src = c.seq_src.long().cpu()
+    want_mask = torch.where((src < 0).unsqueeze(1), e0.unsqueeze(0), mask[src.clamp(min=0)])
+    mask_c = ops.mhsa_compact_mask(c, mask_d)
+    n_c = int(c.counts[0])
+    assert torch.equal(c.ids_c.cpu()[:n_c * T], want_ids_c.cpu()[:n_c * T]) and int(c.ids_c.min()) >= 0
+    assert torch.equal(mask_c.cpu().bool(), want_mask)
