@@ -1,6 +1,7 @@
 """Build liblime_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-The library is rebuilt when the CONTENT of its sources changes: a sha256 over every file under csrc/, include/lime_hip.h and
+One object file per translation unit (build/obj, up to 7 hipcc processes at once; a unit is recompiled when its own text, a
+csrc header or the flags changed), then one link.  The library is rebuilt when the CONTENT of its sources changes: a sha256 over every file under csrc/, include/lime_hip.h and
 the compiler flags is stored beside the binary (liblime_hip.so.sha256, which travels with it); file times play no part, so a
 stale-but-newer binary is never reused.  ``build_library`` reports which of the two happened."""
 import glob
@@ -13,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB = os.path.join(_HERE, 'liblime_hip.so')
 STAMP = LIB + '.sha256'
+OBJ_DIR = os.path.join(_HERE, '..', 'build', 'obj')
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared']
 LAST_ACTION = None            # 'compiled' | 'reused' after build_library()
 
@@ -39,6 +41,68 @@ def _stamp():
         return None
 
 
+def _object_key(src, extra_flags=()):
+    """sha256 of one translation unit's inputs: its own text, every csrc/*.h, include/lime_hip.h, the flags."""
+    h = hashlib.sha256(' '.join(list(FLAGS) + list(extra_flags)).encode())
+    for d in [src] + sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(_HERE, '..', 'include', 'lime_hip.h')]:
+        h.update(os.path.basename(d).encode() + b'\0')
+        with open(d, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def compile_objects(verbose=False, jobs=None):
+    """One object per source under build/obj (git-ignored, never shipped), recompiled only when that unit's inputs changed;
+    up to `jobs` hipcc processes at once.  Returns the object paths in source order."""
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        raise RuntimeError('hipcc not found: cannot build the HIP extension')
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    cflags = [f for f in FLAGS if f != '-shared']
+    todo, objs = [], []
+    for src in sources():
+        stem = os.path.splitext(os.path.basename(src))[0]
+        obj, key = os.path.join(OBJ_DIR, stem + '.o'), _object_key(src)
+        objs.append(obj)
+        try:
+            fresh = os.path.exists(obj) and open(obj + '.key').read().strip() == key
+        except OSError:
+            fresh = False
+        if not fresh:
+            todo.append((src, obj, key))
+    jobs = jobs or max(1, min(len(todo), (os.cpu_count() or 2) - 1, 7))
+    running = []
+
+    def reap(block):
+        for item in list(running):
+            proc, src, obj, key = item
+            if block or proc.poll() is not None:
+                if proc.wait() != 0:
+                    for other in running:
+                        if other[0].poll() is None:
+                            other[0].kill()
+                    raise RuntimeError('hipcc failed on %s' % os.path.basename(src))
+                with open(obj + '.key', 'w') as f:
+                    f.write(key + '\n')
+                running.remove(item)
+                if block:
+                    return
+
+    # longest units first, so the tail of the schedule is short
+    for src, obj, key in sorted(todo, key=lambda t: -os.path.getsize(t[0])):
+        while len(running) >= jobs:
+            reap(False)
+            if len(running) >= jobs:
+                reap(True)
+        cmd = [hipcc] + cflags + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        running.append((subprocess.Popen(cmd, cwd=CSRC), src, obj, key))
+    while running:
+        reap(True)
+    return objs, len(todo)
+
+
 def build_library(force=False, verbose=False):
     """Compile every HIP source into lime_cikm25_amd/liblime_hip.so; returns the path.  Sets LAST_ACTION and prints one line
     saying whether the library was compiled or reused, with the source hash."""
@@ -48,10 +112,11 @@ def build_library(force=False, verbose=False):
         LAST_ACTION = 'reused'
         print('liblime_hip.so: reused (csrc sha256 %s matches the stamp beside the binary)' % want[:16])
         return LIB
+    if force:
+        shutil.rmtree(OBJ_DIR, ignore_errors=True)
+    objs, n_compiled = compile_objects(verbose=verbose)
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
-    if not os.path.exists(hipcc):
-        raise RuntimeError('hipcc not found: cannot build the HIP extension')
-    cmd = [hipcc] + FLAGS + ['-o', LIB + '.tmp'] + sources()
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB + '.tmp'] + objs
     if verbose:
         print(' '.join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
@@ -59,7 +124,8 @@ def build_library(force=False, verbose=False):
     with open(STAMP, 'w') as f:
         f.write(want + '\n')
     LAST_ACTION = 'compiled'
-    print('liblime_hip.so: compiled (csrc sha256 %s, %d bytes)' % (want[:16], os.path.getsize(LIB)))
+    print('liblime_hip.so: compiled (%d of %d units rebuilt, csrc sha256 %s, %d bytes)' % (n_compiled, len(objs), want[:16],
+                                                                                        os.path.getsize(LIB)))
     return LIB
 
 
