@@ -7,14 +7,18 @@ stale-but-newer binary is never reused.  ``build_library`` reports which of the 
 import glob
 import hashlib
 import os
+import json
+import re
 import shutil
 import subprocess
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB = os.path.join(_HERE, 'liblime_hip.so')
 STAMP = LIB + '.sha256'
 OBJ_DIR = os.path.join(_HERE, '..', 'build', 'obj')
+RESOURCES = os.path.join(_HERE, 'liblime_hip.resources.json')
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared']
 LAST_ACTION = None            # 'compiled' | 'reused' after build_library()
 
@@ -78,6 +82,7 @@ def compile_objects(verbose=False, jobs=None):
             proc, src, obj, key = item
             if block or proc.poll() is not None:
                 if proc.wait() != 0:
+                    sys.stderr.write(open(obj + '.rpass').read()[-4000:])
                     for other in running:
                         if other[0].poll() is None:
                             other[0].kill()
@@ -94,13 +99,45 @@ def compile_objects(verbose=False, jobs=None):
             reap(False)
             if len(running) >= jobs:
                 reap(True)
-        cmd = [hipcc] + cflags + ['-c', src, '-o', obj]
+        # -Rpass-analysis prints each kernel's registers / scratch / LDS as remarks (no effect on the code): kept beside the
+        # object, summarised into liblime_hip.resources.json (tests/test_kernel_resources.py reads it)
+        cmd = [hipcc] + cflags + ['-Rpass-analysis=kernel-resource-usage', '-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd))
-        running.append((subprocess.Popen(cmd, cwd=CSRC), src, obj, key))
+        running.append((subprocess.Popen(cmd, cwd=CSRC, stderr=open(obj + '.rpass', 'w')), src, obj, key))
     while running:
         reap(True)
     return objs, len(todo)
+
+
+def _demangle(names):
+    out = subprocess.run(['c++filt'], input='\n'.join(names), capture_output=True, text=True).stdout.split('\n')
+    return [o.replace('(anonymous namespace)::', '').replace('void ', '') for o in out[:len(names)]]
+
+
+def kernel_resources(objs):
+    """{unit: {kernel: {vgprs, agprs, sgprs, vgpr_spill, sgpr_spill, scratch, lds, occupancy}}} from the remarks hipcc printed
+    while compiling each unit."""
+    res = {}
+    for obj in objs:
+        unit, rows, cur = os.path.splitext(os.path.basename(obj))[0], [], None
+        for line in open(obj + '.rpass', errors='replace'):
+            m = re.search(r'remark: +(?:\[[^\]]*\] *)?(.*?): +(\S+)\s*(?:\[-Rpass|$)', line)
+            if not m:
+                continue
+            k, v = m.group(1).strip(), m.group(2)
+            if k == 'Function Name':
+                cur = {'name': v}
+                rows.append(cur)
+            elif cur is not None:
+                cur[k] = v
+        names = _demangle([r['name'] for r in rows]) if rows else []
+        num = lambda r, k: int(r.get(k, '0') or 0)
+        res[unit] = {n: {'vgprs': num(r, 'VGPRs'), 'agprs': num(r, 'AGPRs'), 'sgprs': num(r, 'SGPRs'), 'vgpr_spill': num(r, 'VGPRs Spill'),
+                         'sgpr_spill': num(r, 'SGPRs Spill'), 'scratch': num(r, 'ScratchSize [bytes/lane]'),
+                         'lds': num(r, 'LDS Size [bytes/block]'), 'occupancy': num(r, 'Occupancy [waves/SIMD]')}
+                     for n, r in zip(names, rows)}
+    return res
 
 
 def build_library(force=False, verbose=False):
@@ -121,6 +158,8 @@ def build_library(force=False, verbose=False):
         print(' '.join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
     os.replace(LIB + '.tmp', LIB)
+    with open(RESOURCES, 'w') as f:
+        json.dump({'source_hash': want, 'units': kernel_resources(objs)}, f, indent=1, sort_keys=True)
     with open(STAMP, 'w') as f:
         f.write(want + '\n')
     LAST_ACTION = 'compiled'
