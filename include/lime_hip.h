@@ -106,6 +106,14 @@ int lime_linear_f32(const lime_linear_args* args, void* stream);
  * as rocprofv3 names it: lets a profiler harness match its own event timings to the kernel trace. */
 const char* lime_last_linear_kernel(void);
 
+/* Which kernels take the large 16-byte-aligned problems of lime_linear_f32 (M x N tiles >= 96 of 256 x 320):
+ *   1 (default): csrc/gemm_sp_f32.hip -- fp32 operands split in registers into three bf16 terms each, six bf16 MFMAs per product
+ *                block with fp32 accumulation: the error of one fp32 rounding per product (the same bound as the fp32 MFMA), fp32's
+ *                exponent range, 2.7x the fp32 matrix rate;
+ *   0          : csrc/gemm_pp_f32.hip -- v_mfma_f32_16x16x4_f32 (an fp32 fma chain).
+ * Process-wide; returns the previous setting; any other argument only queries.  LIME_SPLIT_GEMM=0 in the environment sets the start value. */
+int lime_set_split_gemm(int on);
+
 /*
  * lime_linear_bf16: the same operation on the bf16 matrix cores (BASELINE config 3: "bf16 MFMA with fp32
  * accumulate / softmax / LayerNorm").  A (or the gathered table), W and C are bf16 (uint16 storage, row-major);

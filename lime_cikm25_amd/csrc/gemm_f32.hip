@@ -618,6 +618,9 @@ extern "C" int lime_linear_f32(const lime_linear_args* a, void* stream) {
     // big M, 16-byte friendly operands: two four-wave workgroups per CU with LDS-DMA staging (gemm_pp_f32.hip)
     static const bool pp_off = getenv("LIME_GEMM_NO_PP") != nullptr;          // A/B switch for tools/, not a product option
     if (!pp_off || a->pool32) {
+        // first choice: fp32-level split products on the bf16 matrix cores (gemm_sp_f32.hip; lime_set_split_gemm(0) turns it off)
+        const int sp = lime_linear_sp(a, (hipStream_t)stream);
+        if (sp != LIME_PP_NOT_APPLICABLE) return sp;
         const int st = lime_linear_pp(a, (hipStream_t)stream);
         if (st != LIME_PP_NOT_APPLICABLE) return st;
     }

@@ -21,4 +21,5 @@ struct PPParams {
 };
 
 int lime_linear_pp(const lime_linear_args* a, hipStream_t stream);
+int lime_linear_sp(const lime_linear_args* a, hipStream_t stream);       // gemm_sp_f32.hip (split product on the bf16 cores), same convention
 int lime_linear_mid(const lime_linear_args* a, hipStream_t stream);      // gemm_mid_f32.hip, same return convention

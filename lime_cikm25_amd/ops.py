@@ -60,6 +60,12 @@ def _mask_u8(mask, name):
     return _vec(mask, name, dtype=torch.uint8)
 
 
+def set_split_gemm(on):
+    """Route the big lime_linear_f32 problems through the split-product kernel (True, the default: fp32-level products on the bf16
+    matrix cores, csrc/gemm_sp_f32.hip) or the fp32-MFMA kernels (False).  Returns the previous setting."""
+    return bool(_lib.load().lime_set_split_gemm(1 if on else 0))
+
+
 def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=0, res=None, res_div=1, res_ids=None,
            res_pe=None, res_period=0, ln=None, ln_eps=1e-5, res_mod=0, pool32=False, ln_rstd=None, n_alg=None, m_dev=None,
            c_ids=None):

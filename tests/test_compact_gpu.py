@@ -168,9 +168,13 @@ def test_training_gradients_with_and_without_dedup(monkeypatch):
     (l1, g1), (l0, g0) = grads[True], grads[False]
     assert abs(l1 - l0) < 1e-6 * max(1.0, abs(l0)) and set(g1) == set(g0) and len(g1) > 40
     worst = 0.0
+    # a parameter's gradient is judged against its own largest entry -- unless that is rounding noise: the key bias of the
+    # candidate-aware attention has gradient exactly zero (a constant added to every key shifts all scores of a query alike, softmax
+    # cancels it; observed 1e-11 against 1e-4 .. 1 elsewhere), and the two paths round differently wherever their GEMM kernels differ
+    gmax = max(float(b.abs().max()) for b in g0.values())
     for k in g0:
         a, b = g1[k].double(), g0[k].double()
-        scale = float(b.abs().max()) + 1e-12
+        scale = max(float(b.abs().max()), 1e-6 * gmax)
         worst = max(worst, float((a - b).abs().max()) / scale)
     print('dedup vs dense gradients: worst max-normalised difference %.2e' % worst)
     assert worst < 2e-5

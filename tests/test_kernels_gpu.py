@@ -25,6 +25,15 @@ def ops():
     return _ops
 
 
+@pytest.fixture(autouse=True)
+def _fp32_mfma_kernels(ops):
+    """This module pins the fp32-MFMA GEMM kernels (gemm_pp / gemm_mid / gemm_f32) by name; the split-product kernel that takes the
+    big problems by default has its own module (test_split_gemm_gpu.py)."""
+    prev = ops.set_split_gemm(False)
+    yield
+    ops.set_split_gemm(prev)
+
+
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return (torch.rand(*shape, generator=g) * 2 - 1) * scale
