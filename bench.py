@@ -44,6 +44,7 @@ if ROOT not in sys.path:
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 (the 5 PF headline figure includes 2:1 sparsity)
+PEAK_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6     # fp32-level products as six bf16 MFMAs each (csrc/gemm_sp_f32.hip)
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {
@@ -275,9 +276,17 @@ def roofline(by_kernel, workload, steps):
         source = tj.get('_source', 'profiles/traffic.json')
     is_bf16 = ((name.startswith('gemm_pp_kernel<') and name.split(', ')[4].startswith('true')) or     # <NTL, LN, RELU, RES, BF, ...>
                name.startswith('ffn_bf16_kernel<'))                                                    # the fused bf16 encoder block
-    peak = PEAK_BF16_MFMA_TFLOPS if is_bf16 else PEAK_F32_MFMA_TFLOPS
-    return {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-            'frac': round(ach / peak, 4), 'frac_padded': round(flp / sec / 1e12 / peak, 4),
+    is_split = name.startswith('gemm_sp_kernel<')
+    peak = PEAK_BF16_MFMA_TFLOPS if is_bf16 else (PEAK_SPLIT_TFLOPS if is_split else PEAK_F32_MFMA_TFLOPS)
+    extra = {}
+    if is_split:
+        extra = {'peak_note': 'fp32 operands, each product formed as six bf16 MFMAs (csrc/gemm_sp_f32.hip): the pipe that bounds the '
+                              'kernel is the bf16 matrix pipe, whose %.0f TFLOP/s dense peak delivers %.1f TFLOP/s of fp32-level products; '
+                              'achieved counts the algorithmic 2 m n k once' % (PEAK_BF16_MFMA_TFLOPS, PEAK_SPLIT_TFLOPS),
+                 'achieved_bf16_mfma_tflops': round(6 * flp / sec / 1e12, 1),
+                 'frac_of_f32_mfma_peak': round(ach / PEAK_F32_MFMA_TFLOPS, 4)}
+    return {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+            'frac': round(ach / peak, 4), 'frac_padded': round(flp / sec / 1e12 / peak, 4), **extra,
             'traffic': traffic, 'traffic_source': (source + ' -- a rocprofv3 --pmc pass of an earlier run of this command, NOT measured '
                                                    'in this run') if traffic is not None else None,
             'launches': cnt, 'avg_launch_us': round(sec / cnt * 1e6, 1), 'flops_per_launch': fl / cnt,

@@ -524,7 +524,11 @@ int lime_linear_sp(const lime_linear_args* a, hipStream_t s) {
     const int pad5 = (a->N + 319) / 320 * 320 - a->N, pad4 = (a->N + 255) / 256 * 256 - a->N;
     const bool wide = ln || pad5 <= pad4;
     const long ntiles = row_blocks * ((a->N + (wide ? 319 : 255)) / (wide ? 320 : 256));
-    if (ntiles < 96) return LIME_PP_NOT_APPLICABLE;       // 256-row tiles, one workgroup per CU: smaller launches keep the 128-row tiles
+    // From the same M on as gemm_pp_f32.hip takes over from the mid-M kernel: a caller that cuts its rows into passes of >= 4096 gets
+    // one kernel family -- one rounding -- for every pass (Model.score_impressions' last pass is shorter than the others; the
+    // impression-permutation test of tests/test_fullsize_gpu.py compares bit for bit).
+    (void)ntiles;
+    if (a->M < 4096) return LIME_PP_NOT_APPLICABLE;
 
     PPParams p;
     p.a = a->a; p.lda = a->lda; p.a_ids = a->a_ids;

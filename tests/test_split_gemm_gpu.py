@@ -232,6 +232,6 @@ def test_split_is_deterministic(ops):
 
 
 def test_small_problems_stay_on_the_fp32_kernels(ops):
-    a, w = dev(rnd(5000, 300, seed=1)), dev(rnd(300, 300, seed=2))
+    a, w = dev(rnd(3000, 300, seed=1)), dev(rnd(300, 300, seed=2))
     ops.linear(a, w, None)
     assert not last_kernel().startswith('gemm_sp_kernel'), last_kernel()
