@@ -255,3 +255,64 @@ def test_mhsa_compaction_helpers_against_torch(n, T):
     n_c = int(c.counts[0])
     assert torch.equal(c.ids_c.cpu()[:n_c * T], want_ids_c.cpu()[:n_c * T]) and int(c.ids_c.min()) >= 0
     assert torch.equal(mask_c.cpu().bool(), want_mask)
+
+
+def _with_history_fill(cfg, batch, keep):
+    """A copy of `batch` in which impression b keeps the first keep(b) of its history slots live and pads the rest with the all-zero
+    <PAD> news (mask bit 0 set, corpus.py:476-477) -- or, where keep(b) exceeds its live slots, fills them with fresh texts."""
+    rng = np.random.default_rng(7)
+    b2 = {k: v.clone() for k, v in batch.items()}
+    B, H = b2['user_history_mask'].shape
+    for b in range(B):
+        n = keep(b)
+        for key, S in (('user_title_text', cfg.max_title_length), ('user_content_text', cfg.max_abstract_length)):
+            t = b2[key][b]
+            t[n:] = 0
+            for h in range(n):
+                if not bool((t[h] != 0).any()):
+                    ln = int(rng.integers(3, S + 1))
+                    t[h, :ln] = torch.from_numpy(rng.integers(1, cfg.vocabulary_size, size=ln).astype(np.int32))
+        m = b2['user_title_mask'][b]
+        m[n:] = False
+        m[n:, 0] = True
+        m[:n] = b2['user_title_text'][b][:n] != 0
+        b2['user_history_mask'][b, :n] = True
+        b2['user_history_mask'][b, n:] = False
+    return b2
+
+
+@pytest.mark.parametrize('kind', ['fp32', 'bf16', 'mhsa'])
+def test_one_captured_graph_follows_the_live_counts(kind, monkeypatch):
+    """The design claim behind the compacted path: ONE captured HIP graph stays valid when a batch has more or fewer live sequences /
+    live tokens than the batch it was captured on, because every row count lives in device memory (m_dev, n_seq_dev, counts[]) and
+    the buffers have their full-batch size.  Captured on batch A; replayed on B (every history slot live: many more rows than at
+    capture), C (almost nothing but padding: rows beyond the counts still hold A's and B's data) and A again; every replay against
+    the same batch through the eager, dense path (use_graph off, DEDUP off)."""
+    over = dict(vocabulary_size=50000)
+    if kind == 'bf16':
+        over['compute_dtype'] = 'bf16'
+    if kind == 'mhsa':
+        over['content_encoder'] = 'MHSA'
+    cfg = make_config(**over)
+    model, sd = gpu_model(cfg, seed=61)
+    A = synth.make_batch(cfg, 32, 5, seed=62)
+    H = cfg.max_history_num
+    batches = {'A': A, 'B': _with_history_fill(cfg, A, lambda b: H), 'C': _with_history_fill(cfg, A, lambda b: 1 if b % 8 == 0 else 0),
+               'D': _with_history_fill(cfg, synth.make_batch(cfg, 32, 5, seed=63), lambda b: (7 * b) % (H + 1))}
+    monkeypatch.setattr(newsEncoders, 'DEDUP', True)
+    model.use_graph = True
+    model._graphs.clear()
+    got = {}
+    for name in ('A', 'B', 'C', 'D', 'A'):                  # the first call captures; everything behind it replays
+        got.setdefault(name, []).append(run(model, batches[name], False))
+    assert len(model._graphs) == 1, 'the replays must have gone through ONE captured graph'
+    assert torch.equal(got['A'][0], got['A'][1]), 'batch A replayed after B, C and D differs from its capture run'
+    monkeypatch.setattr(newsEncoders, 'DEDUP', False)
+    model.use_graph = False
+    tol = 1e-5 if kind != 'bf16' else 2e-5                  # same kernels per row on both sides (bf16: dedup vs dense, see the test above)
+    for name in ('A', 'B', 'C', 'D'):
+        want = run(model, batches[name], False)
+        e = rel_err(got[name][0].numpy(), want.numpy())
+        print('%s batch %s: graph replay (compacted) vs eager dense %.2e' % (kind, name, e))
+        assert torch.isfinite(got[name][0]).all() and e < tol, (kind, name, e)
+    model.use_graph = True
