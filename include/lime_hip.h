@@ -388,6 +388,12 @@ int lime_additive_pool_f32(const float* hidden, int64_t ldh, const float* affine
  */
 int lime_cand_attn_weights_f32(const float* qp, const float* kp, const uint8_t* mask, float* agg, int32_t B, int32_t N,
                                int32_t H, int32_t D, int32_t n_head, void* stream);
+/* The same result with (row, head) parallelism -- one wave per (b, head) writes that head's softmaxed weights and its share of
+ * ||Q_n||^2 to `workspace` (lime_cand_attn_weights_workspace(B, N, H, n_head) floats), one workgroup per row sums the heads in head
+ * order and finishes: two short launches that fill the chip at B = 32 (the one-workgroup-per-row kernel above: 32 workgroups, 64 us). */
+int64_t lime_cand_attn_weights_workspace(int32_t B, int32_t N, int32_t H, int32_t n_head);
+int lime_cand_attn_weights_ws_f32(const float* qp, const float* kp, const uint8_t* mask, float* agg, int32_t B, int32_t N, int32_t H,
+                                  int32_t D, int32_t n_head, float* workspace, int64_t workspace_floats, void* stream);
 
 /*
  * lime_gate_ln_f32: the gated residual + LayerNorm of CandidateAware_ClickedNewsAttention (layers.py:84-89), one

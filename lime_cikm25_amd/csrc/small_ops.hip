@@ -547,6 +547,110 @@ __global__ __launch_bounds__(256) void cand_attn_weights_kernel(const float* __r
     for (int h = threadIdx.x; h < H; h += 256) agg[(long)b * H + h] = v[h] * inv;
 }
 
+// ---- the same weights with (row, head) parallelism: B = 32 rows put 32 workgroups on 256 CUs and the launch took 64 us ------------
+// pass 1: one wave per (row b, head): that head's softmaxed weights P[b][head][n][h] and its share of ||Q_n||^2 -> workspace
+__global__ __launch_bounds__(64) void cand_attn_head_kernel(const float* __restrict__ qp, const float* __restrict__ kp,
+                                                            const unsigned char* __restrict__ mask, float* __restrict__ ws,
+                                                            int N, int H, int D, int n_head) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int hd = D / n_head, hdp = hd + 1;       // odd pitch: conflict-free column walks
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x / n_head, head = blockIdx.x - b * n_head;
+    float* Qh = sm;                                // [N][hdp]
+    float* Kh = sm + N * hdp;                      // [H][hdp]
+    float* P = ws + ((long)blockIdx.x * N) * (H + 1);             // [N][H] probabilities, then [N] squared-norm shares behind them
+    float* q2out = P + (long)N * H;
+    // a row's head slice is hd contiguous floats: one coalesced load per row, all rows in flight
+    for (int r = 0; r < N + H; ++r) {
+        const float* src = r < N ? qp + ((long)b * N + r) * D + head * hd : kp + ((long)b * H + (r - N)) * D + head * hd;
+        for (int j = lane; j < hd; j += 64) sm[r * hdp + j] = src[j];
+    }
+    wave_lds_fence();
+    for (int n = lane; n < N; n += 64) {
+        float q2 = 0.f;
+        for (int j = 0; j < hd; ++j) q2 += Qh[n * hdp + j] * Qh[n * hdp + j];
+        q2out[n] = q2;
+    }
+    const float inv_scale = 1.0f / sqrtf((float)D);
+    for (int n = 0; n < N; ++n) {                  // keys across the 64 lanes; row max / sum by wave shuffles
+        float sc[8];                               // H <= 512 -> at most 8 keys per lane
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int h = c * 64 + lane;
+            float v = -INFINITY;
+            if (h < H) {
+                float dot = 0.f;
+                for (int j = 0; j < hd; ++j) dot += Qh[n * hdp + j] * Kh[h * hdp + j];
+                v = dot * inv_scale;
+                if (mask[(long)b * H + h] == 0) v = -1e9f;           // layers.py:72
+            }
+            sc[c] = v;
+            mx = fmaxf(mx, v);
+            if ((c + 1) * 64 >= H) break;
+        }
+        mx = wave_max(mx);
+        float den = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            sc[c] = (c * 64 + lane < H) ? expf(sc[c] - mx) : 0.f;
+            den += sc[c];
+            if ((c + 1) * 64 >= H) break;
+        }
+        const float inv = 1.0f / wave_sum(den);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int h = c * 64 + lane;
+            if (h < H) P[(long)n * H + h] = sc[c] * inv;
+            if ((c + 1) * 64 >= H) break;
+        }
+    }
+}
+
+// pass 2: one workgroup per row: sums over the heads in head order, query weights softmax_N(||Q_n||) (layers.py:79), agg (:80-81)
+__global__ __launch_bounds__(256) void cand_attn_finish_kernel(const float* __restrict__ ws, float* __restrict__ agg, int N, int H, int n_head) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* qn = sm;                                // [N]  ||Q_n||
+    float* v = sm + N;                             // [H]
+    float* red = v + H;                            // [4]
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* base = ws + ((long)b * n_head * N) * (H + 1);
+    const long hstride = (long)N * (H + 1);
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float t = 0.f;
+        for (int hh = 0; hh < n_head; ++hh) t += base[hh * hstride + (long)N * H + n];
+        qn[n] = sqrtf(t);
+    }
+    __syncthreads();
+    float qmx = -INFINITY, qden = 0.f;
+    for (int n = 0; n < N; ++n) qmx = fmaxf(qmx, qn[n]);
+    for (int n = 0; n < N; ++n) qden += expf(qn[n] - qmx);
+    float mx = -INFINITY;
+    for (int h = threadIdx.x; h < H; h += 256) {
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) {
+            float a = 0.f;
+            for (int hh = 0; hh < n_head; ++hh) a += base[hh * hstride + (long)n * H + h];
+            acc += a * (expf(qn[n] - qmx) / qden);
+        }
+        v[h] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float part = 0.f;
+    for (int h = threadIdx.x; h < H; h += 256) {
+        const float e = expf(v[h] - mx);
+        v[h] = e;
+        part += e;
+    }
+    const float inv = 1.0f / block_sum(part, red);
+    for (int h = threadIdx.x; h < H; h += 256) agg[(long)b * H + h] = v[h] * inv;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // GraphSAGE mean over the first n_src node slots of cat[hist[b], user_nodes]
 // ---------------------------------------------------------------------------------------------------
@@ -1051,6 +1155,26 @@ extern "C" int lime_cand_attn_weights_f32(const float* qp, const float* kp, cons
     hipLaunchKernelGGL(cand_attn_weights_serial_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, qp, kp, mask, agg, N, H,
                        D, n_head);
     return lime_check_launch("lime_cand_attn_weights_f32");
+}
+
+extern "C" int64_t lime_cand_attn_weights_workspace(int32_t B, int32_t N, int32_t H, int32_t n_head) {
+    return (int64_t)B * n_head * N * (H + 1);
+}
+
+extern "C" int lime_cand_attn_weights_ws_f32(const float* qp, const float* kp, const uint8_t* mask, float* agg, int32_t B, int32_t N, int32_t H,
+                                             int32_t D, int32_t n_head, float* workspace, int64_t workspace_floats, void* stream) {
+    LIME_REQUIRE(qp && kp && mask && agg && workspace, LIME_ERR_BAD_ARG, "lime_cand_attn_weights_ws_f32: NULL pointer");
+    LIME_REQUIRE(B >= 0 && N > 0 && H > 0 && D > 0 && n_head > 0 && D % n_head == 0, LIME_ERR_BAD_ARG, "lime_cand_attn_weights_ws_f32: bad dims");
+    LIME_REQUIRE(N <= 128 && H <= 512, LIME_ERR_UNSUPPORTED, "lime_cand_attn_weights_ws_f32: N <= 128, H <= 512 (N=%d H=%d)", N, H);
+    LIME_REQUIRE(workspace_floats >= lime_cand_attn_weights_workspace(B, N, H, n_head), LIME_ERR_BAD_ARG, "lime_cand_attn_weights_ws_f32: workspace too small");
+    LIME_REQUIRE((long)B * n_head < 0x7FFFFFFFL, LIME_ERR_UNSUPPORTED, "lime_cand_attn_weights_ws_f32: too many (row, head) pairs");
+    if (B == 0) return LIME_OK;
+    const size_t lds1 = (size_t)(N + H) * (D / n_head + 1) * sizeof(float);
+    LIME_REQUIRE(lds1 <= 64 * 1024, LIME_ERR_UNSUPPORTED, "lime_cand_attn_weights_ws_f32: %zu B of LDS needed", lds1);
+    hipLaunchKernelGGL(cand_attn_head_kernel, dim3((unsigned)(B * n_head)), dim3(64), lds1, (hipStream_t)stream, qp, kp, mask, workspace, N, H, D, n_head);
+    hipLaunchKernelGGL(cand_attn_finish_kernel, dim3((unsigned)B), dim3(256), (size_t)(N + H + 4) * sizeof(float), (hipStream_t)stream,
+                       (const float*)workspace, agg, N, H, n_head);
+    return lime_check_launch("lime_cand_attn_weights_ws_f32");
 }
 
 extern "C" int lime_sage_mean_f32(const float* hist, const float* user_nodes, float* out, int32_t B, int32_t H, int32_t n_user,

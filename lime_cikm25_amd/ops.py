@@ -415,6 +415,9 @@ def additive_pool(hidden, affine2, x, n_seq, S, mask=None, out=None):
     return out
 
 
+CAND_ATTN_BY_HEAD = True      # False: the one-workgroup-per-row kernel (tests compare the two)
+
+
 def cand_attn_weights(qp, kp, mask, B, N, H, D, n_head):
     lib = _lib.load()
     _vec(qp, 'qp', B * N * D)
@@ -423,6 +426,13 @@ def cand_attn_weights(qp, kp, mask, B, N, H, D, n_head):
     if m.numel() != B * H:
         raise ValueError('mask must be [B, H]')
     agg = torch.empty((B, H), dtype=torch.float32, device=qp.device)
+    if CAND_ATTN_BY_HEAD and (N + H) * (D // n_head + 1) * 4 <= 64 * 1024:
+        # (row, head)-parallel: two short launches through a workspace (B = 32 rows alone leave 7 of 8 CUs idle)
+        n_ws = int(lib.lime_cand_attn_weights_workspace(B, N, H, n_head))
+        ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=qp.device)
+        check(lib.lime_cand_attn_weights_ws_f32(_p(qp), _p(kp), _p(m), _p(agg), B, N, H, D, n_head, _p(ws), n_ws, _stream()),
+              'lime_cand_attn_weights_ws_f32')
+        return agg
     check(lib.lime_cand_attn_weights_f32(_p(qp), _p(kp), _p(m), _p(agg), B, N, H, D, n_head, _stream()),
           'lime_cand_attn_weights_f32')
     return agg

@@ -456,7 +456,12 @@ def test_cand_attn_weights(ops, B, N, H):
     a = torch.softmax(s, dim=-1)
     qw = torch.softmax(torch.norm(qp.view(B, N, D), dim=-1), dim=1)
     want = torch.softmax((a.sum(dim=1) * qw.unsqueeze(-1)).sum(dim=1), dim=-1)
-    check(ops.cand_attn_weights(dev(qp), dev(kp), dev(mask), B, N, H, D, heads), want, what='cand attn weights')
+    for by_head in (True, False):                     # (row, head)-parallel two-launch form, and one workgroup per row
+        ops.CAND_ATTN_BY_HEAD = by_head
+        try:
+            check(ops.cand_attn_weights(dev(qp), dev(kp), dev(mask), B, N, H, D, heads), want, what='cand attn weights (by head %s)' % by_head)
+        finally:
+            ops.CAND_ATTN_BY_HEAD = True
 
 
 @pytest.mark.parametrize('B,H,n_user,n_src', [(4, 10, 4, 4), (6, 4, 6, 6), (3, 6, 8, 3), (5, 5, 5, 10)])
