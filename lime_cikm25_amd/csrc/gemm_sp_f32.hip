@@ -190,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
     const int w_off = A_BYTES + (16 * CT * wc + fi) * ROWB + pair_off;
     f32x4 acc[4][CT];
     int nct = CT;                                      // column tiles of this wave that hold real columns (set per tile)
-    int crow[4] = {0, 0, 0, 0};                        // CID: output rows of this lane's four result rows (read in acc_init, used in
+    int crow[4] = {0, 0, 0, 0};                        // CID: output rows (RES == 2: residual rows) of this lane's four result rows (read in acc_init, used in
                                                        // the epilogue: the row lists' half is re-parked for the next tile in between)
 
     auto compute = [&](int stage, int nstage, int nc, int sel) {        // nstage >= 0: the DMA pieces of chunk nc go out between the tiles
@@ -254,8 +254,12 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
         }
         float* const bs = Bs + (par ? BN : 0);
         for (int c = tid; c < BN; c += 512) bs[c] = (p.bias && col0 + c < p.N) ? p.bias[col0 + c] : 0.f;
-        if constexpr (RES == 0) {
-#pragma unroll
+        if constexpr (RES == 2) {                   // the residual row ids of this lane's four rows: kept in registers, the lists'
+#pragma unroll                                   // half is re-parked for the next tile before the epilogue reads them
+            for (int i = 0; i < 4; ++i) crow[i] = ids[sel * BM + 64 * wr + 16 * i + fi];
+        }
+        if constexpr (RES == 0 || RES == 2) {       // RES == 2: the gathered rows + positional rows are added in the epilogue (two
+#pragma unroll                                   // loads per element into the accumulators here spilled 186 registers)
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int t = 0; t < CT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -297,17 +301,39 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
         }
     };
 
-    auto epilogue = [&](int tile, int par) {
+    auto epilogue = [&](int tile, int par, int sel) {
         int row0, col0;
         tile_rc(tile, row0, col0);
         const float* const bs = Bs + (par ? BN : 0) + cw0 + 4 * kg;
         float sum[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+        unsigned rof[4] = {OOB, OOB, OOB, OOB}, pof[4] = {OOB, OOB, OOB, OOB};
+        const __amdgpu_buffer_rsrc_t rs_res2 = make_rsrc(p.res ? (const void*)p.res : (const void*)p.w);
+        const __amdgpu_buffer_rsrc_t rs_rpe2 = make_rsrc(p.res_pe ? (const void*)p.res_pe : (const void*)p.w);
+        if constexpr (RES == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rl = 64 * wr + 16 * i + fi, row = row0 + rl;
+                if (row < M) {
+                    rof[i] = (unsigned)crow[i] * (unsigned)ldr4 + (unsigned)(cw0 + 4 * kg) * 4u;
+                    if (p.res_pe) pof[i] = (unsigned)(row % p.res_period) * (unsigned)((int)p.ldr_pe * 4) + (unsigned)(cw0 + 4 * kg) * 4u;
+                }
+            }
+        }
 #pragma unroll
         for (int t = 0; t < CT; ++t) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(bs + 16 * t);
+            f32x4 rr[4];
+            if constexpr (RES == 2) {
+                const bool okc = col0 + cw0 + 16 * t + 4 * kg < p.N;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    rr[i] = buf_load4(rs_res2, okc ? rof[i] + (unsigned)t * 64u : OOB, col0 * 4) +
+                            buf_load4(rs_rpe2, okc ? pof[i] + (unsigned)t * 64u : OOB, col0 * 4);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 f32x4 v = acc[i][t] + b;
+                if constexpr (RES == 2) v += rr[i];
                 if constexpr (RELU) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -318,6 +344,7 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
                     for (int j = 0; j < 4; ++j) { sum[i] += v[j]; sq[i] += v[j] * v[j]; }
                 }
             }
+            if constexpr (RES == 2) __builtin_amdgcn_sched_barrier(0);      // one column tile's eight residual loads at a time
         }
         float mean[4] = {0.f, 0.f, 0.f, 0.f}, rstd[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (LN) {
@@ -440,7 +467,7 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
         lds_barrier();
         stage ^= 1;
         // the stores retire under the next tile's first chunk; the bias image is double-buffered by tile parity
-        epilogue(tile, par);
+        epilogue(tile, par, sel);
     }
 }
 
@@ -483,14 +510,14 @@ extern "C" int lime_set_split_gemm(int on) {
         g_split_mode = (e && e[0] == '0') ? 0 : 1;
     }
     const int prev = g_split_mode;
-    if (on == 0 || on == 1) g_split_mode = on;
+    if (on == 0 || on == 1 || on == 3) g_split_mode = on;       // 3: also the gathered-residual LayerNorm GEMM (tests / A-B runs)
     return prev;
 }
 
 // LIME_OK / error: launched (or failed); LIME_PP_NOT_APPLICABLE: the caller takes the fp32-MFMA kernels.
 int lime_linear_sp(const lime_linear_args* a, hipStream_t s) {
     if (g_split_mode < 0) lime_set_split_gemm(-1);
-    if (!g_split_mode) return LIME_PP_NOT_APPLICABLE;
+    if (!(g_split_mode & 1)) return LIME_PP_NOT_APPLICABLE;
     const bool has_res = a->res != nullptr, ln = a->ln_gamma != nullptr;
     const bool relu = a->act == LIME_ACT_RELU;
     if (a->a_pe != nullptr) return LIME_PP_NOT_APPLICABLE;
@@ -514,11 +541,10 @@ int lime_linear_sp(const lime_linear_args* a, hipStream_t s) {
         if (res == 1 && a->res_mod > 0 && (long)a->res_mod * a->ldr * 4 >= lim) return LIME_PP_NOT_APPLICABLE;
     }
     if (ln && (a->N > 320 || relu)) return LIME_PP_NOT_APPLICABLE;
-    // out_proj (gathered residual + positional rows in the accumulators + LayerNorm): this kernel's instantiation keeps 186 registers in
-    // scratch around its tile boundary and measures 73-80 TFLOP/s against 102 of gemm_pp_f32.hip -- left to the fp32 kernel until the
-    // residual takes another way into the tile (LIME_SP_RES2=1 routes it here for A/B runs)
-    static const bool res2_here = getenv("LIME_SP_RES2") != nullptr;
-    if (res == 2 && !res2_here) return LIME_PP_NOT_APPLICABLE;
+    // out_proj (gathered residual + positional rows + LayerNorm): this kernel's instantiation adds the residual in its epilogue and
+    // keeps 265 registers in scratch there; it measures 67-80 TFLOP/s against 100 of gemm_pp_f32.hip (with the residual loaded into
+    // the accumulators at the tile start: 186 registers, 73 TFLOP/s) -- left to the fp32 kernel; lime_set_split_gemm(3) routes it here
+    if (res == 2 && !(g_split_mode & 2)) return LIME_PP_NOT_APPLICABLE;      // only with lime_set_split_gemm(3)
     if (a->pool32 && !(ln && has_res && !a->res_ids && a->res_div <= 1 && a->M % 32 == 0)) return LIME_PP_NOT_APPLICABLE;
     // the tile width (256 / 320) that pads N least
     const int pad5 = (a->N + 319) / 320 * 320 - a->N, pad4 = (a->N + 255) / 256 * 256 - a->N;

@@ -175,16 +175,21 @@ def test_split_gathered_residual_layernorm(ops, M, S):
     g, be = rnd(N, seed=12) + 1.5, rnd(N, seed=13)
     da, dw, db, dt, dids, dpe, dg, dbe = dev(attn), dev(w), dev(b), dev(table), dev(ids), dev(pe), dev(g), dev(be)
     from lime_cikm25_amd import _lib
-    import os
-    if not os.environ.get('LIME_SP_RES2'):
-        pytest.skip('the gathered-residual LayerNorm instantiation is routed to the fp32 kernel (LIME_SP_RES2=1 to test it)')
-    got, name, ref = both(ops, lambda: ops.linear(da, dw, db, res=dt, res_ids=dids, res_pe=dpe, res_period=S, ln=(dg, dbe)))
+    lib = _lib.load()
+    run = lambda: ops.linear(da, dw, db, res=dt, res_ids=dids, res_pe=dpe, res_period=S, ln=(dg, dbe))
+    run()
+    assert last_kernel().startswith('gemm_pp_kernel'), 'by default this instantiation stays on the fp32 kernel: ' + last_kernel()
+    ref = run().cpu()
+    lib.lime_set_split_gemm(3)                           # route it to the split kernel (off by default: slower there)
+    got = run().cpu()
+    name = last_kernel()
     assert name.startswith('gemm_sp_kernel<10, true, false, 2'), name
     check(got, O.layer_norm(x + attn.double() @ w.double().t() + b.double(), g.double(), be.double()), ref, what='split gather residual + LN')
     m_dev = torch.tensor([M - 3000], dtype=torch.int32, device='cuda')
     out = torch.full((M, N), 7.0, device='cuda')
     ops.linear(da, dw, db, res=dt, res_ids=dids, res_pe=dpe, res_period=S, ln=(dg, dbe), out=out, m_dev=m_dev)
     assert last_kernel().startswith('gemm_sp_kernel'), last_kernel()
+    lib.lime_set_split_gemm(1)
     assert torch.equal(out[:M - 3000].cpu(), got[:M - 3000]) and (out[M - 3000:] == 7.0).all()
 
 
