@@ -405,6 +405,17 @@ int lime_cand_attn_weights_ws_f32(const float* qp, const float* kp, const uint8_
 int lime_gate_ln_f32(const float* y, const float* x, const float* scale, const float* bias, const float* gamma,
                      const float* beta, float eps, float* out, int64_t rows, int32_t D, void* stream);
 
+/* lime_gate_ln_f32 over the H history rows of each user row and the GraphSAGE aggregate of the result in one pass (layers.py:83-91 +
+ * userEncoders.py:121,151-157).  Group g (one impression row of the user encoder; `groups` of them) reads its H history rows from
+ * impression g / row_div -- x and y = gate_proj(x) are [groups / row_div, H, D]: Model.score_impressions keeps ONE copy of a history for
+ * its row_div candidates -- and scale[g * H + h]; writes out[g, h, :] as lime_gate_ln_f32 does and
+ *     mean_out[g, :] = (sum_{h < min(H, n_src)} out[g, h, :] + node_const) / n_src,
+ * node_const [D] = the sum of the first n_src - H user-node rows (the part of the SAGEConv mean that is the same for every row; may be
+ * NULL when n_src <= H).  D <= 512. */
+int lime_gate_ln_sage_f32(const float* y, const float* x, const float* scale, const float* bias, const float* gamma, const float* beta,
+                          float eps, float* out, const float* node_const, float* mean_out, int64_t groups, int32_t H, int32_t D,
+                          int32_t row_div, int32_t n_src, void* stream);
+
 /*
  * lime_sage_mean_f32: m[b, :] = mean over the first n_src node slots of row b of cat[hist[b] (H rows),
  * user_nodes (n_user rows)] -- the aggregation PyG's SAGEConv performs for the edge list of

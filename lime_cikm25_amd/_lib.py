@@ -154,6 +154,8 @@ SIGNATURES = {
                                                 c_int64, c_void_p]),
     'lime_cand_attn_weights_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                              c_int32, c_void_p]),
+    'lime_gate_ln_sage_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
+                                        c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'lime_gate_ln_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64,
                                    c_int32, c_void_p]),
     'lime_sage_mean_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),

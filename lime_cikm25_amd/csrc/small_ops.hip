@@ -822,6 +822,79 @@ __global__ __launch_bounds__(256) void gate_ln_kernel(const float* __restrict__ 
     for (int d = threadIdx.x; d < D; d += 256) out[r * D + d] = (v[d] - mean) * rstd * gamma[d] + beta[d];
 }
 
+// gate_ln over the H history rows of one user row + the GraphSAGE mean of the result, in one pass (userEncoders.py:121,151-157 behind
+// layers.py:83-91): workgroup g = one (impression, candidate) row; its history rows are read from impression g / row_div (the
+// scoring layout keeps ONE copy of a history for its row_div candidates), blended with this row's attention weights, normalised
+// and written to out[g * H + h]; the column sums over the first n_hist node slots + `node_const` (the sum of the user-node rows the
+// mean also covers: the same vector for every row) times inv_n are the SAGEConv aggregate mean_out[g].  A wave owns a row at a time
+// (row statistics by wave shuffles); the four waves' column sums are added in wave order.  D <= 512.
+__global__ __launch_bounds__(256) void gate_ln_sage_kernel(const float* __restrict__ y, const float* __restrict__ x,
+                                                            const float* __restrict__ scale, const float* __restrict__ bias,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                            float* __restrict__ out, const float* __restrict__ node_const,
+                                                            float* __restrict__ mean_out, int H, int D, int row_div, int n_hist, float inv_n) {
+    __shared__ float part[4][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long g = blockIdx.x;
+    const long src = (g / row_div) * H;
+    const int nj = (D + 63) >> 6;                  // <= 8
+    float bi[8], ga[8], be[8], csum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int d = lane + 64 * j;
+        const bool ok = j < nj && d < D;
+        bi[j] = ok ? bias[d] : 0.f;
+        ga[j] = ok ? gamma[d] : 0.f;
+        be[j] = ok ? beta[d] : 0.f;
+        csum[j] = 0.f;
+    }
+    const float inv_d = 1.0f / (float)D;
+    for (int h = wave; h < H; h += 4) {
+        const float s = scale[g * H + h];
+        const float* xr = x + (src + h) * D;
+        const float* yr = y + (src + h) * D;
+        float v[8];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = lane + 64 * j;
+            v[j] = 0.f;
+            if (j < nj && d < D) {
+                const float xv = xr[d];
+                const float gt = lime_sigmoid(s * yr[d] + bi[j]);
+                v[j] = gt * (s * xv) + (1.f - gt) * xv;
+                sum += v[j];
+            }
+        }
+        const float mean = wave_sum(sum) * inv_d;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = lane + 64 * j;
+            if (j < nj && d < D) { const float dv = v[j] - mean; sq += dv * dv; }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(sq) * inv_d + eps);
+        float* orow = out + (g * H + h) * D;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int d = lane + 64 * j;
+            if (j < nj && d < D) {
+                const float o = (v[j] - mean) * rstd * ga[j] + be[j];
+                orow[d] = o;
+                if (h < n_hist) csum[j] += o;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[wave][lane + 64 * j] = csum[j];
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float t = ((part[0][d] + part[1][d]) + part[2][d]) + part[3][d];
+        if (node_const) t += node_const[d];
+        mean_out[g * D + d] = t * inv_n;
+    }
+}
+
 __global__ __launch_bounds__(256) void pad_heads_kernel(const float* __restrict__ src, long lds_, float* __restrict__ dst, long ldd,
                                                          int n_blk, int hd, int hs, int cols) {
     const long total = (long)n_blk * hs * cols;
@@ -1234,6 +1307,20 @@ extern "C" int lime_gate_ln_f32(const float* y, const float* x, const float* sca
     hipLaunchKernelGGL(gate_ln_kernel, dim3((unsigned)rows), dim3(256), (size_t)(D + 4) * sizeof(float), (hipStream_t)stream, y, x,
                        scale, bias, gamma, beta, eps, out, D);
     return lime_check_launch("lime_gate_ln_f32");
+}
+
+extern "C" int lime_gate_ln_sage_f32(const float* y, const float* x, const float* scale, const float* bias, const float* gamma,
+                                     const float* beta, float eps, float* out, const float* node_const, float* mean_out, int64_t groups,
+                                     int32_t H, int32_t D, int32_t row_div, int32_t n_src, void* stream) {
+    LIME_REQUIRE(y && x && scale && bias && gamma && beta && out && mean_out, LIME_ERR_BAD_ARG, "lime_gate_ln_sage_f32: NULL pointer");
+    LIME_REQUIRE(groups >= 0 && H > 0 && D > 0 && row_div >= 1 && n_src > 0, LIME_ERR_BAD_ARG, "lime_gate_ln_sage_f32: bad dims");
+    LIME_REQUIRE(D <= 512, LIME_ERR_UNSUPPORTED, "lime_gate_ln_sage_f32: D %d > 512 (use lime_gate_ln_f32 + lime_sage_mean_f32)", D);
+    LIME_REQUIRE(n_src <= H || node_const, LIME_ERR_BAD_ARG, "lime_gate_ln_sage_f32: n_src %d > H %d needs node_const", n_src, H);
+    LIME_REQUIRE(groups < 0x7FFFFFFFL, LIME_ERR_UNSUPPORTED, "lime_gate_ln_sage_f32: too many rows");
+    if (groups == 0) return LIME_OK;
+    hipLaunchKernelGGL(gate_ln_sage_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, y, x, scale, bias, gamma, beta, eps, out,
+                       n_src > H ? node_const : nullptr, mean_out, H, D, row_div, n_src < H ? n_src : H, 1.0f / (float)n_src);
+    return lime_check_launch("lime_gate_ln_sage_f32");
 }
 
 extern "C" int lime_pad_heads_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int32_t n_blk, int32_t head_dim,

@@ -172,14 +172,16 @@ class Model(nn.Module):
         out = torch.empty((B, K), dtype=torch.float32, device=cand.device)
         per = max(1, rows_per_pass // K)                                              # impressions per pass
         rl = remaining_lifetime.float()
+        gate_y = ue.gate_projection(hist)                                             # once for every pass's histories (one GEMM shape)
         for b0 in range(0, B, per):
             b1 = min(B, b0 + per)
             n = (b1 - b0) * K
-            rep = lambda t: t[b0:b1].repeat_interleave(K, dim=0)                      # history side: one copy per candidate row
-            _, logits = ue.match(rep(hist), news_category[b0:b1].reshape(n, 1), news_subCategory[b0:b1].reshape(n, 1),
+            rep = lambda t: t[b0:b1].repeat_interleave(K, dim=0)                      # per-row ids / masks (the history itself is shared: hist_div)
+            _, logits = ue.match(hist[b0:b1], news_category[b0:b1].reshape(n, 1), news_subCategory[b0:b1].reshape(n, 1),
                                  rep(user_category), rep(user_subCategory), rep(user_history_mask),
                                  cand[b0:b1].reshape(n, 1, -1), remaining_lifetime=rl[b0:b1].reshape(n, 1),
-                                 weighting=self.remaining_lifetime_weighting, n_src=n_src)
+                                 weighting=self.remaining_lifetime_weighting, n_src=n_src, hist_div=K,
+                                 gate_y=None if gate_y is None else gate_y[b0 * H:b1 * H])
             out[b0:b1] = logits.view(b1 - b0, K)
         return out
 

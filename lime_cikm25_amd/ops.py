@@ -438,6 +438,23 @@ def cand_attn_weights(qp, kp, mask, B, N, H, D, n_head):
     return agg
 
 
+def gate_ln_sage(y, x, scale, bias, gamma, beta, eps, groups, H, D, row_div, n_src, node_const=None):
+    """``gate_ln`` over the H history rows of each of `groups` user rows + the GraphSAGE aggregate of the result in one launch:
+    -> (refined [groups * H, D], mean [groups, D]).  x / y are [groups // row_div, H, D] (one history per row_div rows)."""
+    lib = _lib.load()
+    src_rows = (groups // row_div) * H * D
+    x = _vec(x.contiguous(), 'x', src_rows)
+    y = _vec(y.contiguous(), 'y', src_rows)
+    scale = _vec(scale.contiguous(), 'scale', groups * H)
+    out = torch.empty((groups * H, D), dtype=torch.float32, device=x.device)
+    mean = torch.empty((groups, D), dtype=torch.float32, device=x.device)
+    nc = _vec(node_const.contiguous(), 'node_const', D) if node_const is not None else None
+    check(lib.lime_gate_ln_sage_f32(_p(y), _p(x), _p(scale), _p(_vec(bias, 'bias', D)), _p(_vec(gamma, 'gamma', D)), _p(_vec(beta, 'beta', D)),
+                                    eps, _p(out), _p(nc) if nc is not None else None, _p(mean), groups, H, D, row_div, n_src, _stream()),
+          'lime_gate_ln_sage_f32')
+    return out, mean
+
+
 def gate_ln(y, x, scale, bias, gamma, beta, eps=1e-5):
     """LayerNorm(g * (s x) + (1 - g) x), g = sigmoid(s y + bias): the gated residual of layers.py:84-89."""
     lib = _lib.load()

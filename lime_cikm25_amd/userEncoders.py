@@ -120,20 +120,26 @@ class CROWN(UserEncoder):
         return self.candidate_aware_attn.attention_weights(hist_topic, cand_topic, user_history_mask)
 
     def match(self, history_embedding, category, subCategory, user_category, user_subCategory, user_history_mask,
-              candidate_news_representation, remaining_lifetime=None, weighting=None, agg=None, n_src=None):
+              candidate_news_representation, remaining_lifetime=None, weighting=None, agg=None, n_src=None, hist_div=1,
+              gate_y=None):
         """Everything after the history has been encoded (userEncoders.py:103-105, :114-169).
 
         Returns (user_representation [B, N, D], logits [B, N] or None).  With ``weighting`` (the model's
         RemainingLifetimeWeighting) the dot-product match and the lifetime weight are fused into the last kernel.
         ``agg``: precomputed ``attention_weights(...)``.  ``n_src``: how many node slots the GraphSAGE mean runs over
         (Q7: the reference uses the number of rows of the forward; default B).
+        ``hist_div`` > 1 (Model.score_impressions): ``history_embedding`` is [B / hist_div, H, D] -- ONE copy of a history for the
+        hist_div consecutive rows (candidates) that share it; everything per row (attention weights, masks, topic ids) stays [B, ...].
+        ``gate_y``: ``gate_projection(history_embedding)`` computed by the caller (one GEMM over all passes' histories).
         """
         if self.training and (self.dropout_rate > 0 or (self.use_candidate_aware_attn and self.candidate_aware_attn.dropout.p > 0)):
             raise NotImplementedError('match() is the fused scoring kernel chain: with training-mode dropouts active (userEncoders.py:121, '
                                       'layers.py:74) call user_encoder(...) or Model.forward, which take the differentiable path')
-        B, H, D = history_embedding.shape
+        Bh, H, D = history_embedding.shape
+        B = Bh * hist_div
         N = candidate_news_representation.shape[1]
         cand = candidate_news_representation.contiguous()
+        n_src = B if n_src is None else n_src
         # the candidate side of the match (:162) needs the candidates only: branch 6, beside the history chain
         from .newsEncoders import _side_stream
         main = torch.cuda.current_stream()
@@ -141,12 +147,28 @@ class CROWN(UserEncoder):
         side6.wait_stream(main)
         with torch.cuda.stream(side6):
             qp = ops.linear(cand.view(B * N, D), self.Q.weight, self.Q.bias)                                 # :162
-        if self.use_candidate_aware_attn:
-            if agg is None:
-                agg = self.attention_weights(category, subCategory, user_category, user_subCategory, user_history_mask)
-            history_embedding = self.candidate_aware_attn.refine(history_embedding, agg)
-        g = self.graph_sage.forward_closed_form(history_embedding, self.user_node_embedding,
-                                                n_src=B if n_src is None else n_src)                          # :121,:151-157
+        caa = self.candidate_aware_attn if self.use_candidate_aware_attn else None
+        if caa is not None and agg is None:
+            agg = self.attention_weights(category, subCategory, user_category, user_subCategory, user_history_mask)
+        conv = self.graph_sage.convs[0]
+        if caa is not None and caa.use_residual_connection and D <= 512:
+            # gate_proj sees the history alone (the row scale commutes: layers.py:85-87), so it runs once per HISTORY; the gated
+            # residual + LayerNorm of each row's H history rows and the SAGEConv mean over them are one launch, which reads a
+            # shared history through row / hist_div (no per-candidate copies) and takes the user-node part of the mean -- the same
+            # vector for every row -- as one precomputed sum                                                  :121,:151-157
+            hist = history_embedding.reshape(Bh * H, D)
+            y = gate_y if gate_y is not None else ops.linear(hist, caa.gate_proj.weight, None)
+            node_const = self.user_node_embedding[:n_src - H].sum(dim=0) if n_src > H else None
+            refined, m = ops.gate_ln_sage(y, hist, agg.reshape(-1), caa.gate_proj.bias, caa.layernorm.weight, caa.layernorm.bias,
+                                          caa.layernorm.eps, B, H, D, hist_div, n_src, node_const)
+            l = ops.linear(m, conv.lin_l.weight, conv.lin_l.bias)
+            g = ops.linear(refined, conv.lin_r.weight, None, res=l, res_div=H).view(B, H, D)
+        else:
+            if hist_div > 1:
+                history_embedding = history_embedding.repeat_interleave(hist_div, dim=0)
+            if caa is not None:
+                history_embedding = caa.refine(history_embedding, agg)
+            g = self.graph_sage.forward_closed_form(history_embedding, self.user_node_embedding, n_src=n_src)   # :121,:151-157
         kp = ops.linear(g.view(B * H, D), self.K.weight, None)                                               # :161
         main.wait_stream(side6)
         w = weighting
@@ -158,6 +180,15 @@ class CROWN(UserEncoder):
             bool(w.use_expired_penalty) if w is not None else False,
             want_logits=w is not None, want_user=True)
         return user, logits
+
+    def gate_projection(self, history_embedding):
+        """W_g x of the candidate-aware attention's gate (layers.py:87) for histories [*, H, D] -> [* H, D], or None when ``match``
+        does not take the fused path."""
+        caa = self.candidate_aware_attn if self.use_candidate_aware_attn else None
+        D = history_embedding.shape[-1]
+        if caa is None or not caa.use_residual_connection or D > 512:
+            return None
+        return ops.linear(history_embedding.reshape(-1, D), caa.gate_proj.weight, None)
 
     def forward(self, user_title_text, user_title_mask, user_title_entity, user_content_text, user_content_mask,
                 user_content_entity, category, subCategory, user_category, user_subCategory, user_history_mask,

@@ -838,3 +838,29 @@ def test_linear_mid_kernel_randomized(ops, seed):
     if rows:
         check(got[:rows], want[:rows].float(), what='M=%d N=%d K=%d act=%s kind=%d gather=%s m_dev=%s' % (M, N, K, act, kind, gather, m_live))
     assert torch.isnan(got[rows:]).all()                     # rows beyond the device count are left untouched
+
+
+@pytest.mark.parametrize('G,H,D,row_div,n_src,n_user', [(12, 50, 400, 1, 12, 64), (12, 50, 400, 4, 70, 64), (6, 10, 400, 3, 10, 8), (8, 7, 128, 2, 3, 4),
+                                                       (5, 50, 512, 1, 114, 64), (9, 33, 300, 9, 40, 16)])
+def test_gate_ln_sage_fused(ops, G, H, D, row_div, n_src, n_user):
+    """The fused gated-residual LayerNorm + GraphSAGE aggregate against gate_ln on the per-candidate copies + sage_mean over
+    cat[refined history, user nodes] (what the two separate launches compute), and against a plain torch statement."""
+    Gh = G // row_div
+    x, y = rnd(Gh * H, D, seed=1), rnd(Gh * H, D, seed=2)
+    scale, bias = torch.rand(G * H, generator=torch.Generator().manual_seed(3)), rnd(D, seed=4)
+    gamma, beta = rnd(D, seed=5) + 1.5, rnd(D, seed=6)
+    un = rnd(n_user, D, seed=7)
+    xr = x.view(Gh, H, D).repeat_interleave(row_div, dim=0).reshape(G * H, D)
+    yr = y.view(Gh, H, D).repeat_interleave(row_div, dim=0).reshape(G * H, D)
+    gt = torch.sigmoid(scale[:, None] * yr + bias)
+    blend = gt * (scale[:, None] * xr) + (1 - gt) * xr
+    want = O.layer_norm(blend, gamma, beta)
+    nodes = torch.cat([want.view(G, H, D), un.unsqueeze(0).expand(G, -1, -1)], dim=1)
+    want_mean = nodes[:, :n_src].mean(dim=1)
+    const = dev(un[:n_src - H].sum(dim=0)) if n_src > H else None
+    got, mean = ops.gate_ln_sage(dev(y), dev(x), dev(scale), dev(bias), dev(gamma), dev(beta), 1e-5, G, H, D, row_div, n_src, const)
+    check(got, want, what='gate_ln_sage rows')
+    check(mean, want_mean, what='gate_ln_sage mean')
+    two = ops.gate_ln(dev(yr), dev(xr), dev(scale), dev(bias), dev(gamma), dev(beta))
+    check(got, two.cpu().view(G * H, D), what='fused vs gate_ln')
+    check(mean, ops.sage_mean(two.view(G * H, D), dev(un), G, H, n_src, D).cpu(), what='fused vs sage_mean')
