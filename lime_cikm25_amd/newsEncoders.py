@@ -553,34 +553,63 @@ def compact_prepare(ids, table, pe, transformer, nhead):
     return cmp, w_in, pew, qkv
 
 
+_IDENT = {}
+
+
+def _identity_rows(n, device):
+    """arange(n) int32, allocated once per device: the row map of an encoder layer behind the first (every compact row is its own)."""
+    key = (device.type, device.index)
+    z = _IDENT.get(key)
+    if z is None or z.numel() < n:
+        z = _IDENT[key] = torch.arange(max(n, 4096), dtype=torch.int32, device=device)
+    return z[:n]
+
+
 def compact_run(prep, table, pe, transformer, nhead, pooled_out):
     cmp, w_in, pew, qkv = prep
     M, S, cap = cmp.n_seq, cmp.S, cmp.cap
     E = table.shape[1]
     hd = E // nhead
     W = nhead * 32
-    layer = transformer.layers[0]
-    sa = layer.self_attn
-    ops.linear(table, w_in, None, a_ids=cmp.tok_ids, res=pew, res_mod=S, out=qkv[:cap], m_dev=cmp.n_live_tokens,
-               c_ids=cmp.tok_rows, n_alg=3 * E)                                                        # live tokens only
-    attn = ops.token_attention_rows(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], cmp.row_map, cmp.n_compact, M + 1, S, nhead, hd,
-                                    1.0 / math.sqrt(hd))
-    x1 = ops.linear(attn, sa.out_proj.weight, sa.out_proj.bias, res=table, res_ids=cmp.ids_c, res_pe=pe, res_period=S,
-                    ln=(layer.norm1.weight, layer.norm1.bias), ln_eps=layer.norm1.eps, m_dev=cmp.n_rows)
-    h = ops.linear(x1, layer.linear1.weight, layer.linear1.bias, act='relu', m_dev=cmp.n_rows)
-    blocks = ops.linear(h, layer.linear2.weight, layer.linear2.bias, res=x1, ln=(layer.norm2.weight, layer.norm2.bias),
-                        ln_eps=layer.norm2.eps, pool32=True, m_dev=cmp.n_rows)                         # [cap / 32, E] block means
+    n_layers = len(transformer.layers)
+    x = None
+    for li, layer in enumerate(transformer.layers):
+        sa = layer.self_attn
+        ln1 = (layer.norm1.weight, layer.norm1.bias)
+        if li == 0:
+            ops.linear(table, w_in, None, a_ids=cmp.tok_ids, res=pew, res_mod=S, out=qkv[:cap], m_dev=cmp.n_live_tokens,
+                       c_ids=cmp.tok_rows, n_alg=3 * E)                                                    # live tokens only
+            attn = ops.token_attention_rows(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], cmp.row_map, cmp.n_compact, M + 1, S, nhead, hd,
+                                            1.0 / math.sqrt(hd))
+            x1 = ops.linear(attn, sa.out_proj.weight, sa.out_proj.bias, res=table, res_ids=cmp.ids_c, res_pe=pe, res_period=S,
+                            ln=ln1, ln_eps=layer.norm1.eps, m_dev=cmp.n_rows)
+        else:
+            # a layer behind the first (config.py:70 allows num_layers = 2): its input rows are all distinct, so only the sequence-level
+            # sharing is left -- the layer runs over the n_rows compact rows (device-side count), attention through the identity map
+            w_l = ops.pad_heads(sa.in_proj_weight, 3 * nhead, hd, 32)
+            b_l = ops.pad_heads(sa.in_proj_bias, 3 * nhead, hd, 32)
+            qkv_l = ops.linear(x, w_l, b_l, m_dev=cmp.n_rows, n_alg=3 * E)
+            attn = ops.token_attention_rows(qkv_l[:, :W], qkv_l[:, W:2 * W], qkv_l[:, 2 * W:], _identity_rows(cap, x.device), cmp.n_compact,
+                                            M + 1, S, nhead, hd, 1.0 / math.sqrt(hd))
+            x1 = ops.linear(attn, sa.out_proj.weight, sa.out_proj.bias, res=x, ln=ln1, ln_eps=layer.norm1.eps, m_dev=cmp.n_rows)
+        h = ops.linear(x1, layer.linear1.weight, layer.linear1.bias, act='relu', m_dev=cmp.n_rows)
+        if li + 1 < n_layers:
+            x = ops.linear(h, layer.linear2.weight, layer.linear2.bias, res=x1, ln=(layer.norm2.weight, layer.norm2.bias),
+                           ln_eps=layer.norm2.eps, m_dev=cmp.n_rows)
+            continue
+        blocks = ops.linear(h, layer.linear2.weight, layer.linear2.bias, res=x1, ln=(layer.norm2.weight, layer.norm2.bias),
+                            ln_eps=layer.norm2.eps, pool32=True, m_dev=cmp.n_rows)                     # [cap / 32, E] block means
     pooled_c = blocks if S == 32 else ops.mean_pool(blocks, M + 1, S // 32)
     ops.gather_rows(cmp.seq_inv, pooled_c, pooled_out)
     return None
 
 
 def compact_applicable(ids, table, transformer, nhead):
-    """The compacted path covers the shapes of the big-M kernels: one post-LN layer without a final norm, head_dim <= 32,
+    """The compacted path covers the shapes of the big-M kernels: post-LN layers without a final norm, head_dim <= 32,
     S a multiple of 32 that the row-map attention is built for, at least 4096 token rows, 16-byte aligned table rows."""
     M, S = ids.shape
     E = table.shape[1]
-    return (DEDUP and len(transformer.layers) == 1 and transformer.norm is None and E % nhead == 0 and E // nhead <= 32 and
+    return (DEDUP and len(transformer.layers) >= 1 and transformer.norm is None and E % nhead == 0 and E // nhead <= 32 and
             E % 4 == 0 and S % 32 == 0 and (S // 32 <= 4 or S // 32 in (8, 16)) and (M + 1) * S >= 4096 and
             ids.dtype == torch.int32 and ids.is_contiguous())
 

@@ -113,8 +113,10 @@ def crown_news_encoder(sd, p, cfg, title_text, content_text, category, subCatego
     emb = sd[p + 'word_embedding.weight']
     title = emb[title_text.reshape(M, T).long()] + positional_encoding(T, E)          # :311,:315
     body = emb[content_text.reshape(M, L).long()] + positional_encoding(L, E)        # :312,:319
-    title_t = encoder_layer(title, sd, p + 'title_transformer.layers.0.', cfg.head_num)   # :316
-    body_t = encoder_layer(body, sd, p + 'body_transformer.layers.0.', cfg.head_num)      # :320
+    title_t, body_t = title, body
+    for li in range(getattr(cfg, 'num_layers', 1)):                                  # config.py:70 (1 or 2), newsEncoders.py:244-247
+        title_t = encoder_layer(title_t, sd, p + 'title_transformer.layers.%d.' % li, cfg.head_num)   # :316
+        body_t = encoder_layer(body_t, sd, p + 'body_transformer.layers.%d.' % li, cfg.head_num)      # :320
     title_e = title_t.mean(dim=1)                                                    # :317
     body_e = body_t.mean(dim=1)                                                      # :321
     cat = sd[p + 'category_embedding.weight'][category.reshape(M).long()]

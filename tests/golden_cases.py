@@ -107,6 +107,9 @@ CASES = {
                        B=4, N=3, seed=20, eval_shape=False, edit='none'),
     'fusion_gated': dict(cfg=dict(fusion_method='gated', max_history_num=6, max_title_length=8, max_abstract_length=16, batch_size=4, **_SMALL),
                          B=4, N=3, seed=21, eval_shape=False, edit='none'),
+    # config.py:70 allows num_layers = 2: two post-LN encoder layers per token encoder (newsEncoders.py:244-247)
+    'two_layers': dict(cfg=dict(num_layers=2, max_history_num=5, max_title_length=32, max_abstract_length=64, batch_size=3, **_SMALL),
+                       B=3, N=2, seed=22, eval_shape=False, edit='none'),
 }
 
 WEIGHT_SEED = 7

@@ -316,3 +316,31 @@ def test_one_captured_graph_follows_the_live_counts(kind, monkeypatch):
         print('%s batch %s: graph replay (compacted) vs eager dense %.2e' % (kind, name, e))
         assert torch.isfinite(got[name][0]).all() and e < tol, (kind, name, e)
     model.use_graph = True
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_two_encoder_layers(dtype, monkeypatch):
+    """num_layers = 2 (config.py:70 allows 1 or 2; newsEncoders.py:244-247) at a size that takes the big kernels: the compacted path
+    (layer 0 over the live tokens, layer 1 over the compact rows through the identity row map) against the dense path and the oracle."""
+    over = dict(vocabulary_size=20000, num_layers=2, batch_size=8)
+    if dtype == 'bf16':
+        over['compute_dtype'] = 'bf16'
+    cfg = make_config(**over)
+    model, sd = gpu_model(cfg, seed=71)
+    assert len(model.news_encoder.base_news_encoder.body_transformer.layers) == 2
+    batch = synth.make_batch(cfg, 8, 5, seed=72)
+    monkeypatch.setattr(newsEncoders, 'DEDUP', True)
+    got = run(model, batch, False)
+    model._graphs.clear()
+    monkeypatch.setattr(newsEncoders, 'DEDUP', False)
+    dense = run(model, batch, False)
+    model._graphs.clear()
+    want = O.model_forward(sd, cfg, batch)
+    e_dense, e_oracle = rel_err(got.numpy(), dense.numpy()), rel_err(got.numpy(), want.numpy())
+    print('two layers, %s: dedup vs dense %.2e, vs oracle %.2e' % (dtype, e_dense, e_oracle))
+    assert torch.isfinite(got).all()
+    if dtype == 'fp32':
+        assert e_dense < 2e-6 and e_oracle < 1e-3
+    else:
+        scale = float(want.abs()[want != 0].mean())
+        assert e_dense < 2e-5 and float((got - want).abs().max()) < 2e-2 * scale

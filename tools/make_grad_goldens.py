@@ -25,7 +25,7 @@ import ref_harness  # noqa: E402
 from lime_cikm25_amd import synth  # noqa: E402
 import golden_cases  # noqa: E402
 
-CASES = ('cfg1_crown', 'cfg1_mhsa', 'spill', 'empty_history', 'full_len', 'long_body')
+CASES = ('cfg1_crown', 'cfg1_mhsa', 'spill', 'empty_history', 'full_len', 'long_body', 'two_layers')
 KEEP = 2048
 
 
