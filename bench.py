@@ -80,7 +80,7 @@ WORKLOADS = {
              'eval-mode (per-candidate) semantics with every history encoded once (BASELINE.json configs[4]), fp32'),
 }
 # (workload, steps, warmup) run beside the default line so that the driver's own run times them
-ALSO = (('cfg2a', 100, 10), ('cfg3', 30, 5), ('cfg5', 3, 1), ('train2b', 30, 5), ('train4', 8, 2))
+ALSO = (('cfg2a', 100, 10), ('cfg3', 30, 5), ('cfg5', 3, 1), ('train2b', 30, 5), ('train2b_dropout', 10, 3), ('train4', 8, 2))
 N_BATCHES = 4           # distinct resident batches a scoring run rotates through
 
 
@@ -254,23 +254,69 @@ def kernel_profile(run, steps):
         newsEncoders.SERIAL_STREAMS = False
         ops.PROFILE = None
     by_kernel = {}
-    for (name, m, n, k, n_alg, e0, e1) in prof:
-        d = by_kernel.setdefault(name, [0.0, 0.0, 0.0, 0])
+    for rec in prof:
+        name, m, n, k, n_alg, e0, e1 = rec[:7]
+        gathered = rec[7] if len(rec) > 7 else 0
+        d = by_kernel.setdefault(name, [0.0, 0.0, 0.0, 0, 0.0, 0.0])
         d[0] += 2.0 * m * n_alg * k                    # algorithmic: the useful output columns
         d[1] += 2.0 * m * n * k                        # what the kernel computes (head padding included)
         d[2] += e0.elapsed_time(e1) * 1e-3
         d[3] += 1
+        d[5] += gathered                               # bytes of table rows the launch gathered as its A operand (a_ids)
     return by_kernel
+
+
+def gather_figures(run, by_kernel):
+    """The gather-bound embedding lookup of the path (newsEncoders.py:311-312; SURVEY.md 8d "K1"), against the HBM roofline:
+    (1) the stand-alone gather kernel (lime_embed_pe_f32: table rows by id + positional rows -> [tokens, E]; what the training path
+    with dropout runs) timed here on this workload's body ids with HIP events; (2) on the scoring path the gather is FUSED into the
+    in_proj GEMM's A fetch (an LDS-DMA per table row): bytes gathered per launch over the launch's duration -- a lower bound on the
+    rate the fetch sustains, the launch itself being bound by the matrix pipe."""
+    import torch
+    from lime_cikm25_amd import ops
+    cfg = run.cfg
+    if cfg.content_encoder != 'CROWN':
+        return None
+    enc = run.model.news_encoder.base_news_encoder
+    table, pe = enc.word_embedding.weight, enc.body_pos_encoder.table()
+    b = run.batches_cpu[0]
+    ids = torch.cat([b['news_content_text'].reshape(-1), b['user_content_text'].reshape(-1)]).to(torch.int32).cuda()
+    L, E = cfg.max_abstract_length, table.shape[1]
+    out = torch.empty((ids.numel(), E), dtype=torch.float32, device='cuda')
+    for _ in range(3):
+        ops.embed_pe(ids, table, pe, L, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        ops.embed_pe(ids, table, pe, L, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    nbytes = ids.numel() * (4 + 2 * E * 4)                    # id + gathered row read, result row written (the positional rows stay in cache)
+    res = {'embed_pe_kernel': {'tokens': ids.numel(), 'bytes': nbytes, 'us': round(sec * 1e6, 1), 'GB_per_s': round(nbytes / sec / 1e9, 1),
+                               'frac_of_hbm_peak': round(nbytes / sec / 1e9 / PEAK_HBM_GBS, 4), 'peak_GB_per_s': PEAK_HBM_GBS,
+                               'note': 'stand-alone gather + positional add (lime_embed_pe_f32) over every body token of one batch, padding '
+                                       'included; bytes = ids + gathered rows + result rows'}}
+    fused = [(k, v) for k, v in by_kernel.items() if v[5] > 0]
+    if fused:
+        k, v = max(fused, key=lambda kv: kv[1][2])
+        res['fused_in_proj_gather'] = {'kernel': k, 'gathered_bytes_per_launch': int(v[5] / v[3]), 'avg_launch_us': round(v[2] / v[3] * 1e6, 1),
+                                       'GB_per_s': round(v[5] / v[2] / 1e9, 1), 'frac_of_hbm_peak': round(v[5] / v[2] / 1e9 / PEAK_HBM_GBS, 4),
+                                       'note': 'word rows gathered by the in_proj GEMM itself (a_ids: one LDS-DMA per row and k chunk, three column '
+                                               'blocks re-gather a row panel, mostly from L2); the launch is bound by the matrix pipe, so this is '
+                                               'the rate the gather NEEDS there, not what the fetch path can sustain'}
+    return res
 
 
 def roofline(by_kernel, workload, steps):
     if not by_kernel:
         return None
-    name, (fl, flp, sec, cnt) = max(by_kernel.items(), key=lambda kv: kv[1][2])
+    name, (fl, flp, sec, cnt, _x, _g) = max(by_kernel.items(), key=lambda kv: kv[1][2])
     ach = fl / sec / 1e12
     traffic, source = None, None
-    tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if os.path.exists(tfile) and workload == 'cfg2b':       # the PMC passes were taken on this workload's launches
+    tfile = os.path.join(ROOT, 'profiles', 'traffic.json' if workload == 'cfg2b' else 'traffic_%s.json' % workload)
+    if os.path.exists(tfile):                               # the PMC passes were taken on this workload's launches
         tj = json.load(open(tfile))
         traffic = tj.get(name, {}).get('hbm_bytes_per_launch')
         source = tj.get('_source', 'profiles/traffic.json')
@@ -378,15 +424,19 @@ def bench_workload(name, steps, warmup, rank, world, dist, D, args, full=True):
         try:
             ddt, dlogits = timed(run, steps, 3, barrier)
             ddt = D.max_over_ranks(ddt, device='cuda')
+            dense_batch = (run.i - 1) % len(run.batches)        # the batch the last dense step scored
+            dlogits = dlogits.float().cpu()
         finally:
             newsEncoders.DEDUP = True
             run.model._graphs.clear()
+        run.i = dense_batch                                  # the default path on that very batch
+        default_logits = run.step().float().cpu()
         dense = {'value': round(world * B * steps / ddt, 2), 'ms_per_step': round(ddt / steps * 1e3, 4),
                  'note': 'LIME_DENSE_TOKENS=1: every token of every history / candidate slot goes through the encoder layer, padding '
                          'news and padding tokens included (what the reference computes); `value` is the default path, which encodes '
                          'all-padding sequences once and runs in_proj over the live tokens -- same logits',
-                 'max_abs_logit_difference_vs_default': float((dlogits.float().cpu() - run.step().float().cpu()).abs().max())
-                 if len(run.batches) == 1 else None}
+                 'max_abs_logit_difference_vs_default': float((dlogits - default_logits).abs().max()),
+                 'mean_abs_logit': float(default_logits.abs().mean())}
     by_kernel = kernel_profile(run, min(steps, 20) if full else min(steps, 5)) if rank == 0 else {}
     if dist is not None:
         dist.barrier()
@@ -411,6 +461,7 @@ def bench_workload(name, steps, warmup, rank, world, dist, D, args, full=True):
                    'streams': 'title / body / freshness / attention-weight branches forked' if args.overlap_streams else
                    'token encoders on one stream; freshness and attention-weight branches forked beside the head'},
         'roofline': roofline(by_kernel, name, min(steps, 20) if full else min(steps, 5)),
+        'gather': gather_figures(run, by_kernel) if (rank == 0 and full and not train) else None,
         'end_to_end': {'flops_per_impression': fimp, 'achieved_tflops': round(value * fimp / 1e12, 2),
                        'frac_of_f32_mfma_peak': round(value * fimp / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4)},
     }

@@ -152,7 +152,8 @@ def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=
         check(lib.lime_linear_f32(ctypes.byref(args), _stream()), 'lime_linear_f32')
         e1.record()
         m_run = M if m_dev is None else min(M, int(m_dev.item()))      # the rows this launch computed
-        PROFILE.append((lib.lime_last_linear_kernel().decode(), m_run, N, K, n_alg or N, e0, e1))
+        gathered = m_run * K * 4 if a_ids is not None else 0          # bytes of table rows this launch gathered as its A operand
+        PROFILE.append((lib.lime_last_linear_kernel().decode(), m_run, N, K, n_alg or N, e0, e1, gathered))
         return out
     check(lib.lime_linear_f32(ctypes.byref(args), _stream()), 'lime_linear_f32')
     return out

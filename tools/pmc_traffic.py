@@ -31,6 +31,7 @@ def main():
     ap.add_argument('write_csv')
     ap.add_argument('--json', required=True)
     ap.add_argument('--txt', required=True)
+    ap.add_argument('--source', default=None, help='what the passes were taken of (stored as _source, quoted by bench.py)')
     a = ap.parse_args()
     f, w = read(a.fetch_csv, 'FETCH_SIZE'), read(a.write_csv, 'WRITE_SIZE')
     res, lines = {}, ['# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/collect_profiles.sh) of `python bench.py --plain --steps 3 --warmup 2`',
@@ -38,7 +39,7 @@ def main():
                       '# reports half the bytes of a wide (16 B / lane) streaming read (MI355X_MICROARCH.md, HBM section).',
                       '# Per kernel the launches are listed in order (title shape first, then body shape; warm-up launch included).']
     for k in sorted(set(f) & set(w)):
-        if not (k.startswith('gemm') or k.startswith('token_attn') or k.startswith('mean_pool') or k.startswith('embed')):
+        if not k.startswith(('gemm', 'token_attn', 'mean_pool', 'embed', 'ffn_bf16', 'inproj_bf16', 'sage', 'gate_ln', 'interest_match', 'attn_')):
             continue
         n = min(len(f[k]), len(w[k]))
         per = [(2 * f[k][i] + w[k][i]) * 1024 for i in range(n)]
@@ -46,6 +47,8 @@ def main():
                   'hbm_bytes_each': [int(x) for x in per]}
         lines += [k, '    FETCH_SIZE KiB %s' % [int(x) for x in f[k][:n]], '    WRITE_SIZE KiB %s' % [int(x) for x in w[k][:n]],
                   '    corrected HBM bytes / launch: mean %.3e, largest (body shape) %.3e' % (sum(per) / n, max(per))]
+    if a.source:
+        res['_source'] = a.source
     json.dump(res, open(a.json, 'w'), indent=1)
     open(a.txt, 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines))
