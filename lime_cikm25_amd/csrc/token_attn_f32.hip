@@ -303,6 +303,79 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
                         qf[kk][2] = qraw[2 * kk + 1][0] * qscale; qf[kk][3] = qraw[2 * kk + 1][1] * qscale;
                     }
                 }
+                f32x16 o;
+                float inv;
+                if constexpr (NT > 8) {
+                    // ---- long sequences (S > 256: the 512-token bodies of BASELINE configs[3]): the score strip of a query would be
+                    // NT x 16 = 256 registers (the whole-strip form below spilled 158-273 of them to scratch).  Keys go in blocks of
+                    // four 32-key tiles with a running maximum: o and the probability sum are rescaled by exp2(m_old - m_new) when a
+                    // block raises the maximum (both half-waves of a query see the same m: it is taken across the halves).
+                    constexpr int KB = 4;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+                    float m = -INFINITY, sum = 0.f;
+                    for (int c0 = 0; c0 < NT; c0 += KB) {
+                        f32x16 sc[KB];
+#pragma unroll
+                        for (int tt = 0; tt < KB; ++tt) {
+                            const int t = c0 + tt;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) sc[tt][r] = 0.f;
+#pragma unroll
+                            for (int kk = 0; kk < 4; ++kk) {
+                                const f32x4 kf = *reinterpret_cast<const f32x4*>(&Kg[(t * 32 + fi) * LDH + kk * 8 + fh * 4]);
+#pragma unroll
+                                for (int u = 0; u < 4; ++u)
+                                    sc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[u], qf[kk][u], sc[tt], 0, 0, 0);
+                            }
+                        }
+                        if constexpr (!FAST) {
+#pragma unroll
+                            for (int tt = 0; tt < KB; ++tt) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const float f = Fg[(c0 + tt) * 32 + (r & 3) + 8 * (r >> 2) + krow];
+                                    const float v = sc[tt][r];
+                                    sc[tt][r] = (f == 2.f) ? -INFINITY : ((f == 1.f) ? masked : v);   // masked_fill(mask == 0, -1e9), layers.py:233
+                                }
+                            }
+                        }
+                        float mc = sc[0][0];
+#pragma unroll
+                        for (int tt = 0; tt < KB; ++tt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) mc = fmaxf(mc, sc[tt][r]);
+                        mc = fmaxf(mc, __shfl_xor(mc, 32));
+                        const float m_new = fmaxf(m, mc);      // finite from the first block on (key 0 is never padding)
+                        const float alpha = __builtin_amdgcn_exp2f(m - m_new);     // 0 on the first block (m = -inf), 1 when the maximum stands
+                        sum *= alpha;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[r] *= alpha;
+#pragma unroll
+                        for (int tt = 0; tt < KB; ++tt) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float e = __builtin_amdgcn_exp2f(sc[tt][r] - m_new);
+                                sc[tt][r] = e;
+                                sum += e;
+                            }
+                        }
+#pragma unroll
+                        for (int tt = 0; tt < KB; ++tt) {
+#pragma unroll
+                            for (int gq = 0; gq < 4; ++gq) {
+                                const f32x4 vv = *reinterpret_cast<const f32x4*>(&Vg[fi * LDVT + (c0 + tt) * 32 + gq * 8 + krow]);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    o = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[e], sc[tt][4 * gq + e], o, 0, 0, 0);
+                            }
+                        }
+                        m = m_new;
+                    }
+                    sum += __shfl_xor(sum, 32);
+                    inv = 1.0f / sum;
+                    ASTAMP(5)
+                } else {
                 // ---- S^T = K Q^T: keys on rows, this lane's query on the column (rows beyond S are zeros in LDS) ------
                 f32x16 sc[NT];
 #pragma unroll
@@ -348,10 +421,9 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
                     }
                 }
                 sum += __shfl_xor(sum, 32);
-                const float inv = 1.0f / sum;
+                inv = 1.0f / sum;
                 ASTAMP(4)
                 // ---- O^T = V^T P^T: probability registers are the B operand as they stand --------------------------
-                f32x16 o;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[r] = 0.f;
 #pragma unroll
@@ -366,6 +438,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
                     }
                 }
                 ASTAMP(5)
+                }
                 // ---- transpose [head dim][query] -> [query][head dim] through the scratch, store whole head rows ----
 #pragma unroll
                 for (int r = 0; r < 16; ++r) scr[fi * LDO + (r & 3) + 8 * (r >> 2) + krow] = o[r] * inv;

@@ -36,8 +36,6 @@ KNOWN_SCRATCH = {
     # boundary (residual loads into the accumulators, LayerNorm epilogue) spills, the chunk loop does not (ISA checked, profiles/r03_notes.md)
     r'^gemm_sp_kernel<10, (true|false), (true|false), [01], ': 192,
     r'^gemm_sp_kernel<10, true, false, 2, ': 1040,       # off by default (lime_set_split_gemm(3))
-    # whole-row register image of 512-key rows (round-3 item: key-block tiling)
-    r'^token_attn_kernel<16, ': 1096,
 }
 
 
