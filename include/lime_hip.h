@@ -543,11 +543,13 @@ int lime_relu_bwd_f32(float* dh, int64_t lddh, const float* h, int64_t ldh, int6
  * h at column h * head_stride; columns head_dim .. head_stride - 1 come out as zeros).  The probabilities are recomputed.
  * S <= 512, head_dim <= head_stride <= 32.  S <= 128: one pass per (sequence, head); `out` and `workspace` may be NULL.
  * 128 < S <= 512 (the 512-token bodies of BASELINE config 4): 128 x 128 blocks; needs the forward output `out` (packed like
- * dout) and lime_token_attention_bwd_workspace(n_seq, S, n_head) floats; the key blocks' shares of dq are added with float
- * atomics.  dropout_p > 0: the forward was lime_token_attention_dropout_f32 with the same (dropout_p, seed, site).
+ * dout) and lime_token_attention_bwd_workspace(n_seq, S, n_head) floats: the row statistics and one dq slab per key block behind the
+ * first -- the key blocks' shares of dq are stored (no atomics) and summed in block order, so the result is bitwise reproducible.  dropout_p > 0: the forward was lime_token_attention_dropout_f32 with the same (dropout_p, seed, site).
  * key_mask (uint8 [n_seq, S], 0 = masked, or NULL; S <= 128): the masked attention of layers.MultiHeadAttention
  * (layers.py:227-232) -- masked scores are constants (-1e9) and receive no gradient. */
 int64_t lime_token_attention_bwd_workspace(int32_t n_seq, int32_t S, int32_t n_head);
+/* the row-statistics part of it (lse and delta per (token, head)): what lime_token_attention_dropout_f32 needs for S > 128 */
+int64_t lime_token_attention_stats_workspace(int32_t n_seq, int32_t S, int32_t n_head);
 int lime_token_attention_bwd_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out, int64_t ld_out,
                                  const float* dout, int64_t ldo, float* dq, float* dk, float* dv, int64_t ld_dqkv, int32_t n_seq,
                                  int32_t S, int32_t n_head, int32_t head_dim, int32_t head_stride, float scale, float* workspace,

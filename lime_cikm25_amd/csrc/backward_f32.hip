@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(512) void attn_bwd_long_kernel(const float* __restr
                                                              long ldo, const float* __restrict__ stats, float* __restrict__ dq,
                                                              float* __restrict__ dk, float* __restrict__ dv, long ldd, int S,
                                                              int n_head, int head_dim, int head_stride, float scale, int n_blk,
-                                                             LimeDropout drop) {
+                                                             LimeDropout drop, float* __restrict__ dq_slabs, long n_tok) {
     constexpr int NT = LB / 16, LDP = LB + 2;
     extern __shared__ float smem[];
     float* Qs = smem;
@@ -1191,14 +1191,16 @@ __global__ __launch_bounds__(512) void attn_bwd_long_kernel(const float* __restr
             ak0 = mfma16(ds_col, Qs[j * AB_LD + fi], ak0);
             ak1 = mfma16(ds_col, Qs[j * AB_LD + 16 + fi], ak1);
         }
-        // this key block's share of dQ
+        // this key block's share of dQ: key block 0 stores straight into dq, block kb > 0 into slab kb - 1 ([tokens][n_head * 32]);
+        // attn_dq_reduce_kernel adds the slabs in block order -- no atomics, the result is bitwise reproducible
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = R0 + 4 * kg + r;
             if (row < q_valid) {
-                float* d = dq + (row_base + q0 + row) * ldd + (long)head * head_stride;
-                if (fi < head_stride) unsafeAtomicAdd(d + fi, aq0[r]);
-                if (16 + fi < head_stride) unsafeAtomicAdd(d + 16 + fi, aq1[r]);
+                float* d = kb == 0 ? dq + (row_base + q0 + row) * ldd + (long)head * head_stride
+                                   : dq_slabs + ((long)(kb - 1) * n_tok + row_base + q0 + row) * ((long)n_head * 32) + (long)head * 32;
+                if (fi < head_stride) d[fi] = aq0[r];
+                if (16 + fi < head_stride) d[16 + fi] = aq1[r];
             }
         }
     }
@@ -1210,6 +1212,21 @@ __global__ __launch_bounds__(512) void attn_bwd_long_kernel(const float* __restr
             if (fi < head_stride) { dv[o + fi] = av0[r]; dk[o + fi] = ak0[r]; }
             if (16 + fi < head_stride) { dv[o + 16 + fi] = av1[r]; dk[o + 16 + fi] = ak1[r]; }
         }
+    }
+}
+
+// dq[row, head * hs + j] += sum over slabs 0 .. n_slab - 1 (key blocks 1 ..) of slab[row][head * 32 + j], in slab order
+__global__ __launch_bounds__(256) void attn_dq_reduce_kernel(float* __restrict__ dq, long ldd, const float* __restrict__ slabs, long n_tok,
+                                                              int n_head, int hs, int n_slab) {
+    const long total = n_tok * n_head * hs;
+    const long wcols = (long)n_head * 32;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long row = e / (n_head * hs);
+        const int c = (int)(e - row * (n_head * hs));
+        const int head = c / hs, j = c - head * hs;
+        float t = dq[row * ldd + c];
+        for (int b = 0; b < n_slab; ++b) t += slabs[((long)b * n_tok + row) * wcols + head * 32 + j];
+        dq[row * ldd + c] = t;
     }
 }
 
@@ -1604,8 +1621,15 @@ int launch_attn_fwd_dropout(const float* q, const float* k, const float* v, long
 }
 }  // namespace
 
+extern "C" int64_t lime_token_attention_stats_workspace(int32_t n_seq, int32_t S, int32_t n_head) {
+    return S > 128 ? (int64_t)n_seq * S * n_head * 2 : 0;            // lse and delta per (token, head) for the blocked paths
+}
+
 extern "C" int64_t lime_token_attention_bwd_workspace(int32_t n_seq, int32_t S, int32_t n_head) {
-    return S > 128 ? (int64_t)n_seq * S * n_head * 2 : 0;            // lse and delta per (token, head) for the blocked path
+    if (S <= 128) return 0;
+    const int64_t n_blk = (S + LB - 1) / LB;
+    // the row statistics + one [tokens][n_head * 32] slab per key block behind the first (their shares of dq, summed in block order)
+    return lime_token_attention_stats_workspace(n_seq, S, n_head) + (n_blk - 1) * (int64_t)n_seq * S * n_head * 32;
 }
 
 extern "C" int lime_token_attention_bwd_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out,
@@ -1636,8 +1660,9 @@ extern "C" int lime_token_attention_bwd_f32(const float* q, const float* k, cons
     const int n_blk = (S + LB - 1) / LB;
     const long n_prob = (long)n_seq * n_head;
     LIME_REQUIRE(n_prob * n_blk < 0x7FFFFFFFL, LIME_ERR_UNSUPPORTED, "lime_token_attention_bwd_f32: too many blocks");
-    hipError_t e = hipMemset2DAsync(dq, (size_t)ld_dqkv * 4, 0, (size_t)n_head * head_stride * 4, (size_t)n_seq * S, s);
-    LIME_REQUIRE(e == hipSuccess, LIME_ERR_LAUNCH, "lime_token_attention_bwd_f32: clearing dq failed: %s", hipGetErrorString(e));
+    hipError_t e = hipSuccess;
+    float* const dq_slabs = workspace + lime_token_attention_stats_workspace(n_seq, S, n_head);
+    const long n_tok = (long)n_seq * S;
     attn_stats_kernel<<<(unsigned)(n_prob * n_blk), 512, 0, s>>>(q, k, ld_qkv, out, ld_out, dout, ldo, workspace, S, n_head, head_dim,
                                                               head_stride, scale, n_blk);
     int st = lime_check_launch("attn_stats_kernel");
@@ -1651,8 +1676,13 @@ extern "C" int lime_token_attention_bwd_f32(const float* q, const float* k, cons
         configured = true;
     }
     attn_bwd_long_kernel<<<(unsigned)(n_prob * n_blk), 512, BYTES, s>>>(q, k, v, ld_qkv, dout, ldo, workspace, dq, dk, dv, ld_dqkv, S,
-                                                                       n_head, head_dim, head_stride, scale, n_blk, drop);
-    return lime_check_launch("attn_bwd_long_kernel");
+                                                                       n_head, head_dim, head_stride, scale, n_blk, drop, dq_slabs, n_tok);
+    st = lime_check_launch("attn_bwd_long_kernel");
+    if (st != LIME_OK || n_blk == 1) return st;
+    const long total = n_tok * n_head * head_stride;
+    attn_dq_reduce_kernel<<<(unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256), 256, 0, s>>>(dq, ld_dqkv, dq_slabs, n_tok, n_head,
+                                                                                                          head_stride, n_blk - 1);
+    return lime_check_launch("attn_dq_reduce_kernel");
 }
 
 extern "C" int lime_token_attention_dropout_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, float* out, int64_t ldo,
@@ -1672,7 +1702,7 @@ extern "C" int lime_token_attention_dropout_f32(const float* q, const float* k, 
     if (S <= 32) return launch_attn_fwd_dropout<32>(q, k, v, ld_qkv, out, ldo, n_seq, S, n_head, head_dim, head_stride, scale, drop, s);
     if (S <= 64) return launch_attn_fwd_dropout<64>(q, k, v, ld_qkv, out, ldo, n_seq, S, n_head, head_dim, head_stride, scale, drop, s);
     if (S <= 128) return launch_attn_fwd_dropout<128>(q, k, v, ld_qkv, out, ldo, n_seq, S, n_head, head_dim, head_stride, scale, drop, s);
-    LIME_REQUIRE(workspace && workspace_floats >= lime_token_attention_bwd_workspace(n_seq, S, n_head), LIME_ERR_BAD_ARG,
+    LIME_REQUIRE(workspace && workspace_floats >= lime_token_attention_stats_workspace(n_seq, S, n_head), LIME_ERR_BAD_ARG,
                  "lime_token_attention_dropout_f32: S > 128 needs lime_token_attention_bwd_workspace() floats of workspace");
     const int n_blk = (S + LB - 1) / LB;
     const long n_prob = (long)n_seq * n_head;

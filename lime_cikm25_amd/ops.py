@@ -1111,7 +1111,7 @@ def token_attention_dropout(q, k, v, n_seq, S, n_head, head_dim, scale, p, seed,
     if not (_ld(q) == _ld(k) == _ld(v)):
         raise ValueError('q, k, v must share one leading dimension')
     out = torch.empty((n_seq * S, n_head * head_dim), dtype=torch.float32, device=q.device)
-    need = lib.lime_token_attention_bwd_workspace(n_seq, S, n_head)
+    need = lib.lime_token_attention_stats_workspace(n_seq, S, n_head)
     ws = _workspace(q.device, need) if need else None
     check(lib.lime_token_attention_dropout_f32(_p(q), _p(k), _p(v), _ld(q), _p(out), _ld(out), n_seq, S, n_head, head_dim, hs, scale,
                                                p, seed, site, _p(ws), ws.numel() if ws is not None else 0, _stream()),

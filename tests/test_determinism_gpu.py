@@ -33,8 +33,11 @@ def test_sorted_scatter_equals_index_add_and_is_reproducible(rows, vocab, dim, p
     assert bool((outs[0][untouched] == 0).all())
 
 
-def test_training_step_is_bitwise_reproducible():
-    cfg = make_config(vocabulary_size=5000, max_history_num=20, max_title_length=32, max_abstract_length=128, batch_size=16)
+@pytest.mark.parametrize('L', [128, 512])
+def test_training_step_is_bitwise_reproducible(L):
+    """L = 512 (BASELINE configs[3]'s bodies) takes the blocked attention backward: the key blocks' shares of dq are stored to slabs
+    and summed in block order (round 2 added them with float atomics: not reproducible)."""
+    cfg = make_config(vocabulary_size=5000, max_history_num=20 if L == 128 else 6, max_title_length=32, max_abstract_length=L, batch_size=16)
     batch = None
     flats, losses = [], []
     for _ in range(2):
