@@ -560,10 +560,21 @@ __global__ __launch_bounds__(64) void cand_attn_head_kernel(const float* __restr
     float* Kh = sm + N * hdp;                      // [H][hdp]
     float* P = ws + ((long)blockIdx.x * N) * (H + 1);             // [N][H] probabilities, then [N] squared-norm shares behind them
     float* q2out = P + (long)N * H;
-    // a row's head slice is hd contiguous floats: one coalesced load per row, all rows in flight
-    for (int r = 0; r < N + H; ++r) {
-        const float* src = r < N ? qp + ((long)b * N + r) * D + head * hd : kp + ((long)b * H + (r - N)) * D + head * hd;
-        for (int j = lane; j < hd; j += 64) sm[r * hdp + j] = src[j];
+    // a row's head slice is hd contiguous floats: one coalesced load per row, eight rows in flight (a load -> LDS store chain per
+    // row made the 55 rows 55 L2 round trips)
+    for (int j = lane; j < hd; j += 64) {
+        for (int r0 = 0; r0 < N + H; r0 += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + u;
+                const float* src = r < N ? qp + ((long)b * N + r) * D + head * hd : kp + ((long)b * H + (r - N)) * D + head * hd;
+                t[u] = r < N + H ? src[j] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (r0 + u < N + H) sm[(r0 + u) * hdp + j] = t[u];
+        }
     }
     wave_lds_fence();
     for (int n = lane; n < N; n += 64) {
@@ -618,7 +629,13 @@ __global__ __launch_bounds__(256) void cand_attn_finish_kernel(const float* __re
     const long hstride = (long)N * (H + 1);
     for (int n = threadIdx.x; n < N; n += 256) {
         float t = 0.f;
-        for (int hh = 0; hh < n_head; ++hh) t += base[hh * hstride + (long)N * H + n];
+        for (int h0 = 0; h0 < n_head; h0 += 16) {
+            float u[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) u[k] = h0 + k < n_head ? base[(h0 + k) * hstride + (long)N * H + n] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += u[k];               // head order
+        }
         qn[n] = sqrtf(t);
     }
     __syncthreads();
@@ -630,7 +647,13 @@ __global__ __launch_bounds__(256) void cand_attn_finish_kernel(const float* __re
         float acc = 0.f;
         for (int n = 0; n < N; ++n) {
             float a = 0.f;
-            for (int hh = 0; hh < n_head; ++hh) a += base[hh * hstride + (long)n * H + h];
+            for (int h0 = 0; h0 < n_head; h0 += 16) {              // a batch of heads in flight, added in head order
+                float u[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) u[k] = h0 + k < n_head ? base[(h0 + k) * hstride + (long)n * H + h] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) a += u[k];
+            }
             acc += a * (expf(qn[n] - qmx) / qden);
         }
         v[h] = acc;
@@ -828,12 +851,13 @@ __global__ __launch_bounds__(256) void gate_ln_kernel(const float* __restrict__ 
 // and written to out[g * H + h]; the column sums over the first n_hist node slots + `node_const` (the sum of the user-node rows the
 // mean also covers: the same vector for every row) times inv_n are the SAGEConv aggregate mean_out[g].  A wave owns a row at a time
 // (row statistics by wave shuffles); the four waves' column sums are added in wave order.  D <= 512.
-__global__ __launch_bounds__(256) void gate_ln_sage_kernel(const float* __restrict__ y, const float* __restrict__ x,
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void gate_ln_sage_kernel(const float* __restrict__ y, const float* __restrict__ x,
                                                             const float* __restrict__ scale, const float* __restrict__ bias,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                             float* __restrict__ out, const float* __restrict__ node_const,
                                                             float* __restrict__ mean_out, int H, int D, int row_div, int n_hist, float inv_n) {
-    __shared__ float part[4][512];
+    __shared__ float part[NW][512];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long g = blockIdx.x;
     const long src = (g / row_div) * H;
@@ -849,7 +873,7 @@ __global__ __launch_bounds__(256) void gate_ln_sage_kernel(const float* __restri
         csum[j] = 0.f;
     }
     const float inv_d = 1.0f / (float)D;
-    for (int h = wave; h < H; h += 4) {
+    for (int h = wave; h < H; h += NW) {
         const float s = scale[g * H + h];
         const float* xr = x + (src + h) * D;
         const float* yr = y + (src + h) * D;
@@ -888,8 +912,10 @@ __global__ __launch_bounds__(256) void gate_ln_sage_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < 8; ++j) part[wave][lane + 64 * j] = csum[j];
     __syncthreads();
-    for (int d = threadIdx.x; d < D; d += 256) {
-        float t = ((part[0][d] + part[1][d]) + part[2][d]) + part[3][d];
+    for (int d = threadIdx.x; d < D; d += NW * 64) {
+        float t = part[0][d];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) t += part[w][d];          // wave order: fixed
         if (node_const) t += node_const[d];
         mean_out[g * D + d] = t * inv_n;
     }
@@ -1318,8 +1344,15 @@ extern "C" int lime_gate_ln_sage_f32(const float* y, const float* x, const float
     LIME_REQUIRE(n_src <= H || node_const, LIME_ERR_BAD_ARG, "lime_gate_ln_sage_f32: n_src %d > H %d needs node_const", n_src, H);
     LIME_REQUIRE(groups < 0x7FFFFFFFL, LIME_ERR_UNSUPPORTED, "lime_gate_ln_sage_f32: too many rows");
     if (groups == 0) return LIME_OK;
-    hipLaunchKernelGGL(gate_ln_sage_kernel, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, y, x, scale, bias, gamma, beta, eps, out,
-                       n_src > H ? node_const : nullptr, mean_out, H, D, row_div, n_src < H ? n_src : H, 1.0f / (float)n_src);
+    // few rows (a training-shape batch: 32 .. 256 user rows): sixteen waves share a row's H history rows, the launch is a latency chain
+    // otherwise; many rows (the scoring layout): four waves per workgroup, more workgroups per CU.  (The wave count changes the order
+    // in which a column's H values are added: the two forms differ by fp32 rounding, each is deterministic.)
+    if (groups < 4096)
+        hipLaunchKernelGGL(gate_ln_sage_kernel<16>, dim3((unsigned)groups), dim3(1024), 0, (hipStream_t)stream, y, x, scale, bias, gamma, beta, eps,
+                           out, n_src > H ? node_const : nullptr, mean_out, H, D, row_div, n_src < H ? n_src : H, 1.0f / (float)n_src);
+    else
+        hipLaunchKernelGGL(gate_ln_sage_kernel<4>, dim3((unsigned)groups), dim3(256), 0, (hipStream_t)stream, y, x, scale, bias, gamma, beta, eps,
+                           out, n_src > H ? node_const : nullptr, mean_out, H, D, row_div, n_src < H ? n_src : H, 1.0f / (float)n_src);
     return lime_check_launch("lime_gate_ln_sage_f32");
 }
 
