@@ -207,7 +207,17 @@ class Model(nn.Module):
         hist = ne.encode_cached(news_cache, hist_idx, b.user_freshness[rows], b.user_lifetime[rows]).view(R, H, -1)
         cand = ne.encode_cached(news_cache, cand_idx, b.cand_freshness[rows], b.cand_lifetime[rows]).view(R, 1, -1)
         flat_h, flat_c = hist_idx.reshape(-1).long(), cand_idx.reshape(-1).long()
-        remaining = (b.cand_lifetime[rows] - b.cand_freshness[rows])                      # util.py:98-106 (lifetime_type user_topic)
+        # the remaining lifetime per config.lifetime_type, as util.py:98-106 derives it from the batch
+        lt = getattr(self.config, 'lifetime_type', 'user_topic')
+        if lt == 'fixed':
+            remaining = self.config.fixed_lifetime - b.cand_freshness[rows]
+        elif lt == 'topic_wise':
+            cmap = torch.as_tensor(self.config.category_lifetime_map, dtype=torch.float32, device=dev)
+            remaining = cmap[c.news_category[cand_idx.reshape(-1).long()].long()].view_as(b.cand_freshness[rows]) - b.cand_freshness[rows]
+        elif lt == 'user_topic':
+            remaining = (b.cand_lifetime[rows] - b.cand_freshness[rows])
+        else:
+            raise ValueError('Invalid lifetime_type')
         if n_src is None:
             n_src = min(R, H + ue.user_node_embedding.shape[0])
         _, logits = ue.match(hist, c.news_category[flat_c].view(R, 1), c.news_subCategory[flat_c].view(R, 1),

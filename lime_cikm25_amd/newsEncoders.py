@@ -888,7 +888,9 @@ class CROWN(NewsEncoder):
                     (content_text, self.body_pos_encoder, self.body_transformer, L))
         step_of = lambda S: min(max(1, MAX_TOKENS_PER_PASS // S),
                                 # the compacted in_proj scatters rows with 32-bit byte offsets from the base of qkv ([rows, 3 * 320])
-                                max(1, (0x7FFFFFF0 // (3 * self.head_num * 32 * (2 if bf16 else 4))) // S - 2) if DEDUP else M)
+                                max(1, (0x7FFFFFF0 // (3 * self.head_num * 32 * (2 if bf16 else 4))) // S - 2) if DEDUP else M,
+                                # the fused bf16 entry points address a pass's rows with 32-bit byte offsets ([rows, 304] bf16)
+                                max(1, (0x7FFFFFF0 // (((E + 7) // 8 * 8) * 2)) // S - 2) if bf16 else M)
         one_pass = (not bf16 and all(M <= step_of(S) and compact_applicable(ids, table, tr, self.head_num)
                                      for ids, pos, tr, S in encoders))
         if one_pass:
@@ -975,6 +977,14 @@ class MHSA(NewsEncoder):
         pooled_c = ops.additive_pool(hidden, self.attention.affine2.weight.view(-1), c, n + 1, T, mask=mask_c)
         ops.gather_rows(cmp.seq_inv, pooled_c, out)
 
+    def _compact_applicable(self, ids, n, T):
+        """The compacted title path rests on the device-count forms of the kernels, which are stricter than the dense ones:
+        lime_linear_f32 with m_dev needs 16-byte friendly operands (K and N multiples of 4), lime_token_attention with a device count
+        head_dim <= 32 and T <= 512.  Anything else takes the dense branch."""
+        mha = self.multiheadAttention
+        return (DEDUP and (n + 1) * T >= 4096 and ids.dtype == torch.int32 and ids.is_contiguous() and mha.d_model % 4 == 0 and
+                (3 * mha.h * mha.d_k) % 4 == 0 and mha.d_k <= 32 and mha.d_v <= 32 and T <= 512)
+
     def __init__(self, config):
         super().__init__(config)
         self.max_sentence_length = config.max_title_length
@@ -1001,7 +1011,7 @@ class MHSA(NewsEncoder):
         for m0 in range(0, M, step):
             m1 = min(M, m0 + step)
             ids = title_text[m0:m1]
-            if DEDUP and (m1 - m0 + 1) * T >= 4096 and ids.dtype == torch.int32 and ids.is_contiguous():
+            if self._compact_applicable(ids, m1 - m0, T):
                 self._encode_compact(ids, mask[m0:m1], out[m0:m1, :F])
                 continue
             qkv = mha.project(table=self.word_embedding.weight, ids=ids.reshape(-1))                    # :588 + layers.py:224-226

@@ -1122,10 +1122,13 @@ def token_attention_dropout(q, k, v, n_seq, S, n_head, head_dim, scale, p, seed,
 DETERMINISTIC_EMBED_BWD = True      # word-table gradient by sort + segmented sum (no atomics); False: the float-atomic kernel
 
 
-def embed_bwd(ids, dx, dtable, hot_id=0):
-    """dtable[ids[r]] += dx[r] for a ZEROED dtable.  Tables of <= 32 rows: atomic-free LDS accumulation; larger tables with
-    dim <= 320: stable sort of the positions by id + segmented sum in a fixed order (lime_embed_bwd_sorted_f32: bitwise
-    reproducible); otherwise (or with DETERMINISTIC_EMBED_BWD off) float atomics."""
+def embed_bwd(ids, dx, dtable, hot_id=0, accumulate=False):
+    """dtable[ids[r]] = sum of dx[r] over the rows with that id, for a dtable the caller ZEROED (rows no id names are left alone).
+    Tables of <= 32 rows: atomic-free LDS accumulation; larger tables with dim <= 320: stable sort of the positions by id +
+    segmented sum in a fixed order (lime_embed_bwd_sorted_f32: bitwise reproducible) -- this back end STORES each touched row, the
+    other two ADD into it, so a dtable that already holds a gradient needs ``accumulate=True`` (the sorted back end then sums into a
+    zeroed scratch table and adds it: the same result on every back end); otherwise (or with DETERMINISTIC_EMBED_BWD off) float
+    atomics."""
     lib = _lib.load()
     _vec(ids, 'ids', dtype=torch.int32)
     _mat(dx, 'dx')
@@ -1137,6 +1140,8 @@ def embed_bwd(ids, dx, dtable, hot_id=0):
                                            dtable.shape[0], _stream()), 'lime_embed_bwd_small_f32')
         return dtable
     if DETERMINISTIC_EMBED_BWD and dx.shape[1] <= 320 and ids.numel() > 0:
+        if accumulate:
+            return dtable.add_(embed_bwd(ids, dx, torch.zeros_like(dtable), hot_id))
         sorted_ids, order = torch.sort(ids, stable=True)
         order = order.to(torch.int32)
         need = int(lib.lime_embed_bwd_sorted_workspace(ids.numel(), dx.shape[1]))

@@ -91,10 +91,11 @@ def compute_scores_cached(model, behaviors, indices, result_file, truth_file=Non
     (util.py:86-111).  ``behaviors``: a dev / test ``DeviceBehaviors``.  Rows are scored in chunks of ``rows_per_forward`` (default:
     config.batch_size, as trainer.py:153 calls compute_scores; main.py:50,67 pass twice that, which only fits while
     2 x batch_size <= H + config.batch_size node slots) with the chunk's row count as the GraphSAGE source count, so the scores
-    are those of ``compute_scores`` over the same batches; lifetime_type 'user_topic' (config.py:62)."""
+    are those of ``compute_scores`` over the same batches; the remaining lifetime follows ``config.lifetime_type``
+    ('fixed' / 'topic_wise' / 'user_topic', util.py:98-106)."""
     config = model.config
-    if config.lifetime_type != 'user_topic':
-        raise NotImplementedError("the cached pass derives the remaining lifetime as lifetime_type 'user_topic' does")
+    if config.lifetime_type not in ('fixed', 'topic_wise', 'user_topic'):
+        raise ValueError('Invalid lifetime_type')
     per = rows_per_forward or config.batch_size
     slots = behaviors.hist_index.shape[1] + model.user_encoder.user_node_embedding.shape[0]
     if per > slots:

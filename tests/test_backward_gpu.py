@@ -140,6 +140,24 @@ def test_embed_bwd(ops):
     close(got, want, tol=2e-4, what='embedding gradient, no hot row')
 
 
+def test_embed_bwd_into_a_table_that_holds_a_gradient(ops):
+    """accumulate=True: every back end ADDS to what dtable holds (the sorted back end alone would store over the touched rows)."""
+    V, D, rows = 700, 300, 9000
+    g = torch.Generator().manual_seed(8)
+    ids1 = torch.randint(0, V, (rows,), generator=g, dtype=torch.int32)
+    ids2 = torch.randint(0, V, (rows,), generator=g, dtype=torch.int32)
+    dx1, dx2 = rnd(rows, D, seed=9), rnd(rows, D, seed=10)
+    want = torch.zeros(V, D, dtype=torch.float64).index_add_(0, ids1.long(), dx1.double()).index_add_(0, ids2.long(), dx2.double()).float()
+    for det in (True, False):
+        ops.DETERMINISTIC_EMBED_BWD = det
+        try:
+            t = ops.embed_bwd(ids1.cuda(), dx1.cuda(), torch.zeros(V, D, device='cuda'), hot_id=0)
+            t = ops.embed_bwd(ids2.cuda(), dx2.cuda(), t, hot_id=0, accumulate=True)
+        finally:
+            ops.DETERMINISTIC_EMBED_BWD = True
+        close(t, want, tol=2e-4, what='two calls into one table (deterministic back end %s)' % det)
+
+
 def test_embed_bwd_small_table(ops):
     T, D, rows = 10, 500, 1760
     g = torch.Generator().manual_seed(5)

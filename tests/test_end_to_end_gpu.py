@@ -59,6 +59,17 @@ def test_files_to_metrics(tmp_path):
     assert cached == (auc, mrr, ndcg5, ndcg10)
     ranks = [json.loads(line.split(' ', 1)[1]) for line in open(tmp_path / 'rank.txt')]
     assert [sorted(r) for r in ranks] == [list(range(1, len(lab) + 1)) for lab in formats.truth_labels(L['dev_behaviors'])]
+    # the other two ways the reference derives the remaining lifetime (util.py:98-106): the cached pass follows config.lifetime_type
+    # exactly as compute_scores does
+    for lt in ('fixed', 'topic_wise'):
+        cfg.lifetime_type = lt
+        cfg.fixed_lifetime = 5 * 3600
+        cfg.category_lifetime_map = torch.linspace(600.0, 9e4, cfg.category_num)
+        a = util.compute_scores(model, batches, corpus.dev_indices, str(tmp_path / ('rank_%s.txt' % lt)), str(truth))
+        b = util.compute_scores_cached(model, dev, corpus.dev_indices, str(tmp_path / ('rank_cached_%s.txt' % lt)), str(truth), rows_per_forward=dev.num)
+        assert open(tmp_path / ('rank_cached_%s.txt' % lt)).read() == open(tmp_path / ('rank_%s.txt' % lt)).read(), lt
+        assert a == b
+    cfg.lifetime_type = 'user_topic'
 
 
 def test_trainer_loop_selects_and_saves_the_best_epoch(tmp_path):
