@@ -140,6 +140,49 @@ def kernel_resources(objs):
     return res
 
 
+SAN_LIB = os.path.join(_HERE, '..', 'build', 'liblime_hip_san.so')
+SAN_FLAGS = ['-O1', '-g', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-fsanitize=address,undefined', '-fno-omit-frame-pointer',
+             '-fno-sanitize-recover=undefined', '-Wno-option-ignored']
+
+
+def build_sanitized(verbose=False):
+    """The library's HOST pass under AddressSanitizer + UndefinedBehaviorSanitizer (the sanitizer build of the
+    reference's tooling; GPU sanitizers are not available on this pool): every unit recompiled with -fsanitize=address,undefined
+    -- hipcc applies it to the host code (argument validation, dispatch, launch geometry, workspace sizing) and ignores it for the
+    gfx950 pass -- into build/liblime_hip_san.so.  tests/test_sanitizers.py drives it without a GPU, from an instrumented C driver (a python with
+    the ASan runtime preloaded does not start in this container)."""
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    objdir = os.path.join(_HERE, '..', 'build', 'obj_san')
+    os.makedirs(objdir, exist_ok=True)
+    want = hashlib.sha256((source_hash() + ' '.join(SAN_FLAGS)).encode()).hexdigest()
+    stamp = SAN_LIB + '.sha256'
+    try:
+        if os.path.exists(SAN_LIB) and open(stamp).read().strip() == want:
+            return SAN_LIB
+    except OSError:
+        pass
+    procs, objs = [], []
+    jobs = max(1, min((os.cpu_count() or 2) - 1, 7))
+    for src in sorted(sources(), key=lambda p: -os.path.getsize(p)):
+        obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + '.o')
+        objs.append(obj)
+        while len([p for p in procs if p.poll() is None]) >= jobs:
+            [p for p in procs if p.poll() is None][0].wait()
+        cmd = [hipcc] + SAN_FLAGS + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        procs.append(subprocess.Popen(cmd, cwd=CSRC, stderr=subprocess.DEVNULL))
+    for p in procs:
+        if p.wait() != 0:
+            raise RuntimeError('sanitized compile failed')
+    # the sanitizer runtime itself comes from the (instrumented) executable that loads the library
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-fsanitize=address,undefined', '-o', SAN_LIB] + objs,
+                   check=True, cwd=CSRC, stderr=subprocess.DEVNULL)
+    with open(stamp, 'w') as f:
+        f.write(want + '\n')
+    return SAN_LIB
+
+
 def build_library(force=False, verbose=False):
     """Compile every HIP source into lime_cikm25_amd/liblime_hip.so; returns the path.  Sets LAST_ACTION and prints one line
     saying whether the library was compiled or reused, with the source hash."""
