@@ -337,6 +337,110 @@ class _TokenEncoder(torch.autograd.Function):
                 dn1_b, dn2_w, dn2_b)
 
 
+class _EmbedPE(torch.autograd.Function):
+    """x0 [M S, E] = drop(drop(E[ids]) + PE[t]) (newsEncoders.py:311-312, :827): the layer input, materialised -- the entry of the
+    num_layers > 1 path (the single-layer node above gathers it inside its in_proj GEMM)."""
+
+    @staticmethod
+    def forward(ctx, ids, table, pe, p, seed):
+        M, S = ids.shape
+        flat = ids.reshape(-1).contiguous()
+        ctx.cfg = (S, p, seed)
+        ctx.save_for_backward(flat, table)
+        if p > 0:
+            return ops.embed_pe_dropout(flat, table, pe, S, p, seed, _SITE_EMB, _SITE_PE)
+        return ops.embed_pe(flat, table, pe, S)
+
+    @staticmethod
+    def backward(ctx, dx0):
+        flat, table = ctx.saved_tensors
+        S, p, seed = ctx.cfg
+        if not ctx.needs_input_grad[1]:
+            return None, None, None, None, None
+        dx0 = dx0.contiguous()
+        if p > 0:                                                                  # back through the two input dropouts
+            dx0 = ops.dropout(dx0, p, seed, _SITE_PE)
+            ops.dropout(dx0, p, seed, _SITE_EMB, out=dx0)
+        dtable = torch.zeros_like(table)
+        ops.embed_bwd(flat, dx0, dtable, hot_id=0)
+        return None, dtable, None, None, None
+
+
+class _EncoderLayer(torch.autograd.Function):
+    """y [M S, E] = one post-LN TransformerEncoderLayer over a MATERIALISED input x (newsEncoders.py:244-247): what a layer behind the
+    first needs (config.py:70 allows num_layers = 2), and the first one on that path too.  Same kernels as ``_TokenEncoder`` -- in_proj,
+    attention, out_proj + residual + LayerNorm, linear1 + ReLU, linear2 + residual + LayerNorm, with the four in-layer dropouts on the
+    counter-based masks when p > 0 -- with a dense residual instead of the gathered one, and dx as the input gradient."""
+
+    @staticmethod
+    def forward(ctx, x, M, S, nhead, eps1, eps2, p, seed, in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w, n2_b):
+        x = x.contiguous()
+        E = x.shape[1]
+        hd = E // nhead
+        hs = 32 if hd <= 32 else hd
+        if hs > 32 or S > 512:
+            raise NotImplementedError('the attention kernels cover head_dim <= 32 and S <= 512 (got %d, %d)' % (hd, S))
+        W = nhead * hs
+        tok = M * S
+        dev = x.device
+        scale = 1.0 / math.sqrt(hd)
+        w_in = ops.pad_heads(in_w, 3 * nhead, hd, hs) if hs != hd else in_w
+        b_in = ops.pad_heads(in_b, 3 * nhead, hd, hs) if hs != hd else in_b
+        qkv = ops.linear(x, w_in, b_in, n_alg=3 * E)
+        if p > 0:
+            ao = ops.token_attention_dropout(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, scale, p, seed, _SITE_ATTN,
+                                             head_stride=hs)
+            x1, rstd1 = ops.dropout_add_layernorm(ops.linear(ao, out_w, out_b), x, n1_w, n1_b, eps1, p, seed, _SITE_DROP1)
+            h = ops.linear(x1, l1_w, l1_b, act='relu')
+            ops.dropout(h, p, seed, _SITE_FF, out=h)
+            y, rstd2 = ops.dropout_add_layernorm(ops.linear(h, l2_w, l2_b), x1, n2_w, n2_b, eps2, p, seed, _SITE_DROP2)
+        else:
+            ao = ops.token_attention(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, scale, head_stride=hs)
+            rstd1 = torch.empty(tok, dtype=torch.float32, device=dev)
+            x1 = ops.linear(ao, out_w, out_b, res=x, ln=(n1_w, n1_b), ln_eps=eps1, ln_rstd=rstd1)
+            h = ops.linear(x1, l1_w, l1_b, act='relu')
+            rstd2 = torch.empty(tok, dtype=torch.float32, device=dev)
+            y = ops.linear(h, l2_w, l2_b, res=x1, ln=(n2_w, n2_b), ln_eps=eps2, ln_rstd=rstd2)
+        ctx.dims = (M, S, E, nhead, hd, hs, p, seed)
+        ctx.save_for_backward(x, w_in, out_w, l1_w, l2_w, n1_w, n1_b, n2_w, n2_b, qkv, ao, x1, rstd1, h, y, rstd2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x, w_in, out_w, l1_w, l2_w, n1_w, n1_b, n2_w, n2_b, qkv, ao, x1, rstd1, h, y, rstd2) = ctx.saved_tensors
+        M, S, E, nhead, hd, hs, p, seed = ctx.dims
+        W = nhead * hs
+        drop = p > 0
+        keep_scale = 1.0 / (1.0 - p) if drop else 1.0
+        dz2, dn2_w, dn2_b, dl2_b = ops.layernorm_bwd(dy.contiguous(), y, n2_w, n2_b, rstd2, want_dzsum=not drop)
+        dt2 = ops.dropout(dz2, p, seed, _SITE_DROP2) if drop else dz2              # the branch through dropout2 into linear2
+        if drop:
+            dl2_w, dl2_b = ops.linear_wgrad(dt2, h, want_bias=True)
+        else:
+            dl2_w = ops.linear_wgrad(dt2, h)
+        dh = ops.linear(dt2, l2_w.t().contiguous(), None)
+        ops.relu_bwd_(dh, h, keep_scale)                                           # h > 0 <=> ReLU passed and the mask kept
+        dl1_w, dl1_b = ops.linear_wgrad(dh, x1, want_bias=True)
+        dx1 = ops.linear(dh, l1_w.t().contiguous(), None, res=dz2)                 # through linear1 + the residual branch
+        del dh, dz2
+        dz1, dn1_w, dn1_b, dout_b = ops.layernorm_bwd(dx1, x1, n1_w, n1_b, rstd1, want_dzsum=not drop)
+        del dx1
+        dt1 = ops.dropout(dz1, p, seed, _SITE_DROP1) if drop else dz1
+        if drop:
+            dout_w, dout_b = ops.linear_wgrad(dt1, ao, want_bias=True)
+        else:
+            dout_w = ops.linear_wgrad(dt1, ao)
+        dao = ops.linear(dt1, out_w.t().contiguous(), None)
+        dqkv = ops.token_attention_bwd(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], dao, M, S, nhead, hd, 1.0 / math.sqrt(hd),
+                                       head_stride=hs, out=ao, dropout=(p, seed, _SITE_ATTN) if drop else None)
+        del dao, dt1
+        din_w, din_b = ops.linear_wgrad(dqkv, x, want_bias=True)
+        din_w, din_b = _unpad_heads(din_w, 3 * nhead, hd, hs), _unpad_heads(din_b, 3 * nhead, hd, hs)
+        dx = ops.linear(dqkv, w_in.t().contiguous(), None, res=dz1)                # through in_proj + the residual branch
+        return (dx, None, None, None, None, None, None, None, din_w, din_b, dout_w, dout_b, dl1_w, dl1_b, dl2_w, dl2_b, dn1_w, dn1_b,
+                dn2_w, dn2_b)
+
+
 class _SeqExpand(torch.autograd.Function):
     """pooled[s] = pooled_c[seq_inv[s]]: the compact sequences' pooled vectors back on every slot (all-padding slots share the
     representative's).  Backward: every live compact row has exactly one slot (a gather by seq_src), the representative's
@@ -387,22 +491,36 @@ def encode_tokens(ids, table, pos_encoder, transformer, nhead, p_embedding=0.0):
     """``p_embedding``: the probability of the inplace dropout the caller's encoder applies to the word embeddings (0 in eval
     mode).  The HIP layer applies ONE probability to its six dropout sites, which is how the reference builds it
     (config.dropout_rate everywhere); anything else is refused."""
-    if len(transformer.layers) != 1 or transformer.norm is not None:
-        raise NotImplementedError('the training path covers num_layers = 1 without a final norm (config.py default)')
-    layer = transformer.layers[0]
-    sa = layer.self_attn
+    if transformer.norm is not None:
+        raise NotImplementedError('a final encoder norm is not used by the reference (newsEncoders.py:245,247)')
+    layers = list(transformer.layers)
     ps = [p_embedding, pos_encoder.dropout.p if pos_encoder.training else 0.0]
-    ps += [sa.dropout, layer.dropout1.p, layer.dropout.p, layer.dropout2.p] if layer.training else [0.0] * 4
+    for layer in layers:
+        ps += [layer.self_attn.dropout, layer.dropout1.p, layer.dropout.p, layer.dropout2.p] if layer.training else [0.0] * 4
     if max(ps) != min(ps):
         raise NotImplementedError('the HIP encoder layer applies one dropout probability to all of its sites; got %s (embedding, '
-                                  'positional, attention, dropout1, dropout, dropout2): put the news encoder into one mode' % ps)
+                                  'positional, then attention, dropout1, dropout, dropout2 per layer): put the news encoder into one mode' % ps)
     p = float(ps[0])
     ids = ids.contiguous()
     dd = _dedup_sequences(ids) if p == 0 else None
-    run = lambda rows: _TokenEncoder.apply(rows, nhead, layer.norm1.eps, layer.norm2.eps, p, _draw_seed() if p > 0 else 0, table,
-                                           pos_encoder.table(), sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias,
-                                           layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias,
-                                           layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias)
+    if len(layers) == 1:
+        layer = layers[0]
+        sa = layer.self_attn
+        run = lambda rows: _TokenEncoder.apply(rows, nhead, layer.norm1.eps, layer.norm2.eps, p, _draw_seed() if p > 0 else 0, table,
+                                               pos_encoder.table(), sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias,
+                                               layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias,
+                                               layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias)
+    else:
+        def run(rows):                                  # num_layers = 2 (config.py:70): materialised input, one node per layer, mean pool
+            M, S = rows.shape
+            x = _EmbedPE.apply(rows, table, pos_encoder.table(), p, _draw_seed() if p > 0 else 0)
+            for layer in layers:
+                sa = layer.self_attn
+                x = _EncoderLayer.apply(x, M, S, nhead, layer.norm1.eps, layer.norm2.eps, p, _draw_seed() if p > 0 else 0,
+                                        sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, layer.linear1.weight,
+                                        layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, layer.norm1.weight, layer.norm1.bias,
+                                        layer.norm2.weight, layer.norm2.bias)
+            return x.view(M, S, -1).mean(dim=1)                                                                 # :317 / :321
     if dd is None:
         return run(ids)
     cmp, n_c, n_live = dd

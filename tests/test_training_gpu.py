@@ -17,7 +17,7 @@ from lime_cikm25_amd.training import TrainStep, negative_log_softmax
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
 LR = 1e-5
-GRAD_CASES = ['cfg1_crown', 'cfg1_mhsa', 'spill', 'empty_history', 'full_len', 'long_body', 'fusion_gated']
+GRAD_CASES = ['cfg1_crown', 'cfg1_mhsa', 'spill', 'empty_history', 'full_len', 'long_body', 'fusion_gated', 'two_layers']
 
 
 def train_model(name):
