@@ -39,6 +39,23 @@
 
 using namespace lime_dev;
 
+#ifdef LIME_STAMPS
+// Diagnostic build only (tools/gemm_stamps.py): per-wave s_memtime sums of the main-loop segments; never in liblime_hip.so.
+static unsigned long long* g_sp_stamp_buf = nullptr;
+extern "C" void lime_debug_set_sp_stamp_buffer(unsigned long long* p) { g_sp_stamp_buf = p; }
+#define SSTAMP(i)                                                           \
+    {                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();         \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                 \
+        tsum[i] += t_ - tlast;                                              \
+        tlast = t_;                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+    }
+#else
+#define SSTAMP(i)
+#endif
+
 namespace {
 
 constexpr int BM = 256;                    // rows per tile: 4 row waves x 64
@@ -446,16 +463,25 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
     int stage = 0, par = 0;
+#ifdef LIME_STAMPS
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     for (; tile >= 0; ti += nw_x, tile = tile_at(ti), par ^= 1, sel ^= 1) {
         const bool more = ti + nw_x < tcount;
         acc_init(tile, par, sel);
         load_rows(tile_at(ti + nw_x));                 // the next tile's row lists: loaded now, parked after the first chunk
+        SSTAMP(0)                                     // 0: accumulator init (residual loads issued)
         for (int c = 0; c + 1 < nchunk; ++c) {
             compute(stage, stage ^ 1, c + 1, sel);
             __builtin_amdgcn_sched_barrier(0);         // MFMAs touch no memory: hipcc otherwise sinks them below the wait + barrier
+            SSTAMP(c == 0 ? 1 : 2)                    // 1: first chunk of a tile (waits for the residual loads), 2: reads + split + MFMA + DMA issue
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SSTAMP(c == 0 ? 3 : 4)                    // 3: DMA (and the previous tile's stores) landed, first chunk; 4: other chunks
             if (c == 0) park_rows(sel ^ 1);
             lds_barrier();
+            SSTAMP(5)                                 // 5: barrier
             stage ^= 1;
         }
         // last chunk of the tile: the loader moves on to the next tile first (its row lists were parked >= one barrier ago:
@@ -463,12 +489,22 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
         if (more) loader_set_tile(tbase + ti + nw_x);
         compute(stage, more ? (stage ^ 1) : -1, 0, sel ^ 1);
         __builtin_amdgcn_sched_barrier(0);
+        SSTAMP(2)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SSTAMP(4)
         lds_barrier();
+        SSTAMP(5)
         stage ^= 1;
         // the stores retire under the next tile's first chunk; the bias image is double-buffered by tile parity
         epilogue(tile, par, sel);
+        SSTAMP(6)                                     // 6: epilogue (stores issued)
     }
+#ifdef LIME_STAMPS
+    if (p.stamps && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p.stamps[((long)blockIdx.x * 8 + wave) * 8 + i] = tsum[i];
+    }
+#endif
 }
 
 int sp_num_cus() {
@@ -490,6 +526,9 @@ int launch(const PPParams& p0, hipStream_t stream) {
     const long ntiles = (long)p.n_row_blocks * p.n_col_blocks;
     long nwg = sp_num_cus();
     if (nwg > ntiles) nwg = ntiles;
+#ifdef LIME_STAMPS
+    p.stamps = g_sp_stamp_buf;
+#endif
     hipLaunchKernelGGL((gemm_sp_kernel<CT, LN, RELU, RES, POOL, RSTD, CID>), dim3((unsigned)nwg), dim3(512), 0, stream, p);
     lime_set_last_linear_kernel("gemm_sp_kernel<%d, %s, %s, %d, %s, %s, %s>", CT, LN ? "true" : "false", RELU ? "true" : "false", RES,
                                 POOL ? "true" : "false", RSTD ? "true" : "false", CID ? "true" : "false");    // as rocprofv3 prints it
