@@ -222,34 +222,38 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
             x0[i] = *reinterpret_cast<const f32x4*>(sb + a_off + i * 16 * ROWB + h0);
             x1[i] = *reinterpret_cast<const f32x4*>(sb + a_off + i * 16 * ROWB + h1);
         }
-        {
-            const Split w = split8(r0, r1);
-            if (CT > 1) {
-                r0 = *reinterpret_cast<const f32x4*>(sb + w_off + 16 * ROWB + h0);
-                r1 = *reinterpret_cast<const f32x4*>(sb + w_off + 16 * ROWB + h1);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = split8(x0[i], x1[i]);
-                if (0 < nct) acc[i][0] = mfma6(w, a[i], acc[i][0]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (nstage >= 0) {
-                issue_piece(0, nstage, nc, sel);
-                if (1 < NPIECE) issue_piece(1, nstage, nc, sel);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+        // software pipeline over the column tiles: tile j + 1's weight fragment is read and split in the same basic block as tile j's 24
+        // MFMAs (hipcc keeps the MFMAs together and the split behind them -- sched_group_barrier requests for a 1 : 2 interleave were
+        // not honoured; the partner wave of the SIMD has the pipe meanwhile, and the loop sits at 0.89 of the bf16 pipe's sustained rate
+        // either way: profiles/r03_notes.md)
+        Split w = split8(r0, r1);
+        if (CT > 1) {
+            r0 = *reinterpret_cast<const f32x4*>(sb + w_off + 16 * ROWB + h0);
+            r1 = *reinterpret_cast<const f32x4*>(sb + w_off + 16 * ROWB + h1);
         }
 #pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i] = split8(x0[i], x1[i]);
+            if (0 < nct) acc[i][0] = mfma6(w, a[i], acc[i][0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (nstage >= 0) {
+            issue_piece(0, nstage, nc, sel);
+            if (1 < NPIECE) issue_piece(1, nstage, nc, sel);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (CT > 1) w = split8(r0, r1);
+#pragma unroll
         for (int j = 1; j < CT; ++j) {
-            if (j < nct) {
-                const Split w = split8(r0, r1);
-                if (j + 1 < CT) {                      // the next tile's fragment: read behind the split that freed the registers
+            Split wn = w;
+            if (j < nct) {                             // (one basic block: the reads, this tile's MFMAs and the next tile's split)
+                if (j + 1 < CT) {                      // the next tile's fragment: read, and split under this tile's MFMAs
                     r0 = *reinterpret_cast<const f32x4*>(sb + w_off + (j + 1) * 16 * ROWB + h0);
                     r1 = *reinterpret_cast<const f32x4*>(sb + w_off + (j + 1) * 16 * ROWB + h1);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i][j] = mfma6(w, a[i], acc[i][j]);
+                if (j + 1 < CT) wn = split8(r0, r1);
             }
             __builtin_amdgcn_sched_barrier(0);         // pins the DMA issue between the column tiles
             if (nstage >= 0) {                         // two pieces per column tile: all out in the first half of the chunk
@@ -257,6 +261,7 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
                 if (2 * j + 1 < NPIECE) issue_piece(2 * j + 1, nstage, nc, sel);
             }
             __builtin_amdgcn_sched_barrier(0);
+            w = wn;
         }
     };
 
