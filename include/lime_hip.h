@@ -102,6 +102,14 @@ typedef struct {
 
 int lime_linear_f32(const lime_linear_args* args, void* stream);
 
+/* n (1 .. 8) INDEPENDENT problems in one launch of the small / mid-M kernel (csrc/gemm_mid_f32.hip): the GEMMs around the token
+ * encoders are latency bound -- a launch costs one tile's k loop, >= 10 us however small --, so two that do not depend on each other
+ * (the two intent-attention affine1 layers, layers.py:288; gate_proj and Q, layers.py:87 / userEncoders.py:162; the positional tables
+ * of the two encoders through in_proj) take one launch's time side by side.  Every problem must be one that kernel takes: 16-byte
+ * friendly operands (K, N multiples of 4, aligned rows), K >= 16, no LayerNorm / pool32 / a_pe / c_ids / res_pe; m_dev is honoured.
+ * Any M (it is meant for M < 4096); LIME_ERR_UNSUPPORTED names the first problem outside the kernel. */
+int lime_linear_group_f32(const lime_linear_args* args, int32_t n, void* stream);
+
 /* The kernel instantiation the calling thread's last lime_linear_f32 launched (e.g. "gemm_pp_kernel<10, true, false, 1>"),
  * as rocprofv3 names it: lets a profiler harness match its own event timings to the kernel trace. */
 const char* lime_last_linear_kernel(void);

@@ -123,6 +123,7 @@ SIGNATURES = {
     'lime_last_linear_kernel': (c_char_p, []),
     'lime_set_split_gemm': (c_int32, [c_int32]),
     'lime_linear_f32': (c_int32, [POINTER(LinearArgs), c_void_p]),
+    'lime_linear_group_f32': (c_int32, [POINTER(LinearArgs), c_int32, c_void_p]),
     'lime_embed_pe_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_int64,
                                     c_int32, c_void_p]),
     'lime_token_attention_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,

@@ -48,14 +48,15 @@ __device__ __forceinline__ float act_fn(float v, int act) {
     return v;
 }
 
-__global__ __launch_bounds__(256, 3) void gemm_mid_kernel(const MidP p) {
-    constexpr int A_ST = MB * KB, STAGE = (MB + NB) * KB;               // floats
-    __shared__ __attribute__((aligned(16))) float lds[NS * STAGE];
+constexpr int A_ST = MB * KB, STAGE = (MB + NB) * KB;               // floats
+
+// one 64 x 64 tile of problem p (tile index inside the problem); lds: the workgroup's NS * STAGE floats
+__device__ __forceinline__ void mid_tile(const MidP& p, const int tile, float* const lds) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fi = lane & 15, kg = lane >> 4;
-    const int rb = blockIdx.x / p.n_col_blocks;
-    const int row0 = rb * MB, col0 = (blockIdx.x - rb * p.n_col_blocks) * NB;
+    const int rb = tile / p.n_col_blocks;
+    const int row0 = rb * MB, col0 = (tile - rb * p.n_col_blocks) * NB;
     int M = p.M;
     if (p.m_dev) {
         const int m = __builtin_amdgcn_readfirstlane(*p.m_dev);
@@ -153,20 +154,38 @@ __global__ __launch_bounds__(256, 3) void gemm_mid_kernel(const MidP p) {
     }
 }
 
+__global__ __launch_bounds__(256, 3) void gemm_mid_kernel(const MidP p) {
+    __shared__ __attribute__((aligned(16))) float lds[NS * STAGE];
+    mid_tile(p, (int)blockIdx.x, lds);
+}
+
+// Several INDEPENDENT problems in one launch: the launches around the encoders are latency bound (one tile's k loop, >= 10 us each
+// however small), so two GEMMs that do not depend on each other cost one launch's time side by side instead of two in a row.
+constexpr int MAX_GROUP = 8;
+struct MidGroup {
+    MidP p[MAX_GROUP];
+    int first[MAX_GROUP + 1];       // first[k]: the first workgroup of problem k; first[n] = the grid
+    int n;
+};
+
+__global__ __launch_bounds__(256, 3) void gemm_mid_group_kernel(const MidGroup g) {
+    __shared__ __attribute__((aligned(16))) float lds[NS * STAGE];
+    int k = 0;
+    while (k + 1 < g.n && (int)blockIdx.x >= g.first[k + 1]) ++k;        // uniform: scalar loads and compares
+    mid_tile(g.p[k], (int)blockIdx.x - g.first[k], lds);
+}
+
 inline bool al16(const void* ptr, long ld) { return ptr == nullptr || (((uintptr_t)ptr % 16) == 0 && (ld % 4) == 0); }
 
 }  // namespace
 
-// LIME_OK / error: launched; LIME_PP_NOT_APPLICABLE: the caller takes the general kernel.
-int lime_linear_mid(const lime_linear_args* a, hipStream_t s) {
-    static const bool off = getenv("LIME_GEMM_NO_MID") != nullptr;           // A/B switch for tools/, not a product option
-    if (off) return LIME_PP_NOT_APPLICABLE;
-    if (a->ln_gamma || a->pool32 || a->a_pe || a->ln_rstd || a->c_ids || a->res_pe) return LIME_PP_NOT_APPLICABLE;
-    if (a->K % 4 || a->N % 4 || a->K < 16) return LIME_PP_NOT_APPLICABLE;
-    if (!al16(a->a, a->lda) || !al16(a->w, a->ldw) || !al16(a->c, a->ldc) || !al16(a->res, a->ldr)) return LIME_PP_NOT_APPLICABLE;
+// fills p and the tile count; false: the problem is outside this kernel
+static bool mid_params(const lime_linear_args* a, MidP& p, long& ntiles) {
+    if (a->ln_gamma || a->pool32 || a->a_pe || a->ln_rstd || a->c_ids || a->res_pe) return false;
+    if (a->K % 4 || a->N % 4 || a->K < 16) return false;
+    if (!al16(a->a, a->lda) || !al16(a->w, a->ldw) || !al16(a->c, a->ldc) || !al16(a->res, a->ldr)) return false;
     const long lim = 0x7FFFFFF0L;
-    if (64L * a->lda * 4 >= lim || 64L * a->ldw * 4 >= lim) return LIME_PP_NOT_APPLICABLE;
-    MidP p;
+    if (64L * a->lda * 4 >= lim || 64L * a->ldw * 4 >= lim) return false;
     p.a = a->a; p.lda = a->lda; p.a_ids = a->a_ids;
     p.w = a->w; p.ldw = a->ldw; p.bias = a->bias;
     p.res = a->res; p.ldr = a->ldr; p.res_div = a->res_div > 0 ? a->res_div : 1; p.res_ids = a->res_ids;
@@ -174,9 +193,47 @@ int lime_linear_mid(const lime_linear_args* a, hipStream_t s) {
     p.c = a->c; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act; p.m_dev = a->m_dev;
     const long n_row_blocks = (a->M + MB - 1) / MB;
     p.n_col_blocks = (a->N + NB - 1) / NB;
-    const long ntiles = n_row_blocks * p.n_col_blocks;
-    if (ntiles > 0x7FFFFFFFL) return LIME_PP_NOT_APPLICABLE;
+    ntiles = n_row_blocks * p.n_col_blocks;
+    return ntiles <= 0x3FFFFFFFL;
+}
+
+// LIME_OK / error: launched; LIME_PP_NOT_APPLICABLE: the caller takes the general kernel.
+int lime_linear_mid(const lime_linear_args* a, hipStream_t s) {
+    static const bool off = getenv("LIME_GEMM_NO_MID") != nullptr;           // A/B switch for tools/, not a product option
+    if (off) return LIME_PP_NOT_APPLICABLE;
+    MidP p;
+    long ntiles = 0;
+    if (!mid_params(a, p, ntiles)) return LIME_PP_NOT_APPLICABLE;
     hipLaunchKernelGGL(gemm_mid_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, p);
     lime_set_last_linear_kernel("gemm_mid_kernel");
     return lime_check_launch("lime_linear_f32");
+}
+
+extern "C" int lime_linear_group_f32(const lime_linear_args* args, int32_t n, void* stream) {
+    LIME_REQUIRE(args != nullptr && n >= 1 && n <= MAX_GROUP, LIME_ERR_BAD_ARG, "lime_linear_group_f32: args is NULL or n outside 1 .. %d", MAX_GROUP);
+    MidGroup g;
+    g.n = 0;
+    long total = 0;
+    for (int k = 0; k < n; ++k) {
+        const lime_linear_args* a = &args[k];
+        LIME_REQUIRE(a->a && a->w && a->c, LIME_ERR_BAD_ARG, "lime_linear_group_f32: problem %d: a, w and c must be non-NULL", k);
+        LIME_REQUIRE(a->M >= 0 && a->N > 0 && a->K > 0 && a->ldw >= a->K && a->ldc >= a->N && a->lda >= a->K, LIME_ERR_BAD_ARG,
+                     "lime_linear_group_f32: problem %d: bad dims / leading dimensions", k);
+        LIME_REQUIRE(a->act >= LIME_ACT_NONE && a->act <= LIME_ACT_SIGMOID && a->res_mod >= 0 && (!a->res || a->res_ids || a->res_div >= 1) &&
+                     (!a->res || a->ldr >= a->N), LIME_ERR_BAD_ARG, "lime_linear_group_f32: problem %d: bad act / residual arguments", k);
+        if (a->M == 0) continue;
+        long ntiles = 0;
+        LIME_REQUIRE(mid_params(a, g.p[g.n], ntiles), LIME_ERR_UNSUPPORTED,
+                     "lime_linear_group_f32: problem %d is outside the mid-M kernel (16-byte friendly operands, K >= 16, no LayerNorm / pooling / "
+                     "a_pe / c_ids / res_pe): launch it with lime_linear_f32", k);
+        g.first[g.n] = (int)total;
+        total += ntiles;
+        LIME_REQUIRE(total <= 0x3FFFFFFFL, LIME_ERR_UNSUPPORTED, "lime_linear_group_f32: too many tiles");
+        ++g.n;
+    }
+    if (g.n == 0) return LIME_OK;
+    g.first[g.n] = (int)total;
+    hipLaunchKernelGGL(gemm_mid_group_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, g);
+    lime_set_last_linear_kernel("gemm_mid_group_kernel");
+    return lime_check_launch("lime_linear_group_f32");
 }

@@ -279,8 +279,8 @@ class LIME(nn.Module):
         side.wait_stream(main)
         with torch.cuda.stream(side):
             pair = torch.add(fe.buckets(lifetime), fe.buckets(freshness), alpha=nb)                        # b_f * nb + b_l, int32 [M]
-            t_f = ops.linear(fe.freshness_embedding.weight, fe.dense.weight[:, :E], None)                 # [nb, cdim]
-            t_l = ops.linear(fe.lifetime_embedding.weight, fe.dense.weight[:, E:], fe.dense.bias)         # [nb, cdim]
+            t_f, t_l = ops.linear_group([dict(a=fe.freshness_embedding.weight, w=fe.dense.weight[:, :E], bias=None),       # [nb, cdim]
+                                         dict(a=fe.lifetime_embedding.weight, w=fe.dense.weight[:, E:], bias=fe.dense.bias)])   # [nb, cdim]
             fresh = torch.tanh(t_f.unsqueeze(1) + t_l.unsqueeze(0)).view(nb * nb, -1)                     # row b_f * nb + b_l
             table = ops.linear(fresh, self.project.weight[:, cdim:], self.project.bias)                   # [nb^2, final_dim]
         content = torch.empty((M, cdim), dtype=torch.float32, device=title_text.device)
@@ -538,19 +538,29 @@ def compact_prepare(ids, table, pe, transformer, nhead):
     """Everything of ``encode_tokens_compact`` in front of the big GEMMs -- index lists, padded in_proj weights, the positional
     table through in_proj, the S rows shared by the padding tokens: a dozen short launches that depend on the ids and the
     weights only, so the caller can run them on a side stream under another encoder's GEMMs."""
-    M, S = ids.shape
+    return compact_prepare_many([(ids, pe, transformer)], table, nhead)[0]
+
+
+def compact_prepare_many(encoders, table, nhead):
+    """``compact_prepare`` for several token encoders over one word table ((ids, pe, transformer) each): their positional tables go
+    through in_proj in ONE grouped launch, their padding rows in another (independent, latency-bound GEMMs)."""
     E = table.shape[1]
     hd = E // nhead
     W = nhead * 32
-    sa = transformer.layers[0].self_attn
-    cap = (M + 1) * S
-    cmp = ops.compact_sequences(ids)                                           # pad rows live at qkv[cap : cap + S]
-    w_in = ops.pad_heads(sa.in_proj_weight, 3 * nhead, hd, 32)
-    b_in = ops.pad_heads(sa.in_proj_bias, 3 * nhead, hd, 32)
-    pew = ops.linear(pe[:S], w_in, b_in)                                       # [S, 3W]: positional term + bias
-    qkv = torch.empty((cap + S, 3 * W), dtype=torch.float32, device=ids.device)
-    ops.linear(table, w_in, None, a_ids=_zero_ids(S, ids.device), res=pew, res_mod=S, out=qkv[cap:])   # the S padding rows
-    return cmp, w_in, pew, qkv
+    parts = []
+    for ids, pe, transformer in encoders:
+        M, S = ids.shape
+        sa = transformer.layers[0].self_attn
+        cap = (M + 1) * S
+        cmp = ops.compact_sequences(ids)                                       # pad rows live at qkv[cap : cap + S]
+        w_in = ops.pad_heads(sa.in_proj_weight, 3 * nhead, hd, 32)
+        b_in = ops.pad_heads(sa.in_proj_bias, 3 * nhead, hd, 32)
+        qkv = torch.empty((cap + S, 3 * W), dtype=torch.float32, device=ids.device)
+        parts.append((cmp, w_in, b_in, qkv, pe, S, cap))
+    pews = ops.linear_group([dict(a=pe[:S], w=w_in, bias=b_in) for (_, w_in, b_in, _, pe, S, _) in parts])   # [S, 3W]: positional term + bias
+    ops.linear_group([dict(a=table, w=w_in, bias=None, a_ids=_zero_ids(S, table.device), res=pew, res_mod=S, out=qkv[cap:])
+                      for (_, w_in, _, qkv, _, S, cap), pew in zip(parts, pews)])                             # the S padding rows
+    return [(cmp, w_in, pew, qkv) for (cmp, w_in, _, qkv, _, _, _), pew in zip(parts, pews)]
 
 
 _IDENT = {}
@@ -899,12 +909,11 @@ class CROWN(NewsEncoder):
             (t_ids, t_pos, t_tr, _), (b_ids, b_pos, b_tr, _) = encoders
             side3 = _side_stream(dev, 3)
             side3.wait_stream(main)
-            with torch.cuda.stream(side3):
-                prep_b = compact_prepare(b_ids, table, b_pos.table(), b_tr, self.head_num)
+            with torch.cuda.stream(side3):              # both encoders' preparation together: their small GEMMs share launches
+                prep_t, prep_b = compact_prepare_many([(t_ids, t_pos.table(), t_tr), (b_ids, b_pos.table(), b_tr)], table, self.head_num)
             side1 = _side_stream(dev, 7)                   # branch 7: the (short) title chain beside the body chain
-            side1.wait_stream(main)
+            side1.wait_stream(side3)
             with torch.cuda.stream(side1):
-                prep_t = compact_prepare(t_ids, table, t_pos.table(), t_tr, self.head_num)
                 compact_run(prep_t, table, t_pos.table(), t_tr, self.head_num, xin[:M, :E])                    # :311-317
             main.wait_stream(side3)
             compact_run(prep_b, table, b_pos.table(), b_tr, self.head_num, xin[M:, :E])                        # :312-321
@@ -940,13 +949,10 @@ class CROWN(NewsEncoder):
         A = self.title_intent_attention.affine1.out_features
         hidden = torch.empty((2 * M * k, A), dtype=torch.float32, device=dev)
         iv = intents.view(2 * M * k, D)
-        side5 = _side_stream(dev, 5)
-        side5.wait_stream(main)
-        for half, att in enumerate((self.title_intent_attention, self.body_intent_attention)):
-            with torch.cuda.stream(main if half == 0 else side5):
-                ops.linear(iv[half * M * k:(half + 1) * M * k], att.affine1.weight, att.affine1.bias, act='tanh',
-                           out=hidden[half * M * k:(half + 1) * M * k])
-        main.wait_stream(side5)
+        # the two halves do not depend on each other: one grouped launch (they were two launches on two streams)
+        ops.linear_group([dict(a=iv[half * M * k:(half + 1) * M * k], w=att.affine1.weight, bias=att.affine1.bias, act='tanh',
+                               out=hidden[half * M * k:(half + 1) * M * k])
+                          for half, att in enumerate((self.title_intent_attention, self.body_intent_attention))])
         ops.intent_fuse(iv, hidden, self.title_intent_attention.affine2.weight.view(-1),
                         self.body_intent_attention.affine2.weight.view(-1), out, M, k, D, A)          # :355-371
         return out

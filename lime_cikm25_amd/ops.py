@@ -68,7 +68,7 @@ def set_split_gemm(on):
 
 def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=0, res=None, res_div=1, res_ids=None,
            res_pe=None, res_period=0, ln=None, ln_eps=1e-5, res_mod=0, pool32=False, ln_rstd=None, n_alg=None, m_dev=None,
-           c_ids=None):
+           c_ids=None, _build_only=False):
     """C = epilogue(A . W^T + bias) -- see ``lime_linear_f32`` in include/lime_hip.h.
 
     n_alg: the number of USEFUL output columns when w carries zero padding rows (in_proj with heads padded to 32 columns:
@@ -146,6 +146,8 @@ def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=
     args.c, args.ldc = out.data_ptr(), _ld(out)
     args.M, args.N, args.K = M, N, K
     args.act = LIME_ACT[act]
+    if _build_only:
+        return args, out
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -157,6 +159,30 @@ def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=
         return out
     check(lib.lime_linear_f32(ctypes.byref(args), _stream()), 'lime_linear_f32')
     return out
+
+
+GROUP_SMALL_GEMMS = True      # False: linear_group issues its problems one by one (A/B runs, tests)
+
+
+def linear_group(problems):
+    """Several INDEPENDENT small GEMMs in one launch (``lime_linear_group_f32``): ``problems`` is a list of dicts of ``linear``'s
+    arguments; returns the list of outputs.  The launches around the encoders are latency bound (>= 10 us each however small), so two
+    that do not depend on each other cost one launch's time side by side.  Falls back to separate launches when a problem is outside
+    the mid-M kernel (large M, LayerNorm, misaligned operands), under bench.py's per-kernel timing pass, or with GROUP_SMALL_GEMMS off."""
+    if len(problems) == 1 or not GROUP_SMALL_GEMMS or PROFILE is not None or len(problems) > 8:
+        return [linear(**kw) for kw in problems]
+    lib = _lib.load()
+    built = [linear(_build_only=True, **kw) for kw in problems]
+    if any(a.M >= 4096 or a.ln_gamma or a.pool32 or a.c_ids or a.a_pe or a.res_pe or a.K % 4 or a.N % 4 or a.K < 16 for a, _ in built):
+        return [linear(**kw) for kw in problems]
+    arr = (LinearArgs * len(built))()
+    for i, (a, _) in enumerate(built):
+        ctypes.memmove(ctypes.byref(arr[i]), ctypes.byref(a), ctypes.sizeof(LinearArgs))
+    st = lib.lime_linear_group_f32(arr, len(built), _stream())
+    if st == -2:                                       # LIME_ERR_UNSUPPORTED                # e.g. a misaligned view: the general kernels take it
+        return [linear(**kw) for kw in problems]
+    check(st, 'lime_linear_group_f32')
+    return [out for _, out in built]
 
 
 def embed_pe(ids, table, pe=None, period=0, out=None):

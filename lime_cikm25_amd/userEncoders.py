@@ -140,24 +140,31 @@ class CROWN(UserEncoder):
         N = candidate_news_representation.shape[1]
         cand = candidate_news_representation.contiguous()
         n_src = B if n_src is None else n_src
-        # the candidate side of the match (:162) needs the candidates only: branch 6, beside the history chain
-        from .newsEncoders import _side_stream
-        main = torch.cuda.current_stream()
-        side6 = _side_stream(cand.device, 6)
-        side6.wait_stream(main)
-        with torch.cuda.stream(side6):
-            qp = ops.linear(cand.view(B * N, D), self.Q.weight, self.Q.bias)                                 # :162
         caa = self.candidate_aware_attn if self.use_candidate_aware_attn else None
+        fused = caa is not None and caa.use_residual_connection and D <= 512
+        main = torch.cuda.current_stream()
+        if fused and gate_y is None:
+            # Q(candidates) (:162) and gate_proj(history) (layers.py:87) do not depend on each other: one grouped launch
+            qp, gate_y = ops.linear_group([dict(a=cand.view(B * N, D), w=self.Q.weight, bias=self.Q.bias),
+                                           dict(a=history_embedding.reshape(Bh * H, D), w=caa.gate_proj.weight, bias=None)])
+            side6 = None
+        else:
+            # the candidate side of the match (:162) needs the candidates only: branch 6, beside the history chain
+            from .newsEncoders import _side_stream
+            side6 = _side_stream(cand.device, 6)
+            side6.wait_stream(main)
+            with torch.cuda.stream(side6):
+                qp = ops.linear(cand.view(B * N, D), self.Q.weight, self.Q.bias)                             # :162
         if caa is not None and agg is None:
             agg = self.attention_weights(category, subCategory, user_category, user_subCategory, user_history_mask)
         conv = self.graph_sage.convs[0]
-        if caa is not None and caa.use_residual_connection and D <= 512:
+        if fused:
             # gate_proj sees the history alone (the row scale commutes: layers.py:85-87), so it runs once per HISTORY; the gated
             # residual + LayerNorm of each row's H history rows and the SAGEConv mean over them are one launch, which reads a
             # shared history through row / hist_div (no per-candidate copies) and takes the user-node part of the mean -- the same
             # vector for every row -- as one precomputed sum                                                  :121,:151-157
             hist = history_embedding.reshape(Bh * H, D)
-            y = gate_y if gate_y is not None else ops.linear(hist, caa.gate_proj.weight, None)
+            y = gate_y
             node_const = self.user_node_embedding[:n_src - H].sum(dim=0) if n_src > H else None
             refined, m = ops.gate_ln_sage(y, hist, agg.reshape(-1), caa.gate_proj.bias, caa.layernorm.weight, caa.layernorm.bias,
                                           caa.layernorm.eps, B, H, D, hist_div, n_src, node_const)
@@ -170,7 +177,8 @@ class CROWN(UserEncoder):
                 history_embedding = caa.refine(history_embedding, agg)
             g = self.graph_sage.forward_closed_form(history_embedding, self.user_node_embedding, n_src=n_src)   # :121,:151-157
         kp = ops.linear(g.view(B * H, D), self.K.weight, None)                                               # :161
-        main.wait_stream(side6)
+        if side6 is not None:
+            main.wait_stream(side6)
         w = weighting
         user, logits = ops.interest_match(
             kp, qp, g.reshape(-1), cand.reshape(-1), remaining_lifetime, B, N, H, self.attention_dim, D,

@@ -864,3 +864,28 @@ def test_gate_ln_sage_fused(ops, G, H, D, row_div, n_src, n_user):
     two = ops.gate_ln(dev(yr), dev(xr), dev(scale), dev(bias), dev(gamma), dev(beta))
     check(got, two.cpu().view(G * H, D), what='fused vs gate_ln')
     check(mean, ops.sage_mean(two.view(G * H, D), dev(un), G, H, n_src, D).cpu(), what='fused vs sage_mean')
+
+
+def test_linear_group_equals_separate_launches(ops):
+    """lime_linear_group_f32: independent small GEMMs in one launch -- bit for bit what the single launches of the same kernel give,
+    for plain / tanh / gathered-A + periodic-residual / broadcast-residual problems of different shapes."""
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, 300, (128,), generator=g, dtype=torch.int32).cuda()
+    table, pew = dev(rnd(300, 300, seed=1)), dev(rnd(32, 960, seed=2))
+    probs = [dict(a=dev(rnd(32, 300, seed=3)), w=dev(rnd(960, 300, seed=4, scale=0.05)), bias=dev(rnd(960, seed=5))),
+             dict(a=dev(rnd(5280, 400, seed=6))[:3000], w=dev(rnd(400, 400, seed=7, scale=0.05)), bias=dev(rnd(400, seed=8)), act='tanh'),
+             dict(a=table, w=dev(rnd(960, 300, seed=9, scale=0.05)), bias=None, a_ids=ids, res=pew, res_mod=32),
+             dict(a=dev(rnd(1600, 400, seed=10)), w=dev(rnd(400, 400, seed=11, scale=0.05)), bias=None, res=dev(rnd(32, 400, seed=12)), res_div=50)]
+    ops.GROUP_SMALL_GEMMS = False
+    try:
+        want = [o.clone() for o in ops.linear_group([dict(p) for p in probs])]
+    finally:
+        ops.GROUP_SMALL_GEMMS = True
+    got = ops.linear_group([dict(p) for p in probs])
+    assert last_kernel() == 'gemm_mid_group_kernel', last_kernel()
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a.shape == b.shape and torch.equal(a, b), 'problem %d' % i
+    # a problem the mid-M kernel does not take (LayerNorm) sends the whole group down the single-launch path
+    lnp = dict(a=dev(rnd(200, 300, seed=15)), w=dev(rnd(300, 300, seed=16, scale=0.05)), bias=None, ln=(dev(rnd(300, seed=17) + 1.5), dev(rnd(300, seed=18))))
+    outs = ops.linear_group([dict(probs[0]), lnp])
+    check(outs[1], O.layer_norm(lnp['a'].cpu() @ lnp['w'].cpu().t(), lnp['ln'][0].cpu(), lnp['ln'][1].cpu()), what='fallback')
