@@ -15,6 +15,8 @@ struct PPParams {
     int n_row_blocks, n_col_blocks;
     const int* m_dev;    // optional device-side row count: the kernel runs min(*m_dev, M) rows (M is the capacity)
     const int* c_ids;    // optional (CID instantiations): output row of A row r is c_ids[r]; a periodic residual is indexed by it
+    int act = 0;         // gemm_sp_kernel only, instantiations without the ReLU template flag: LIME_ACT_TANH / LIME_ACT_SIGMOID at run time
+    int res_div = 1;     // gemm_sp_kernel only (RES == 1 without res_mod): residual row = r / res_div (one row broadcast to res_div rows)
 #ifdef LIME_STAMPS
     unsigned long long* stamps;
 #endif

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
         } else {
             const __amdgpu_buffer_rsrc_t rs_rpe = make_rsrc(p.res_pe ? p.res_pe : p.w);
             __amdgpu_buffer_rsrc_t rs_res;
-            if (RES == 1 && p.res_mod <= 0) rs_res = make_rsrc((const char*)p.res + (long)row0 * p.ldr * 4);
+            if (RES == 1 && p.res_mod <= 0 && p.res_div <= 1) rs_res = make_rsrc((const char*)p.res + (long)row0 * p.ldr * 4);
             else rs_res = make_rsrc(p.res);
             unsigned rof[4], pof[4];
 #pragma unroll
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
                         if constexpr (CID) {
                             crow[i] = ids[sel * BM + rl];
                             ro = (unsigned)(crow[i] % p.res_mod) * (unsigned)ldr4;       // dispatcher: res_mod > 0
-                        } else ro = (p.res_mod > 0 ? (unsigned)(row % p.res_mod) : (unsigned)rl) * (unsigned)ldr4;
+                        } else ro = (p.res_mod > 0 ? (unsigned)(row % p.res_mod) : (p.res_div > 1 ? (unsigned)(row / p.res_div) : (unsigned)rl)) * (unsigned)ldr4;
                     } else {
                         ro = (unsigned)ids[sel * BM + rl] * (unsigned)ldr4;
                         if (p.res_pe) po = (unsigned)(row % p.res_period) * (unsigned)((int)p.ldr_pe * 4);
@@ -331,6 +331,13 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
         unsigned rof[4] = {OOB, OOB, OOB, OOB}, pof[4] = {OOB, OOB, OOB, OOB};
         const __amdgpu_buffer_rsrc_t rs_res2 = make_rsrc(p.res ? (const void*)p.res : (const void*)p.w);
         const __amdgpu_buffer_rsrc_t rs_rpe2 = make_rsrc(p.res_pe ? (const void*)p.res_pe : (const void*)p.w);
+        const __amdgpu_buffer_rsrc_t rs_c = make_rsrc((char*)p.c + ((CID ? 0L : (long)row0 * p.ldc) + col0) * 4);
+        unsigned cof[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rl = 64 * wr + 16 * i + fi;
+            cof[i] = (row0 + rl < M) ? (unsigned)(CID ? crow[i] : rl) * (unsigned)ldc4 + (unsigned)(cw0 + 4 * kg) * 4u : OOB;
+        }
         if constexpr (RES == 2) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -355,10 +362,21 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 f32x4 v = acc[i][t] + b;
-                if constexpr (RES == 2) v += rr[i];
                 if constexpr (RELU) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                } else if constexpr (!LN && RES != 1) {        // Attention.affine1 (tanh), gates (sigmoid): uniform run-time choice
+                    if (p.act == LIME_ACT_TANH) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = tanhf(v[j]);
+                    } else if (p.act == LIME_ACT_SIGMOID) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = lime_sigmoid(v[j]);
+                    }
+                }
+                if constexpr (RES == 2) v += rr[i];               // act(acc + bias) + residual, the documented order
+                if constexpr (!LN) {                   // nothing of the row is needed any more: store now (the accumulators die here)
+                    buf_store4(v, rs_c, (col0 + cw0 + 16 * t + 4 * kg < p.N) ? cof[i] + (unsigned)t * 64u : OOB, 0);
                 }
                 acc[i][t] = v;
                 if constexpr (LN) {                    // columns beyond N are exact zeros (zero weights, zero bias, no residual)
@@ -390,13 +408,6 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
                 rstd[i] = rsqrtf(fmaxf(s2 * inv_n - mean[i] * mean[i], 0.f) + p.ln_eps);
             }
         }
-        const __amdgpu_buffer_rsrc_t rs_c = make_rsrc((char*)p.c + ((CID ? 0L : (long)row0 * p.ldc) + col0) * 4);
-        unsigned cof[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rl = 64 * wr + 16 * i + fi;
-            cof[i] = (row0 + rl < M) ? (unsigned)(CID ? crow[i] : rl) * (unsigned)ldc4 + (unsigned)(cw0 + 4 * kg) * 4u : OOB;
-        }
         if constexpr (RSTD) {
             const __amdgpu_buffer_rsrc_t rs_r = make_rsrc(p.ln_rstd + row0);
 #pragma unroll
@@ -427,19 +438,15 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
                     buf_store4(y, rs_p, ok ? (unsigned)(cw0 + 16 * t + 4 * kg) * 4u : OOB, 0);
                 }
             }
-        } else {
+        } else if constexpr (LN) {
 #pragma unroll
             for (int t = 0; t < CT; ++t) {
-                f32x4 ga, be;
-                if constexpr (LN) {
-                    ga = *reinterpret_cast<const f32x4*>(gs + 16 * t);
-                    be = *reinterpret_cast<const f32x4*>(es + 16 * t);
-                }
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(gs + 16 * t);
+                const f32x4 be = *reinterpret_cast<const f32x4*>(es + 16 * t);
                 const bool ok = col0 + cw0 + 16 * t + 4 * kg < p.N;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    f32x4 y = acc[i][t];
-                    if constexpr (LN) y = (y - mean[i]) * rstd[i] * ga + be;
+                    const f32x4 y = (acc[i][t] - mean[i]) * rstd[i] * ga + be;
                     buf_store4(y, rs_c, ok ? cof[i] + (unsigned)t * 64u : OOB, 0);
                 }
             }
@@ -554,7 +561,7 @@ extern "C" int lime_set_split_gemm(int on) {
         g_split_mode = (e && e[0] == '0') ? 0 : 1;
     }
     const int prev = g_split_mode;
-    if (on == 0 || on == 1 || on == 3) g_split_mode = on;       // 3: also the gathered-residual LayerNorm GEMM (tests / A-B runs)
+    if (on >= 0 && on <= 7) g_split_mode = on;       // bit 1: also the gathered-residual LayerNorm GEMM, bit 2: ignore the fill and row-count rules (tests / A-B runs)
     return prev;
 }
 
@@ -565,7 +572,8 @@ int lime_linear_sp(const lime_linear_args* a, hipStream_t s) {
     const bool has_res = a->res != nullptr, ln = a->ln_gamma != nullptr;
     const bool relu = a->act == LIME_ACT_RELU;
     if (a->a_pe != nullptr) return LIME_PP_NOT_APPLICABLE;
-    if (!(a->act == LIME_ACT_NONE || (relu && !has_res))) return LIME_PP_NOT_APPLICABLE;
+    const bool act_rt = a->act == LIME_ACT_TANH || a->act == LIME_ACT_SIGMOID;       // applied at run time in the epilogue
+    if (!(a->act == LIME_ACT_NONE || (relu && !has_res) || (act_rt && !ln && (!has_res || a->res_ids)))) return LIME_PP_NOT_APPLICABLE;
     if (a->K % 4 || a->N % 4 || a->K < 64) return LIME_PP_NOT_APPLICABLE;          // >= 2 chunks (row lists, bias image)
     if (!al16(a->a, a->lda) || !al16(a->w, a->ldw) || !al16(a->c, a->ldc) || !al16(a->res, a->ldr) || !al16(a->res_pe, a->ldr_pe))
         return LIME_PP_NOT_APPLICABLE;
@@ -580,25 +588,39 @@ int lime_linear_sp(const lime_linear_args* a, hipStream_t s) {
     int res = 0;
     if (has_res) {
         if (a->res_ids) res = 2;
-        else if (a->res_div <= 1) res = 1;
-        else return LIME_PP_NOT_APPLICABLE;
+        else res = 1;                                  // dense, periodic (res_mod) or broadcast (res_div > 1) rows
         if (res == 1 && a->res_mod > 0 && (long)a->res_mod * a->ldr * 4 >= lim) return LIME_PP_NOT_APPLICABLE;
+        if (res == 1 && a->res_div > 1 && (a->res_mod > 0 || ln || ((long)a->M / a->res_div + 1) * a->ldr * 4 >= lim)) return LIME_PP_NOT_APPLICABLE;
     }
+    // The epilogues the layers AROUND the encoders need (tanh / sigmoid: Attention.affine1, gates; a gathered residual without
+    // LayerNorm: LIME.project over the freshness table; a broadcast residual: SAGEConv lin_r) exist here for the LARGE batches
+    // (BASELINE configs[2] and [4]: 14k .. 150k rows, where the 64 x 64-tile mid-M kernel runs at a fifth of this kernel's rate);
+    // below ~12k rows one round of 256-row tiles is slower than the mid-M kernel's launch.
+    const bool extended = act_rt || (res == 2 && !ln) || (res == 1 && a->res_div > 1);
+    if (extended && a->M < 12288 && !(g_split_mode & 4)) return LIME_PP_NOT_APPLICABLE;
     if (ln && (a->N > 320 || relu)) return LIME_PP_NOT_APPLICABLE;
     // out_proj (gathered residual + positional rows + LayerNorm): this kernel's instantiation adds the residual in its epilogue and
     // keeps 265 registers in scratch there; it measures 67-80 TFLOP/s against 100 of gemm_pp_f32.hip (with the residual loaded into
     // the accumulators at the tile start: 186 registers, 73 TFLOP/s) -- left to the fp32 kernel; lime_set_split_gemm(3) routes it here
-    if (res == 2 && !(g_split_mode & 2)) return LIME_PP_NOT_APPLICABLE;      // only with lime_set_split_gemm(3)
+    if (res == 2 && ln && !(g_split_mode & 2)) return LIME_PP_NOT_APPLICABLE;      // only with lime_set_split_gemm(3)
     if (a->pool32 && !(ln && has_res && !a->res_ids && a->res_div <= 1 && a->M % 32 == 0)) return LIME_PP_NOT_APPLICABLE;
     // the tile width (256 / 320) that pads N least
     const int pad5 = (a->N + 319) / 320 * 320 - a->N, pad4 = (a->N + 255) / 256 * 256 - a->N;
     const bool wide = ln || pad5 <= pad4;
     const long ntiles = row_blocks * ((a->N + (wide ? 319 : 255)) / (wide ? 320 : 256));
-    // From the same M on as gemm_pp_f32.hip takes over from the mid-M kernel: a caller that cuts its rows into passes of >= 4096 gets
-    // one kernel family -- one rounding -- for every pass (Model.score_impressions' last pass is shorter than the others; the
-    // impression-permutation test of tests/test_fullsize_gpu.py compares bit for bit).
-    (void)ntiles;
+    // From the same M on as gemm_pp_f32.hip takes over from the mid-M kernel ...
     if (a->M < 4096) return LIME_PP_NOT_APPLICABLE;
+    // ... and only where 256-row tiles on one workgroup per CU fill the chip: a launch is `rounds` passes of ncu tiles, and a tile
+    // block that hangs over N computes dead columns.  Below ~0.55 of (tiles / (rounds x ncu)) x (N / covered columns) the 128-row /
+    // 64-row tile kernels win (tools/exp/sp_vs_mid.py: M = 14k, N = 400 -- 110 tiles -- 73 us here, 57 us there; M = 28k: 79 vs 95).
+    // A device-side row count (m_dev) hides the real M: those launches (the compacted encoder layers) always come here.  A caller
+    // that cuts its rows into EQUAL passes (Model.score_impressions) gets one kernel family -- one rounding -- for every pass.
+    if (!a->m_dev && !(g_split_mode & 4)) {
+        const long ncu = sp_num_cus();
+        const long rounds = (ntiles + ncu - 1) / ncu;
+        const double fill = (double)ntiles / (double)(rounds * ncu) * (double)a->N / (double)(((a->N + (wide ? 319 : 255)) / (wide ? 320 : 256)) * (wide ? 320 : 256));
+        if (fill < 0.55) return LIME_PP_NOT_APPLICABLE;
+    }
 
     PPParams p;
     p.a = a->a; p.lda = a->lda; p.a_ids = a->a_ids;
@@ -609,6 +631,8 @@ int lime_linear_sp(const lime_linear_args* a, hipStream_t s) {
     p.c = a->c; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K; p.ln_count = a->N;
     p.n_row_blocks = p.n_col_blocks = 0;
     p.m_dev = a->m_dev; p.c_ids = a->c_ids;
+    p.act = act_rt ? a->act : 0;
+    p.res_div = (res == 1 && a->res_div > 1) ? a->res_div : 1;
     {   // diagnostic: LIME_SP_MASK disables classes of instantiations (bit 0 c_ids, 1 LayerNorm + rstd, 2 LayerNorm, 3 residual,
         // 4 ReLU, 5 plain; bit 6: the 256-column tiles)
         static const int mask = getenv("LIME_SP_MASK") ? atoi(getenv("LIME_SP_MASK")) : 0;
@@ -626,7 +650,7 @@ int lime_linear_sp(const lime_linear_args* a, hipStream_t s) {
         if (res == 1) return a->pool32 ? launch<10, true, false, 1, true>(p, s) : launch<10, true, false, 1>(p, s);
         return launch<10, true, false, 2>(p, s);
     }
-    if (res == 2) return LIME_PP_NOT_APPLICABLE;
+    if (res == 2) return wide ? launch<10, false, false, 2>(p, s) : launch<8, false, false, 2>(p, s);
     if (wide) {
         if (res == 1) return launch<10, false, false, 1>(p, s);
         return relu ? launch<10, false, true, 0>(p, s) : launch<10, false, false, 0>(p, s);

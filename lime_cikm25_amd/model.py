@@ -170,7 +170,10 @@ class Model(nn.Module):
         if n_src is None:
             n_src = min(rows, H + ue.user_node_embedding.shape[0])
         out = torch.empty((B, K), dtype=torch.float32, device=cand.device)
-        per = max(1, rows_per_pass // K)                                              # impressions per pass
+        per = max(1, rows_per_pass // K)                                              # impressions per pass ...
+        n_pass = (B + per - 1) // per
+        per = (B + n_pass - 1) // n_pass          # ... evened out: the passes then take the same kernels (a short last pass would
+                                                  # fall under the row counts from which the big-M GEMM kernels take over)
         rl = remaining_lifetime.float()
         gate_y = ue.gate_projection(hist)                                             # once for every pass's histories (one GEMM shape)
         for b0 in range(0, B, per):

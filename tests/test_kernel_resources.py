@@ -35,6 +35,8 @@ KNOWN_SCRATCH = {
     # split-product GEMM (csrc/gemm_sp_f32.hip, waits are all vmcnt(0)): 160 accumulators + 60 fragment registers of 256 -- the tile
     # boundary (residual loads into the accumulators, LayerNorm epilogue) spills, the chunk loop does not (ISA checked, profiles/r03_notes.md)
     r'^gemm_sp_kernel<10, (true|false), (true|false), [01], ': 192,
+    r'^gemm_sp_kernel<10, false, false, 2, ': 192,
+    r'^gemm_sp_kernel<8, false, false, 1, false, false, true>': 16,
     r'^gemm_sp_kernel<10, true, false, 2, ': 1040,       # off by default (lime_set_split_gemm(3))
 }
 

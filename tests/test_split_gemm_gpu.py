@@ -23,7 +23,7 @@ def ops():
 
 @pytest.fixture(autouse=True)
 def _restore(ops):
-    prev = ops.set_split_gemm(True)
+    prev = ops.set_split_gemm(True, force=True)        # every shape below on the split kernel, however few tiles it makes
     yield
     ops.set_split_gemm(prev)
 
@@ -44,13 +44,13 @@ def dev(t):
 
 def both(ops, fn):
     """fn() under the split kernel and under the fp32-MFMA kernel -> (split result, its kernel name, fp32 result)."""
-    ops.set_split_gemm(True)
+    ops.set_split_gemm(True, force=True)
     a = fn().cpu()
     ka = last_kernel()
     ops.set_split_gemm(False)
     b = fn().cpu()
     kb = last_kernel()
-    ops.set_split_gemm(True)
+    ops.set_split_gemm(True, force=True)
     assert ka.startswith('gemm_sp_kernel'), ka
     assert not kb.startswith('gemm_sp_kernel'), kb
     return a, ka, b
@@ -177,10 +177,11 @@ def test_split_gathered_residual_layernorm(ops, M, S):
     from lime_cikm25_amd import _lib
     lib = _lib.load()
     run = lambda: ops.linear(da, dw, db, res=dt, res_ids=dids, res_pe=dpe, res_period=S, ln=(dg, dbe))
+    lib.lime_set_split_gemm(5)
     run()
-    assert last_kernel().startswith('gemm_pp_kernel'), 'by default this instantiation stays on the fp32 kernel: ' + last_kernel()
+    assert last_kernel().startswith('gemm_pp_kernel'), 'without bit 1 this instantiation stays on the fp32 kernel: ' + last_kernel()
     ref = run().cpu()
-    lib.lime_set_split_gemm(3)                           # route it to the split kernel (off by default: slower there)
+    lib.lime_set_split_gemm(7)                           # route it to the split kernel (off by default: slower there)
     got = run().cpu()
     name = last_kernel()
     assert name.startswith('gemm_sp_kernel<10, true, false, 2'), name
@@ -189,7 +190,7 @@ def test_split_gathered_residual_layernorm(ops, M, S):
     out = torch.full((M, N), 7.0, device='cuda')
     ops.linear(da, dw, db, res=dt, res_ids=dids, res_pe=dpe, res_period=S, ln=(dg, dbe), out=out, m_dev=m_dev)
     assert last_kernel().startswith('gemm_sp_kernel'), last_kernel()
-    lib.lime_set_split_gemm(1)
+    lib.lime_set_split_gemm(5)
     assert torch.equal(out[:M - 3000].cpu(), got[:M - 3000]) and (out[M - 3000:] == 7.0).all()
 
 
@@ -240,3 +241,48 @@ def test_small_problems_stay_on_the_fp32_kernels(ops):
     a, w = dev(rnd(3000, 300, seed=1)), dev(rnd(300, 300, seed=2))
     ops.linear(a, w, None)
     assert not last_kernel().startswith('gemm_sp_kernel'), last_kernel()
+
+
+@pytest.mark.parametrize('M,N,K,act', [(14080, 400, 400, 'tanh'), (42240, 400, 400, 'tanh'), (13000, 900, 1800, 'sigmoid'), (20000, 320, 96, 'tanh')])
+def test_split_runtime_activation(ops, M, N, K, act):
+    """tanh / sigmoid in the epilogue (Attention.affine1, layers.py:288; the gates) for the large batches of BASELINE configs[2] / [4]."""
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3)
+    f = torch.tanh if act == 'tanh' else torch.sigmoid
+    da, dw, db = dev(a), dev(w), dev(b)
+    got, name, ref = both(ops, lambda: ops.linear(da, dw, db, act=act))
+    check(got, f(a.double() @ w.double().t() + b.double()), ref, what='split + %s' % act)
+
+
+@pytest.mark.parametrize('M,N,K', [(14080, 400, 900), (16300, 400, 400), (30000, 300, 512)])
+def test_split_gathered_residual_without_layernorm(ops, M, N, K):
+    """LIME.project as encode_flat issues it: content half of the GEMM + the freshness half gathered from a [buckets^2, N] table by the
+    bucket pair (newsEncoders.py:151-153)."""
+    T = 100
+    a, w, table = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(T, N, seed=3)
+    ids = torch.randint(0, T, (M,), generator=torch.Generator().manual_seed(4), dtype=torch.int32)
+    da, dw, dt, dids = dev(a), dev(w), dev(table), dev(ids)
+    got, name, ref = both(ops, lambda: ops.linear(da, dw, None, res=dt, res_ids=dids))
+    assert ', 2, ' in name, name
+    check(got, a.double() @ w.double().t() + table[ids.long()].double(), ref, what='split + gathered residual')
+
+
+@pytest.mark.parametrize('M,H,N,K', [(16000, 50, 400, 400), (81500, 50, 400, 400), (12800, 25, 320, 64)])
+def test_split_broadcast_residual(ops, M, H, N, K):
+    """SAGEConv's lin_r with lin_l(mean) as a residual row shared by the H history rows of a user row (userEncoders.py:153)."""
+    a, w, l = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(M // H, N, seed=3)
+    da, dw, dl = dev(a), dev(w), dev(l)
+    got, name, ref = both(ops, lambda: ops.linear(da, dw, None, res=dl, res_div=H))
+    check(got, a.double() @ w.double().t() + l.double().repeat_interleave(H, dim=0), ref, what='split + broadcast residual')
+
+
+def test_badly_filling_launches_stay_on_the_other_kernels(ops):
+    ops.set_split_gemm(True)                             # the default rules
+    a, w = dev(rnd(5280, 400, seed=1)), dev(rnd(400, 400, seed=2))
+    ops.linear(a, w, None, act='tanh')
+    assert last_kernel().startswith('gemm_mid'), last_kernel()
+    a = dev(rnd(14080, 400, seed=3))                     # 110 tiles of 256 x 256 on 256 CUs
+    ops.linear(a, w, None)
+    assert last_kernel().startswith('gemm_pp'), last_kernel()
+    a = dev(rnd(28160, 400, seed=4))                     # 220 tiles: the split kernel
+    ops.linear(a, w, None)
+    assert last_kernel().startswith('gemm_sp'), last_kernel()
