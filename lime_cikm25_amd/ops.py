@@ -174,7 +174,10 @@ def linear_group(problems):
         return [linear(**kw) for kw in problems]
     lib = _lib.load()
     built = [linear(_build_only=True, **kw) for kw in problems]
-    if any(a.M >= 4096 or a.ln_gamma or a.pool32 or a.c_ids or a.a_pe or a.res_pe or a.K % 4 or a.N % 4 or a.K < 16 for a, _ in built):
+    # only problems lime_linear_f32 itself hands to the mid-M kernel: M < 4096, or below 12288 rows with an epilogue the big-M kernels
+    # take from there on only (tanh / sigmoid, broadcast or gathered residual without LayerNorm)
+    mid = lambda a: a.M < 4096 or (a.M < 12288 and (a.act in (2, 3) or (a.res and (a.res_ids or a.res_div > 1))))
+    if any(not mid(a) or a.ln_gamma or a.pool32 or a.c_ids or a.a_pe or a.res_pe or a.K % 4 or a.N % 4 or a.K < 16 for a, _ in built):
         return [linear(**kw) for kw in problems]
     arr = (LinearArgs * len(built))()
     for i, (a, _) in enumerate(built):
