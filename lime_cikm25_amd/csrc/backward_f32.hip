@@ -12,6 +12,7 @@
 // All dense reductions are fixed-order (partials in a caller workspace, then one summing pass).
 #include "common.h"
 #include "dropout.h"
+#include "gemm_pp.h"
 
 namespace {
 
@@ -1466,10 +1467,20 @@ int ln_blocks(int M) { const int b = (M + 15) / 16; return b > 768 ? 768 : b; } 
 extern "C" int lime_colsum_f32(const float* x, int64_t ldx, int32_t M, int32_t N, float* out, int32_t accumulate,
                                float* workspace, int64_t workspace_floats, void* stream);
 
+// The split-product kernel (wgrad_sp_f32.hip) takes the problems that fill its 256 x 320 tiles: from 4096 rows on (below, the
+// workgroups' slices are a handful of chunks), 16-byte friendly operands, at least half of the padded tile grid real.
+static bool wgrad_sp_shape(int M, int N, int K) { return M >= 4096 && N % 4 == 0 && K % 4 == 0 && N >= 64 && K >= 64 && lime_wgrad_sp_plan(M, N, K).fill >= 0.5; }
+
 extern "C" int64_t lime_linear_wgrad_workspace(int32_t M, int32_t N, int32_t K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const WgradPlan w = wgrad_plan(M, N, K);
-    return (int64_t)w.splits * w.np * w.kp + (int64_t)colsum_blocks(M) * N;      // + the column-sum fallback of db
+    int64_t need = (int64_t)w.splits * w.np * w.kp;
+    if (wgrad_sp_shape(M, N, K)) {                                               // whichever kernel the call ends up on
+        const LimeWgradSpPlan sp = lime_wgrad_sp_plan(M, N, K);
+        const int64_t need_sp = (int64_t)sp.splits * sp.np * sp.kp;
+        if (need_sp > need) need = need_sp;
+    }
+    return need + (int64_t)colsum_blocks(M) * N;                                  // + the column-sum fallback of db
 }
 
 extern "C" int lime_linear_wgrad_f32(const float* dy, int64_t ldy, const float* x, int64_t ldx, float* dw, int64_t lddw,
@@ -1488,6 +1499,21 @@ extern "C" int lime_linear_wgrad_f32(const float* dy, int64_t ldy, const float* 
     LIME_REQUIRE(((long)w.rows_per_split + WG_MC) * (ldy > ldx ? ldy : ldx) * 4 < 0x7FFFFFF0L, LIME_ERR_UNSUPPORTED,
                  "lime_linear_wgrad_f32: a row slice spans more than 2 GB (rows %d, ld %ld)", w.rows_per_split, (long)(ldy > ldx ? ldy : ldx));
     int st;
+    static const bool no_sp = getenv("LIME_WGRAD_NO_SP") != nullptr;          // A/B switch for tools/
+    if (vec && !no_sp && (lime_split_mode() & 1) && wgrad_sp_shape(M, N, K)) {
+        const LimeWgradSpPlan sp = lime_wgrad_sp_plan(M, N, K);
+        LIME_REQUIRE(((long)sp.rows_per_split + 32) * (ldy > ldx ? ldy : ldx) * 4 < 0x7FFFFFF0L, LIME_ERR_UNSUPPORTED,
+                     "lime_linear_wgrad_f32: a row slice spans more than 2 GB (rows %d, ld %ld)", sp.rows_per_split, (long)(ldy > ldx ? ldy : ldx));
+        const int ones = (!sp.swap && db != nullptr && K < sp.kp) ? 1 : 0;
+        st = lime_wgrad_sp_launch(sp, dy, ldy, x, ldx, workspace, M, N, K, ones, s);
+        if (st != LIME_OK) return st;
+        const int64_t used = (int64_t)sp.splits * sp.np * sp.kp;
+        if (sp.swap) st = lime_wgrad_sp_reduce_t(sp, workspace, dw, lddw, N, K, accumulate, s);
+        else st = launch_reduce(workspace, sp.np * sp.kp, sp.splits, sp.kp, dw, lddw, N, K, accumulate, s);
+        if (st != LIME_OK || db == nullptr) return st;
+        if (ones) return launch_reduce(workspace + K, sp.np * sp.kp, sp.splits, sp.kp, db, 1, N, 1, accumulate, s);
+        return lime_colsum_f32(dy, ldy, M, N, db, accumulate, workspace + used, workspace_floats - used, stream);
+    }
     const int ones_col = (db != nullptr && K < w.kp) ? 1 : 0;          // room for a ones column in the padded tile grid
 #define WGRAD(NKT) (vec ? (no_dma ? launch_wgrad<NKT, true>(w, dy, ldy, x, ldx, workspace, M, N, K, ones_col, s)              \
                                   : launch_wgrad_dma<NKT>(w, dy, ldy, x, ldx, workspace, M, N, K, ones_col, s))                \

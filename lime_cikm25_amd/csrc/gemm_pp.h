@@ -25,3 +25,11 @@ struct PPParams {
 int lime_linear_pp(const lime_linear_args* a, hipStream_t stream);
 int lime_linear_sp(const lime_linear_args* a, hipStream_t stream);       // gemm_sp_f32.hip (split product on the bf16 cores), same convention
 int lime_linear_mid(const lime_linear_args* a, hipStream_t stream);      // gemm_mid_f32.hip, same return convention
+
+// wgrad_sp_f32.hip: the weight gradient on the split product (lime_linear_wgrad_f32's big-M path, backward_f32.hip dispatches)
+struct LimeWgradSpPlan { bool swap; int n_tiles, k_tiles, splits, rows_per_split; long np, kp; double fill; };
+LimeWgradSpPlan lime_wgrad_sp_plan(int M, int N, int K);
+int lime_wgrad_sp_launch(const LimeWgradSpPlan& w, const float* dy, long ldy, const float* x, long ldx, float* ws, int M, int N, int K,
+                         int ones_col, hipStream_t s);
+int lime_wgrad_sp_reduce_t(const LimeWgradSpPlan& w, const float* ws, float* dw, long lddw, int N, int K, int accumulate, hipStream_t s);
+int lime_split_mode();                                                   // gemm_sp_f32.hip: the lime_set_split_gemm() setting

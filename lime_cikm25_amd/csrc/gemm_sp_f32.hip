@@ -565,6 +565,11 @@ extern "C" int lime_set_split_gemm(int on) {
     return prev;
 }
 
+int lime_split_mode() {
+    if (g_split_mode < 0) lime_set_split_gemm(-1);
+    return g_split_mode;
+}
+
 // LIME_OK / error: launched (or failed); LIME_PP_NOT_APPLICABLE: the caller takes the fp32-MFMA kernels.
 int lime_linear_sp(const lime_linear_args* a, hipStream_t s) {
     if (g_split_mode < 0) lime_set_split_gemm(-1);

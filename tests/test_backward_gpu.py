@@ -37,9 +37,33 @@ def close(got, want, tol=TIGHT, what=''):
     return e
 
 
+@pytest.mark.parametrize('split', [True, False], ids=['split_product', 'fp32_mfma'])
 @pytest.mark.parametrize('M,N,K', [(1000, 900, 300), (5000, 300, 512), (333, 50, 100), (70, 400, 1800), (4099, 512, 300),
-                                   (20000, 960, 300)])
-def test_wgrad(ops, M, N, K):
+                                   (20000, 960, 300), (4127, 300, 300), (8200, 1024, 640), (6000, 64, 320), (4096, 300, 304)])
+def test_wgrad(ops, M, N, K, split):
+    """From 4096 rows on the default kernel is the split-product one (csrc/wgrad_sp_f32.hip; (5000, 300, 512) runs transposed,
+    (4127, 300, 300) has a 44-row tile tail and a ragged last chunk, (8200, 1024, 640) several tiles both ways, (4096, 300, 304)
+    the ones column in its own 16-column tile); `split=False`: the fp32-MFMA kernels for every shape."""
+    prev = ops.set_split_gemm(split)
+    try:
+        _wgrad_case(ops, M, N, K)
+    finally:
+        ops.set_split_gemm(prev)
+
+
+def test_wgrad_small_magnitudes(ops):
+    """Gradient-sized operands (1e-7 .. 1e-3, mixed signs) through the split product: bf16 has fp32's exponent range."""
+    M, N, K = 6000, 300, 300
+    g = torch.Generator().manual_seed(5)
+    dy = rnd(M, N, seed=1) * torch.pow(10.0, -3 - 4 * torch.rand(M, 1, generator=g))
+    x = rnd(M, K, seed=2)
+    want = (dy.double().t() @ x.double()).float()
+    got, got_b = ops.linear_wgrad(dy.cuda(), x.cuda(), want_bias=True)
+    close(got, want, what='wgrad small magnitudes')
+    close(got_b, dy.double().sum(0).float(), what='bias gradient small magnitudes')
+
+
+def _wgrad_case(ops, M, N, K):
     dy, x = rnd(M, N, seed=1), rnd(M, K, seed=2)
     want = (dy.double().t() @ x.double()).float()
     got, got_b = ops.linear_wgrad(dy.cuda(), x.cuda(), want_bias=True)
