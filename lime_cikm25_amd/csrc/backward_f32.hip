@@ -1399,7 +1399,9 @@ WgradPlan wgrad_plan(int M, int N, int K, int wg_per_cu = 1) {
     w.kp = (long)w.k_tiles * w.tk;
     const int ntile = w.n_tiles * w.k_tiles;
     int splits = 256 * wg_per_cu / ntile;                         // a single round of eight-wave workgroups, one per CU
-    const int max_splits = (M + 511) / 512;                       // at least 8 chunks of 64 rows per workgroup
+    // at least 8 chunks of 64 rows per workgroup -- but the small-M problems of the layers around the encoders (B x 55 = 1760 rows: 36
+    // workgroups of 9 serial chunks took 50 us) go down to 2 chunks so that a launch reaches ~150 workgroups
+    const int max_splits = M >= 8192 ? (M + 511) / 512 : (M + 127) / 128;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     int rps = (M + splits - 1) / splits;

@@ -20,6 +20,7 @@
 // LDS; Q fragments come straight from global memory in MFMA operand form; short sequences pack 4 (S <= 32)
 // or 2 (S <= 64) pairs per group.  Scores live in the log2 domain so the exponential is one v_exp_f32.
 #include "common.h"
+#include "gemm_pp.h"
 #include <type_traits>
 
 #ifdef LIME_STAMPS
@@ -547,8 +548,12 @@ extern "C" int lime_token_attention_rows_f32(const float* q, const float* k, con
                  LIME_ERR_BAD_ARG, "lime_token_attention_rows_f32: heads are 32 columns apart (zero padded), rows 16-byte aligned");
     LIME_REQUIRE(ldo >= (int64_t)n_head * head_dim, LIME_ERR_BAD_ARG, "lime_token_attention_rows_f32: ldo smaller than n_head * head_dim");
     if (n_seq == 0) return LIME_OK;
-    AttnP p{q, k, v, (long)ld_qkv, nullptr, out, (long)ldo, n_seq, S, n_head, head_dim, 32, scale, n_seq * n_head, 1, 0, 0, row_map, n_seq_dev};
     hipStream_t s = (hipStream_t)stream;
+    {   // S <= 128: the split-product kernel (token_attn_sp_f32.hip) unless lime_set_split_gemm(0)
+        const int st = lime_token_attention_sp(q, k, v, (long)ld_qkv, row_map, n_seq_dev, out, (long)ldo, n_seq, S, n_head, head_dim, scale, s);
+        if (st != LIME_PP_NOT_APPLICABLE) return st;
+    }
+    AttnP p{q, k, v, (long)ld_qkv, nullptr, out, (long)ldo, n_seq, S, n_head, head_dim, 32, scale, n_seq * n_head, 1, 0, 0, row_map, n_seq_dev};
     switch (S / 32) {
         case 1: return launch_map<1>(p, s);
         case 2: return launch_map<2>(p, s);
@@ -574,8 +579,12 @@ extern "C" int lime_token_attention_count_f32(const float* q, const float* k, co
     // 8-byte loads need an even head_dim and leading dimension and 8-byte aligned bases
     const int vec2 = (head_dim % 2 == 0) && (head_stride % 2 == 0) && (ld_qkv % 2 == 0) &&
                      (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 8 == 0);
-    AttnP p{q, k, v, (long)ld_qkv, key_mask, out, (long)ldo, n_seq, S, n_head, head_dim, head_stride, scale, n_seq * n_head, vec2, 0, 0, nullptr, n_seq_dev};
     hipStream_t s = (hipStream_t)stream;
+    if (key_mask == nullptr && head_stride == 32) {   // the encoder layers' shapes: the split-product kernel (token_attn_sp_f32.hip)
+        const int st = lime_token_attention_sp(q, k, v, (long)ld_qkv, nullptr, n_seq_dev, out, (long)ldo, n_seq, S, n_head, head_dim, scale, s);
+        if (st != LIME_PP_NOT_APPLICABLE) return st;
+    }
+    AttnP p{q, k, v, (long)ld_qkv, key_mask, out, (long)ldo, n_seq, S, n_head, head_dim, head_stride, scale, n_seq * n_head, vec2, 0, 0, nullptr, n_seq_dev};
     const int nt = (S + 31) / 32;
     if (nt <= 1) return launch<1>(p, s);
     if (nt <= 2) return launch<2>(p, s);

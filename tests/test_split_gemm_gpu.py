@@ -286,3 +286,69 @@ def test_badly_filling_launches_stay_on_the_other_kernels(ops):
     a = dev(rnd(28160, 400, seed=4))                     # 220 tiles: the split kernel
     ops.linear(a, w, None)
     assert last_kernel().startswith('gemm_sp'), last_kernel()
+
+
+# ---------------------------------------------------------------------------------------------------
+# token attention on the split product (csrc/token_attn_sp_f32.hip)
+# ---------------------------------------------------------------------------------------------------
+def _attn_ref64(qkv, n_seq, S, h, hd, scale):
+    E = h * hd
+    q, k, v = [t.double().view(n_seq, S, h, hd).transpose(1, 2) for t in qkv.split(E, dim=1)]
+    a = (q * scale) @ k.transpose(-2, -1)
+    return (torch.softmax(a, dim=-1) @ v).transpose(1, 2).reshape(n_seq * S, E)
+
+
+@pytest.mark.parametrize('S', [32, 64, 128])
+@pytest.mark.parametrize('h,hd,n_seq', [(10, 30, 37), (7, 20, 5), (3, 32, 1), (10, 30, 700)])
+def test_token_attention_split_product(ops, S, h, hd, n_seq):
+    """The encoder layers' attention (heads padded to 32 columns, no mask) on the bf16 matrix cores: against fp64, and no further
+    from it than the fp32-MFMA kernel plus a rounding.  n_seq x h is not a multiple of the pairs per group (partial last group);
+    700 sequences make every persistent workgroup walk several groups (the register prefetch)."""
+    E, W = h * hd, h * 32
+    qkv = rnd(n_seq * S, 3 * E, seed=S + h, scale=2.0)
+    padded = ops.pad_heads(dev(qkv.t().contiguous()), 3 * h, hd, 32).t().contiguous()
+    scale = 1.0 / math.sqrt(hd)
+    run = lambda: ops.token_attention(padded[:, :W], padded[:, W:2 * W], padded[:, 2 * W:], n_seq, S, h, hd, scale, head_stride=32)
+    ops.set_split_gemm(True)
+    a = run().cpu()
+    ops.set_split_gemm(False)
+    b = run().cpu()
+    ops.set_split_gemm(True, force=True)
+    want = _attn_ref64(qkv, n_seq, S, h, hd, scale)
+    ea, eb = rel_err(a.double().numpy(), want.numpy()), rel_err(b.double().numpy(), want.numpy())
+    assert torch.isfinite(a).all()
+    assert ea <= TIGHT and ea <= 2.0 * eb + 2e-7, (ea, eb)
+    assert not torch.equal(a, b)                        # two different kernels did run
+
+
+def test_token_attention_split_product_wide_scores(ops):
+    """Peaked softmaxes (|score| up to ~60): the three-term split keeps q . k to fp32 accuracy where one bf16 term would not."""
+    n_seq, S, h, hd = 9, 128, 10, 30
+    E, W = h * hd, h * 32
+    qkv = rnd(n_seq * S, 3 * E, seed=5, scale=6.0)
+    padded = ops.pad_heads(dev(qkv.t().contiguous()), 3 * h, hd, 32).t().contiguous()
+    scale = 1.0 / math.sqrt(hd)
+    got = ops.token_attention(padded[:, :W], padded[:, W:2 * W], padded[:, 2 * W:], n_seq, S, h, hd, scale, head_stride=32).cpu()
+    want = _attn_ref64(qkv, n_seq, S, h, hd, scale)
+    assert rel_err(got.double().numpy(), want.numpy()) <= TIGHT
+
+
+@pytest.mark.parametrize('S', [32, 128])
+def test_token_attention_rows_split_product(ops, S):
+    """The row-map variant (compacted batches): bit-identical to the dense call on the materialised rows, device-side sequence count."""
+    n_seq, h, hd = 23, 10, 30
+    W = h * 32
+    g = torch.Generator().manual_seed(S)
+    n_rows = 400
+    qkv = (torch.rand(n_rows, 3 * W, generator=g) * 4 - 2)
+    qkv.view(n_rows, 3 * h, 32)[:, :, hd:] = 0
+    row_map = torch.randint(0, n_rows, (n_seq * S,), generator=g, dtype=torch.int32)
+    d, rm = dev(qkv), dev(row_map)
+    full = d[rm.long()]
+    scale = 1.0 / math.sqrt(hd)
+    want = ops.token_attention(full[:, :W], full[:, W:2 * W], full[:, 2 * W:], n_seq, S, h, hd, scale, head_stride=32)
+    n_dev = torch.tensor([n_seq - 3], dtype=torch.int32, device='cuda')
+    got = ops.token_attention_rows(d[:, :W], d[:, W:2 * W], d[:, 2 * W:], rm, n_dev, n_seq, S, h, hd, scale)
+    torch.cuda.synchronize()
+    live = (n_seq - 3) * S
+    assert torch.equal(got[:live], want[:live])

@@ -35,7 +35,7 @@ def main():
         names = [short(r[0]) for r in rows]
         # find period: index distance between repeats of the whole sequence
         period = None
-        for p in range(20, 400):
+        for p in range(20, 1500):
             mid = len(rows) // 2
             if names[mid:mid + p] == names[mid + p:mid + 2 * p]:
                 period = p
