@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LIME_ABI_VERSION 5
+#define LIME_ABI_VERSION 6
 
 typedef enum {
     LIME_OK = 0,
@@ -42,7 +42,8 @@ int lime_abi_version(void);
 const char* lime_last_error_string(void);
 
 /* activation applied after bias (+ residual) */
-enum { LIME_ACT_NONE = 0, LIME_ACT_RELU = 1, LIME_ACT_TANH = 2, LIME_ACT_SIGMOID = 3 };
+enum { LIME_ACT_NONE = 0, LIME_ACT_RELU = 1, LIME_ACT_TANH = 2, LIME_ACT_SIGMOID = 3,
+       LIME_ACT_RELU_GRAD = 4 /* backward of a ReLU: v = res(r, n) > 0 ? v * act_scale : 0, res = the forward activation (no residual add) */ };
 
 /*
  * lime_linear_f32: C = epilogue(A . W^T + bias), exact-fp32 MFMA: v_mfma_f32_16x16x4_f32 in the LDS-DMA kernel that takes the
@@ -98,6 +99,9 @@ typedef struct {
     const int32_t* c_ids; /* optional int32 [M]: the A rows are a compacted row list -- result row r is stored at c[c_ids[r] * ldc] and
                              the periodic residual is res[(c_ids[r] % res_mod) * ldr].  Needs res with res_mod > 0, no LayerNorm, act none
                              (the in_proj GEMM over the non-padding tokens of a batch). */
+    float act_scale;      /* LIME_ACT_RELU_GRAD only: the factor on the passed gradient (1 / (1 - p) when the forward ReLU output went
+                             through dropout in place: h > 0 <=> ReLU passed AND the mask kept); dH = dY W2 with the ReLU gradient of
+                             linear1 applied in the epilogue (trainer.py:145 through newsEncoders.py:244-247).  res = h, dense rows. */
 } lime_linear_args;
 
 int lime_linear_f32(const lime_linear_args* args, void* stream);

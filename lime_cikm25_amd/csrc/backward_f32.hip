@@ -102,6 +102,43 @@ __global__ __launch_bounds__(256) void reduce_partials_vec4_kernel(const float* 
     }
 }
 
+// The three column sums of layernorm_bwd (dgamma, dbeta, dzsum) out of its per-workgroup partials ws[blk][3][E] in ONE launch:
+// a workgroup owns 16 groups of four consecutive floats of the 3 E, its 16 split lanes take the blocks s, s + 16, ... (up to 768
+// blocks: 48 independent 16-byte loads per thread instead of 192 dependent-issue ones in two workgroups, 18 us per vector) and their
+// sums meet in LDS in a fixed order.  E % 4 == 0.
+__global__ __launch_bounds__(256) void reduce_ln3_kernel(const float* __restrict__ ws, int nblk, int E, float* __restrict__ o0,
+                                                          float* __restrict__ o1, float* __restrict__ o2, int accumulate) {
+    __shared__ f32x4v red[16][16];
+    const int cg = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int g = blockIdx.x * 16 + cg, ng = 3 * E / 4;
+    f32x4v s = {0.f, 0.f, 0.f, 0.f};
+    if (g < ng) {
+        const float* p = ws + 4L * g;
+        int i = sl;
+        for (; i + 48 < nblk; i += 64) {
+            f32x4v v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4v*>(p + (long)(i + 16 * u) * 3 * E);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += v[u];
+        }
+        for (; i < nblk; i += 16) s += *reinterpret_cast<const f32x4v*>(p + (long)i * 3 * E);
+    }
+    red[sl][cg] = s;
+    __syncthreads();
+    if (sl == 0 && g < ng) {
+        f32x4v t = red[0][cg];
+#pragma unroll
+        for (int u = 1; u < 16; ++u) t += red[u][cg];
+        const int c = 4 * g, k = c / E, cc = c - k * E;          // E % 4 == 0: a group never leaves its vector
+        float* const o = k == 0 ? o0 : (k == 1 ? o1 : o2);
+        if (o) {
+            f32x4v* q = reinterpret_cast<f32x4v*>(o + cc);
+            *q = accumulate ? *q + t : t;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // wgrad: workgroup = one 128 x TK tile of dW (TK = 64 NKT: the whole K of the encoder layers' 300-wide operands) over one
 // slice of the M rows.  Eight waves in a 2 x 4 grid, each a 64 x 16 NKT patch (4 x NKT accumulator tiles of 16 x 16), two
@@ -1278,33 +1315,36 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ 
 // Tables of at most 32 rows (the freshness / lifetime bucket embeddings, 10 rows x 500): every row receives hundreds of
 // contributions, so atomics would serialise.  A workgroup owns 64 columns; its four waves walk the rows r = wave, wave + 4,
 // ... and add into a private [32][64] LDS image each; the four images are summed in a fixed order.  No atomics.
-__global__ __launch_bounds__(256) void embed_bwd_small_kernel(const int* __restrict__ ids, const float* __restrict__ dx, long lddx,
+__global__ __launch_bounds__(512) void embed_bwd_small_kernel(const int* __restrict__ ids, const float* __restrict__ dx, long lddx,
                                                                float* __restrict__ dtable, long ldt, long rows, int dim,
                                                                int table_rows) {
-    __shared__ float acc[4][32][64];
+    // eight waves, each with its own [32][64] image of the table and sixteen rows in flight (one 64-column workgroup walks every
+    // row: with four waves and eight rows in flight the 1760 rows of a 50-column table took 55 us of dependent round trips)
+    __shared__ float acc[8][32][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     for (int t = 0; t < 32; ++t) acc[wave][t][lane] = 0.f;
     if (c < dim) {
         long r = wave;
-        for (; r + 28 < rows; r += 32) {                    // eight rows in flight per wave
-            int id[8];
-            float v[8];
+        for (; r + 120 < rows; r += 128) {
+            int id[16];
+            float v[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { id[u] = ids[r + 4 * u]; v[u] = dx[(r + 4 * u) * lddx + c]; }
+            for (int u = 0; u < 16; ++u) { id[u] = ids[r + 8 * u]; v[u] = dx[(r + 8 * u) * lddx + c]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 16; ++u)
                 if (id[u] >= 0 && id[u] < table_rows) acc[wave][id[u]][lane] += v[u];
         }
-        for (; r < rows; r += 4) {
+        for (; r < rows; r += 8) {
             const int id = ids[r];
             if (id >= 0 && id < table_rows) acc[wave][id][lane] += dx[r * lddx + c];
         }
     }
     __syncthreads();
     if (c < dim)
-        for (int t = wave; t < table_rows; t += 4)
-            dtable[(long)t * ldt + c] += (acc[0][t][lane] + acc[1][t][lane]) + (acc[2][t][lane] + acc[3][t][lane]);
+        for (int t = wave; t < table_rows; t += 8)
+            dtable[(long)t * ldt + c] += ((acc[0][t][lane] + acc[1][t][lane]) + (acc[2][t][lane] + acc[3][t][lane])) +
+                                         ((acc[4][t][lane] + acc[5][t][lane]) + (acc[6][t][lane] + acc[7][t][lane]));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1581,6 +1621,10 @@ extern "C" int lime_layernorm_bwd_f32(const float* dy, int64_t lddy, int32_t dy_
     }
     int st = lime_check_launch("layernorm_bwd_kernel");
     if (st != LIME_OK) return st;
+    if (E % 4 == 0 && ((((uintptr_t)dgamma) | ((uintptr_t)dbeta) | ((uintptr_t)dzsum) | ((uintptr_t)workspace)) & 15) == 0) {
+        reduce_ln3_kernel<<<(3 * E / 4 + 15) / 16, 256, 0, s>>>(workspace, nblk, E, dgamma, dbeta, dzsum, accumulate);
+        return lime_check_launch("reduce_ln3_kernel");
+    }
     float* outs[3] = {dgamma, dbeta, dzsum};
     for (int k = 0; k < 3; ++k) {
         if (!outs[k]) continue;
@@ -1772,7 +1816,7 @@ extern "C" int lime_embed_bwd_small_f32(const int32_t* ids, const float* dx, int
     LIME_REQUIRE(rows >= 0 && dim > 0 && lddx >= dim && ld_table >= dim, LIME_ERR_BAD_ARG, "lime_embed_bwd_small_f32: bad dimensions");
     LIME_REQUIRE(table_rows >= 1 && table_rows <= 32, LIME_ERR_UNSUPPORTED, "lime_embed_bwd_small_f32: table_rows = %d outside [1, 32]", table_rows);
     if (rows == 0) return LIME_OK;
-    embed_bwd_small_kernel<<<(dim + 63) / 64, 256, 0, (hipStream_t)stream>>>(ids, dx, lddx, dtable, ld_table, rows, dim, table_rows);
+    embed_bwd_small_kernel<<<(dim + 63) / 64, 512, 0, (hipStream_t)stream>>>(ids, dx, lddx, dtable, ld_table, rows, dim, table_rows);
     return lime_check_launch("embed_bwd_small_kernel");
 }
 

@@ -595,6 +595,9 @@ inline bool aligned(const void* ptr, long ld, int vec) {
 
 }  // namespace
 
+extern "C" int lime_relu_bwd_f32(float* dh, int64_t lddh, const float* h, int64_t ldh, int64_t rows, int32_t cols, float scale,
+                                 void* stream);          // backward_f32.hip
+
 extern "C" int lime_linear_f32(const lime_linear_args* a, void* stream) {
     LIME_REQUIRE(a != nullptr, LIME_ERR_BAD_ARG, "lime_linear_f32: args is NULL");
     LIME_REQUIRE(a->a && a->w && a->c, LIME_ERR_BAD_ARG, "lime_linear_f32: a, w and c must be non-NULL");
@@ -610,10 +613,23 @@ extern "C" int lime_linear_f32(const lime_linear_args* a, void* stream) {
     LIME_REQUIRE(!a->res_pe || (a->res_ids && a->res_period > 0 && a->ldr_pe >= a->N), LIME_ERR_BAD_ARG,
                  "lime_linear_f32: res_pe needs res_ids, res_period > 0 and ldr_pe >= N");
     LIME_REQUIRE(!a->ln_gamma || a->ln_beta, LIME_ERR_BAD_ARG, "lime_linear_f32: ln_gamma without ln_beta");
-    LIME_REQUIRE(a->act >= LIME_ACT_NONE && a->act <= LIME_ACT_SIGMOID, LIME_ERR_BAD_ARG, "lime_linear_f32: bad act %d", a->act);
+    LIME_REQUIRE(a->act >= LIME_ACT_NONE && a->act <= LIME_ACT_RELU_GRAD, LIME_ERR_BAD_ARG, "lime_linear_f32: bad act %d", a->act);
     LIME_REQUIRE(a->res_mod >= 0 && (a->pool32 == 0 || a->pool32 == 1), LIME_ERR_BAD_ARG, "lime_linear_f32: res_mod < 0 or pool32 not 0 / 1");
     LIME_REQUIRE(!a->ln_rstd || (a->ln_gamma && !a->pool32), LIME_ERR_BAD_ARG, "lime_linear_f32: ln_rstd needs the LayerNorm epilogue without pool32");
     if (a->M == 0) return LIME_OK;
+
+    if (a->act == LIME_ACT_RELU_GRAD) {               // the ReLU gradient as an epilogue: fused in the split-product kernel, else two launches
+        LIME_REQUIRE(a->res && !a->res_ids && a->res_mod == 0 && a->res_div <= 1 && !a->ln_gamma && !a->pool32 && !a->m_dev && !a->c_ids,
+                     LIME_ERR_BAD_ARG, "lime_linear_f32: LIME_ACT_RELU_GRAD takes res = the forward activation (dense rows) and no other epilogue");
+        const int sp = lime_linear_sp(a, (hipStream_t)stream);
+        if (sp != LIME_PP_NOT_APPLICABLE) return sp;
+        lime_linear_args plain = *a;
+        plain.act = LIME_ACT_NONE;
+        plain.res = nullptr;
+        const int st = lime_linear_f32(&plain, stream);
+        if (st != LIME_OK) return st;
+        return lime_relu_bwd_f32(a->c, a->ldc, a->res, a->ldr, a->M, a->N, a->act_scale, stream);
+    }
 
     // big M, 16-byte friendly operands: two four-wave workgroups per CU with LDS-DMA staging (gemm_pp_f32.hip)
     static const bool pp_off = getenv("LIME_GEMM_NO_PP") != nullptr;          // A/B switch for tools/, not a product option

@@ -17,6 +17,7 @@ struct PPParams {
     const int* c_ids;    // optional (CID instantiations): output row of A row r is c_ids[r]; a periodic residual is indexed by it
     int act = 0;         // gemm_sp_kernel only, instantiations without the ReLU template flag: LIME_ACT_TANH / LIME_ACT_SIGMOID at run time
     int res_div = 1;     // gemm_sp_kernel only (RES == 1 without res_mod): residual row = r / res_div (one row broadcast to res_div rows)
+    float act_scale = 1.f;   // gemm_sp_kernel, RES == 3 (LIME_ACT_RELU_GRAD): v = res > 0 ? v * act_scale : 0
 #ifdef LIME_STAMPS
     unsigned long long* stamps;
 #endif

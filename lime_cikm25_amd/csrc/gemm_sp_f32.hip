@@ -100,7 +100,7 @@ __device__ __forceinline__ f32x4 mfma6(const Split& w, const Split& a, f32x4 c) 
 
 // CT: 16-column tiles per wave (tile width 32 CT).  LN / RELU / RES / POOL / RSTD / CID as in gemm_pp_kernel:
 // RES 0 none, 1 dense fp32 residual rows (r, or r % res_mod; with CID: c_ids[r] % res_mod), 2 rows gathered by res_ids + the fp32
-// positional table.
+// positional table, 3 no residual: `res` holds the forward ReLU output whose sign gates the result (LIME_ACT_RELU_GRAD).
 template <int CT, bool LN, bool RELU, int RES, bool POOL, bool RSTD, bool CID>
 __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
     constexpr int BN = 32 * CT;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
 #pragma unroll                                   // half is re-parked for the next tile before the epilogue reads them
             for (int i = 0; i < 4; ++i) crow[i] = ids[sel * BM + 64 * wr + 16 * i + fi];
         }
-        if constexpr (RES == 0 || RES == 2) {       // RES == 2: the gathered rows + positional rows are added in the epilogue (two
+        if constexpr (RES == 0 || RES == 2 || RES == 3) {       // RES == 2: the gathered rows + positional rows are added in the epilogue (two
 #pragma unroll                                   // loads per element into the accumulators here spilled 186 registers)
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -338,6 +338,13 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
             const int rl = 64 * wr + 16 * i + fi;
             cof[i] = (row0 + rl < M) ? (unsigned)(CID ? crow[i] : rl) * (unsigned)ldc4 + (unsigned)(cw0 + 4 * kg) * 4u : OOB;
         }
+        if constexpr (RES == 3) {                   // the forward activation h of this tile: rows row0 + rl of p.res
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rl = 64 * wr + 16 * i + fi;
+                if (row0 + rl < M) rof[i] = (unsigned)(row0 + rl) * (unsigned)ldr4 + (unsigned)(cw0 + 4 * kg) * 4u;
+            }
+        }
         if constexpr (RES == 2) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -359,6 +366,11 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
                     rr[i] = buf_load4(rs_res2, okc ? rof[i] + (unsigned)t * 64u : OOB, col0 * 4) +
                             buf_load4(rs_rpe2, okc ? pof[i] + (unsigned)t * 64u : OOB, col0 * 4);
             }
+            if constexpr (RES == 3) {
+                const bool okc = col0 + cw0 + 16 * t + 4 * kg < p.N;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rr[i] = buf_load4(rs_res2, okc ? rof[i] + (unsigned)t * 64u : OOB, col0 * 4);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 f32x4 v = acc[i][t] + b;
@@ -375,6 +387,10 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
                     }
                 }
                 if constexpr (RES == 2) v += rr[i];               // act(acc + bias) + residual, the documented order
+                if constexpr (RES == 3) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = rr[i][j] > 0.f ? v[j] * p.act_scale : 0.f;
+                }
                 if constexpr (!LN) {                   // nothing of the row is needed any more: store now (the accumulators die here)
                     buf_store4(v, rs_c, (col0 + cw0 + 16 * t + 4 * kg < p.N) ? cof[i] + (unsigned)t * 64u : OOB, 0);
                 }
@@ -384,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
                     for (int j = 0; j < 4; ++j) { sum[i] += v[j]; sq[i] += v[j] * v[j]; }
                 }
             }
-            if constexpr (RES == 2) __builtin_amdgcn_sched_barrier(0);      // one column tile's eight residual loads at a time
+            if constexpr (RES == 2 || RES == 3) __builtin_amdgcn_sched_barrier(0);      // one column tile's residual loads at a time
         }
         float mean[4] = {0.f, 0.f, 0.f, 0.f}, rstd[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (LN) {
@@ -578,7 +594,9 @@ int lime_linear_sp(const lime_linear_args* a, hipStream_t s) {
     const bool relu = a->act == LIME_ACT_RELU;
     if (a->a_pe != nullptr) return LIME_PP_NOT_APPLICABLE;
     const bool act_rt = a->act == LIME_ACT_TANH || a->act == LIME_ACT_SIGMOID;       // applied at run time in the epilogue
-    if (!(a->act == LIME_ACT_NONE || (relu && !has_res) || (act_rt && !ln && (!has_res || a->res_ids)))) return LIME_PP_NOT_APPLICABLE;
+    const bool relu_grad = a->act == LIME_ACT_RELU_GRAD;
+    if (relu_grad && (!has_res || ln || a->res_ids || a->res_mod > 0 || a->res_div > 1 || a->c_ids || a->pool32)) return LIME_PP_NOT_APPLICABLE;
+    if (!(a->act == LIME_ACT_NONE || relu_grad || (relu && !has_res) || (act_rt && !ln && (!has_res || a->res_ids)))) return LIME_PP_NOT_APPLICABLE;
     if (a->K % 4 || a->N % 4 || a->K < 64) return LIME_PP_NOT_APPLICABLE;          // >= 2 chunks (row lists, bias image)
     if (!al16(a->a, a->lda) || !al16(a->w, a->ldw) || !al16(a->c, a->ldc) || !al16(a->res, a->ldr) || !al16(a->res_pe, a->ldr_pe))
         return LIME_PP_NOT_APPLICABLE;
@@ -591,7 +609,10 @@ int lime_linear_sp(const lime_linear_args* a, hipStream_t s) {
         (long)a->M * 4 >= lim)
         return LIME_PP_NOT_APPLICABLE;
     int res = 0;
-    if (has_res) {
+    if (relu_grad) {
+        if ((long)a->M * a->ldr * 4 >= lim) return LIME_PP_NOT_APPLICABLE;
+        res = 3;
+    } else if (has_res) {
         if (a->res_ids) res = 2;
         else res = 1;                                  // dense, periodic (res_mod) or broadcast (res_div > 1) rows
         if (res == 1 && a->res_mod > 0 && (long)a->res_mod * a->ldr * 4 >= lim) return LIME_PP_NOT_APPLICABLE;
@@ -638,6 +659,7 @@ int lime_linear_sp(const lime_linear_args* a, hipStream_t s) {
     p.m_dev = a->m_dev; p.c_ids = a->c_ids;
     p.act = act_rt ? a->act : 0;
     p.res_div = (res == 1 && a->res_div > 1) ? a->res_div : 1;
+    p.act_scale = a->act_scale;
     {   // diagnostic: LIME_SP_MASK disables classes of instantiations (bit 0 c_ids, 1 LayerNorm + rstd, 2 LayerNorm, 3 residual,
         // 4 ReLU, 5 plain; bit 6: the 256-column tiles)
         static const int mask = getenv("LIME_SP_MASK") ? atoi(getenv("LIME_SP_MASK")) : 0;
@@ -654,6 +676,10 @@ int lime_linear_sp(const lime_linear_args* a, hipStream_t s) {
         if (res == 0) return LIME_PP_NOT_APPLICABLE;
         if (res == 1) return a->pool32 ? launch<10, true, false, 1, true>(p, s) : launch<10, true, false, 1>(p, s);
         return launch<10, true, false, 2>(p, s);
+    }
+    if (res == 3) {                                    // (the 320-column instantiation puts 33 registers in scratch: not built; linear1 is 512 wide)
+        if (wide) return LIME_PP_NOT_APPLICABLE;
+        return launch<8, false, false, 3>(p, s);
     }
     if (res == 2) return wide ? launch<10, false, false, 2>(p, s) : launch<8, false, false, 2>(p, s);
     if (wide) {

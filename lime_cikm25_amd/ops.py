@@ -69,7 +69,7 @@ def set_split_gemm(on, force=False):
 
 def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=0, res=None, res_div=1, res_ids=None,
            res_pe=None, res_period=0, ln=None, ln_eps=1e-5, res_mod=0, pool32=False, ln_rstd=None, n_alg=None, m_dev=None,
-           c_ids=None, _build_only=False):
+           c_ids=None, act_scale=1.0, _build_only=False):
     """C = epilogue(A . W^T + bias) -- see ``lime_linear_f32`` in include/lime_hip.h.
 
     n_alg: the number of USEFUL output columns when w carries zero padding rows (in_proj with heads padded to 32 columns:
@@ -147,6 +147,7 @@ def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=
     args.c, args.ldc = out.data_ptr(), _ld(out)
     args.M, args.N, args.K = M, N, K
     args.act = LIME_ACT[act]
+    args.act_scale = act_scale
     if _build_only:
         return args, out
     if PROFILE is not None:

@@ -303,8 +303,8 @@ class _TokenEncoder(torch.autograd.Function):
             dl2_w, dl2_b = ops.linear_wgrad(dt2, h, want_bias=True)
         else:
             dl2_w = ops.linear_wgrad(dt2, h)
-        dh = ops.linear(dt2, l2_w.t().contiguous(), None)
-        ops.relu_bwd_(dh, h, keep_scale)                                           # h > 0 <=> ReLU passed and the mask kept
+        # dH = dT2 W2 with the ReLU (and dropout) gradient in the GEMM's epilogue: h > 0 <=> ReLU passed and the mask kept
+        dh = ops.linear(dt2, l2_w.t().contiguous(), None, act='relu_grad', res=h, act_scale=keep_scale)
         del h, dt2
         dl1_w, dl1_b = ops.linear_wgrad(dh, x1, want_bias=True)
         dx1 = ops.linear(dh, l1_w.t().contiguous(), None, res=dz2)                 # through linear1 + the residual branch
@@ -418,8 +418,8 @@ class _EncoderLayer(torch.autograd.Function):
             dl2_w, dl2_b = ops.linear_wgrad(dt2, h, want_bias=True)
         else:
             dl2_w = ops.linear_wgrad(dt2, h)
-        dh = ops.linear(dt2, l2_w.t().contiguous(), None)
-        ops.relu_bwd_(dh, h, keep_scale)                                           # h > 0 <=> ReLU passed and the mask kept
+        # dH = dT2 W2 with the ReLU (and dropout) gradient in the GEMM's epilogue: h > 0 <=> ReLU passed and the mask kept
+        dh = ops.linear(dt2, l2_w.t().contiguous(), None, act='relu_grad', res=h, act_scale=keep_scale)
         dl1_w, dl1_b = ops.linear_wgrad(dh, x1, want_bias=True)
         dx1 = ops.linear(dh, l1_w.t().contiguous(), None, res=dz2)                 # through linear1 + the residual branch
         del dh, dz2

@@ -352,3 +352,19 @@ def test_token_attention_rows_split_product(ops, S):
     torch.cuda.synchronize()
     live = (n_seq - 3) * S
     assert torch.equal(got[:live], want[:live])
+
+
+@pytest.mark.parametrize('M,N,K,scale', [(5000, 512, 300, 1.0), (4096, 512, 300, 1.25), (300, 512, 300, 1.25), (5000, 300, 512, 2.0)])
+def test_relu_grad_epilogue(ops, M, N, K, scale):
+    """LIME_ACT_RELU_GRAD (dH = (h > 0) ? (dY W) * scale : 0): fused into the split kernel's epilogue for the 256-column tiles
+    from 4096 rows on, GEMM + relu_bwd_kernel otherwise -- the same result either way, and equal to the two-step form."""
+    dy, w, h = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(M, N, seed=3)
+    h = torch.where(h > 0.3, h, torch.zeros_like(h))                     # a ReLU output: exact zeros where it did not pass
+    want = torch.where(h > 0, (dy.double() @ w.double().t()) * scale, torch.zeros(M, N, dtype=torch.float64))
+    got = ops.linear(dev(dy), dev(w), None, act='relu_grad', res=dev(h), act_scale=scale).cpu()
+    k = last_kernel()
+    assert (k == 'gemm_sp_kernel<8, false, false, 3, false, false, false>') == (M >= 4096 and N == 512), k
+    assert rel_err(got.double().numpy(), want.numpy()) <= TIGHT
+    assert torch.equal(got == 0, (h <= 0) | (got == 0))                  # gated entries are exact zeros
+    two = ops.relu_bwd_(ops.linear(dev(dy), dev(w), None), dev(h), scale).cpu()
+    assert rel_err(got.double().numpy(), two.double().numpy()) <= 2e-6
