@@ -637,15 +637,16 @@ int lime_linear_sp(const lime_linear_args* a, hipStream_t s) {
     // From the same M on as gemm_pp_f32.hip takes over from the mid-M kernel ...
     if (a->M < 4096) return LIME_PP_NOT_APPLICABLE;
     // ... and only where 256-row tiles on one workgroup per CU fill the chip: a launch is `rounds` passes of ncu tiles, and a tile
-    // block that hangs over N computes dead columns.  Below ~0.55 of (tiles / (rounds x ncu)) x (N / covered columns) the 128-row /
-    // 64-row tile kernels win (tools/exp/sp_vs_mid.py: M = 14k, N = 400 -- 110 tiles -- 73 us here, 57 us there; M = 28k: 79 vs 95).
+    // block that hangs over N computes dead columns.  Below ~0.45 of (tiles / (rounds x ncu)) x (N / covered columns) the 128-row /
+    // 64-row tile kernels win: one round here takes 70 us at K = 400 however few tiles it has (tools/exp/sp_fill.py: M = 14k, N = 400 -- fill
+    // 0.34 -- 70 us here, 53 there; M = 21k -- 0.50 -- 71 vs 85; tanh, N = 200: M = 28k -- 0.33 -- 70 vs 68, M = 42k -- 0.50 -- 75 vs 107).
     // A device-side row count (m_dev) hides the real M: those launches (the compacted encoder layers) always come here.  A caller
     // that cuts its rows into EQUAL passes (Model.score_impressions) gets one kernel family -- one rounding -- for every pass.
     if (!a->m_dev && !(g_split_mode & 4)) {
         const long ncu = sp_num_cus();
         const long rounds = (ntiles + ncu - 1) / ncu;
         const double fill = (double)ntiles / (double)(rounds * ncu) * (double)a->N / (double)(((a->N + (wide ? 319 : 255)) / (wide ? 320 : 256)) * (wide ? 320 : 256));
-        if (fill < 0.55) return LIME_PP_NOT_APPLICABLE;
+        if (fill < 0.45) return LIME_PP_NOT_APPLICABLE;
     }
 
     PPParams p;
