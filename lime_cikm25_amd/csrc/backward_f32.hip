@@ -13,6 +13,7 @@
 #include "common.h"
 #include "dropout.h"
 #include "gemm_pp.h"
+#include "split_mfma.h"
 
 namespace {
 
@@ -979,12 +980,28 @@ __device__ __forceinline__ void stage_rows(float* dst, const float* src, long ld
     }
 }
 
+// dst: three bf16 images [128][SPLIT_PITCH] (split_mfma.h) of src rows row0 .. row0 + 127, columns col0 .. col0 + 31 (zero outside the
+// valid rows / columns): the operand of the split-product Q K^T / dO V^T of the blocked kernels
+__device__ __forceinline__ void stage_rows_split(unsigned short* dst, const float* src, long ld, long row0, int rows_valid, int col0,
+                                                 int cols_valid, int tid) {
+    for (int e = tid; e < LB * 16; e += 512) {
+        const int r = e >> 4, c = (e & 15) * 2;
+        const float* const p = src + (row0 + r) * ld + col0 + c;
+        const float a = (r < rows_valid && c < cols_valid) ? p[0] : 0.f, b = (r < rows_valid && c + 1 < cols_valid) ? p[1] : 0.f;
+        lime_dev::split_store2(dst, LB * lime_dev::SPLIT_PITCH, r, c, a, b);
+    }
+}
+
+// SPX: the scores on the bf16 matrix cores as split products (K staged as three bf16 images, the wave's Q rows split in registers:
+// six 16x16x32 MFMAs per 16 x 16 tile instead of eight 16x16x4 fp32 ones -- 96 cycles against 256)
+template <bool SPX>
 __global__ __launch_bounds__(512) void attn_stats_kernel(const float* __restrict__ q, const float* __restrict__ k, long ld,
                                                           const float* __restrict__ out, long ldout, const float* __restrict__ dout,
                                                           long ldo, float* __restrict__ stats, int S, int n_head, int head_dim,
                                                           int head_stride, float scale, int n_blk) {
     __shared__ float Qs[LB * AB_LD];
-    __shared__ float Ks[LB * AB_LD];
+    __shared__ __attribute__((aligned(16))) float Ks[SPX ? (3 * LB * lime_dev::SPLIT_PITCH) / 2 : LB * AB_LD];
+    unsigned short* const Kt = reinterpret_cast<unsigned short*>(Ks);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, kg = lane >> 4;
     const int qb = blockIdx.x % n_blk;
     const long prob = blockIdx.x / n_blk;
@@ -997,23 +1014,33 @@ __global__ __launch_bounds__(512) void attn_stats_kernel(const float* __restrict
     f32x4v qa[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) qa[h] = *reinterpret_cast<const f32x4v*>(&Qs[(R0 + fi) * AB_LD + 8 * kg + 4 * h]);
+    lime_dev::SplitFrag qs;
+    if constexpr (SPX) {
+        const float x[8] = {qa[0][0], qa[0][1], qa[0][2], qa[0][3], qa[1][0], qa[1][1], qa[1][2], qa[1][3]};
+        qs = lime_dev::split_frag(x);
+    }
     float m[4], l[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
     for (int kb = 0; kb < n_blk; ++kb) {
         const int k0 = kb * LB, k_valid = min(LB, S - k0);
         __syncthreads();
-        stage_rows(Ks, k, ld, row_base + k0, k_valid, head * head_stride, head_dim, tid);
+        if constexpr (SPX) stage_rows_split(Kt, k, ld, row_base + k0, k_valid, head * head_stride, head_dim, tid);
+        else stage_rows(Ks, k, ld, row_base + k0, k_valid, head * head_stride, head_dim, tid);
         __syncthreads();
         f32x4 sc[LB / 16];
 #pragma unroll
         for (int ct = 0; ct < LB / 16; ++ct) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            f32x4v kf[2];
+            if constexpr (SPX) {
+                a = lime_dev::split_mfma16(qs, lime_dev::split_load(Kt, LB * lime_dev::SPLIT_PITCH, 16 * ct + fi, kg), a);
+            } else {
+                f32x4v kf[2];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) kf[h] = *reinterpret_cast<const f32x4v*>(&Ks[(16 * ct + fi) * AB_LD + 8 * kg + 4 * h]);
+                for (int h = 0; h < 2; ++h) kf[h] = *reinterpret_cast<const f32x4v*>(&Ks[(16 * ct + fi) * AB_LD + 8 * kg + 4 * h]);
 #pragma unroll
-            for (int t = 0; t < 8; ++t) a = mfma16(qa[t >> 2][t & 3], kf[t >> 2][t & 3], a);
+                for (int t = 0; t < 8; ++t) a = mfma16(qa[t >> 2][t & 3], kf[t >> 2][t & 3], a);
+            }
             sc[ct] = a;
         }
 #pragma unroll
@@ -1239,6 +1266,160 @@ __global__ __launch_bounds__(512) void attn_bwd_long_kernel(const float* __restr
                                    : dq_slabs + ((long)(kb - 1) * n_tok + row_base + q0 + row) * ((long)n_head * 32) + (long)head * 32;
                 if (fi < head_stride) d[fi] = aq0[r];
                 if (16 + fi < head_stride) d[16 + fi] = aq1[r];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = R0 + 4 * kg + r;
+        if (row < k_valid) {
+            const long o = (row_base + k0 + row) * ldd + (long)head * head_stride;
+            if (fi < head_stride) { dv[o + fi] = av0[r]; dk[o + fi] = ak0[r]; }
+            if (16 + fi < head_stride) { dv[o + 16 + fi] = av1[r]; dk[o + 16 + fi] = ak1[r]; }
+        }
+    }
+}
+
+// The blocked backward with Q K^T and dO V^T as split products on the bf16 matrix cores (lime_set_split_gemm(1), the default): the
+// key block's K and V are staged once as three bf16 images each (split_mfma.h), the wave's Q / dO rows are split in registers, a
+// 16 x 16 tile of S or dP costs six 16x16x32 MFMAs (96 cycles) instead of eight fp32 ones (256); dV, dK and dQ -- whose P / dS
+// operand would have to be split per use -- stay on the fp32 MFMA.  The images take 60 KB, so the query side goes in blocks of 64
+// rows (P / dS image 33 KB): phase 1 wave w = query tile w & 3 x key half w >> 2; dV / dK wave w = keys 16 w .. 16 w + 15 as in
+// attn_bwd_long_kernel; dQ wave w = query tile w & 3 x head-dim half w >> 2.  Same slabs, same reduction order over key blocks.
+constexpr int LQ = 64;
+__global__ __launch_bounds__(512) void attn_bwd_long_sp_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                const float* __restrict__ v, long ld, const float* __restrict__ dout,
+                                                                long ldo, const float* __restrict__ stats, float* __restrict__ dq,
+                                                                float* __restrict__ dk, float* __restrict__ dv, long ldd, int S,
+                                                                int n_head, int head_dim, int head_stride, float scale, int n_blk,
+                                                                LimeDropout drop, float* __restrict__ dq_slabs, long n_tok) {
+    using namespace lime_dev;
+    constexpr int LDP = LB + 2, TS = LB * SPLIT_PITCH;
+    extern __shared__ float smem[];
+    unsigned short* const Kt = reinterpret_cast<unsigned short*>(smem);       // three bf16 images of the K block
+    unsigned short* const Vt = Kt + 3 * TS;
+    float* const Ks = smem + 3 * TS;             // (2 x 3 TS bf16 = 3 TS floats) the K block in fp32: the B operand of dQ
+    float* const Qs = Ks + LB * AB_LD;           // [LQ][AB_LD]
+    float* const Os = Qs + LQ * AB_LD;
+    float* const Ps = Os + LQ * AB_LD;           // [LQ][LDP]: P, then dS
+    float* const Ls = Ps + LQ * LDP;
+    float* const Ds = Ls + LQ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, kg = lane >> 4;
+    const int kb = blockIdx.x % n_blk;
+    const long prob = blockIdx.x / n_blk;
+    const int seq = (int)(prob / n_head), head = (int)(prob % n_head);
+    const long row_base = (long)seq * S;
+    const int k0 = kb * LB, k_valid = min(LB, S - k0);
+    const int R0 = 16 * wave, qi = wave & 3, hh = wave >> 2;
+    stage_rows(Ks, k, ld, row_base + k0, k_valid, head * head_stride, head_dim, tid);
+    stage_rows_split(Kt, k, ld, row_base + k0, k_valid, head * head_stride, head_dim, tid);
+    stage_rows_split(Vt, v, ld, row_base + k0, k_valid, head * head_stride, head_dim, tid);
+    f32x4 av0 = {0.f, 0.f, 0.f, 0.f}, av1 = av0, ak0 = av0, ak1 = av0;
+    const int n_qblk = (S + LQ - 1) / LQ;
+    // the NEXT query block's Q / dO rows (4 + 4 floats per thread) and statistics wait in registers while the current block is
+    // computed: one workgroup per CU (132 KB of LDS), so nothing else would cover the global latency of the staging
+    float pq[4], po[4], pl = INFINITY, pd = 0.f;
+    auto fetch_q = [&](int qb) {
+        const int q0 = qb * LQ, q_valid = min(LQ, S - q0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 512 * u, r = e >> 5, c = e & 31;
+            const bool ok = r < q_valid && c < head_dim;
+            pq[u] = ok ? q[(row_base + q0 + r) * ld + head * head_stride + c] : 0.f;
+            po[u] = ok ? dout[(row_base + q0 + r) * ldo + head * head_dim + c] : 0.f;
+        }
+        if (tid < LQ) {
+            const bool ok = tid < q_valid;
+            const float* st = stats + ((row_base + q0 + (ok ? tid : 0)) * n_head + head) * 2;
+            pl = ok ? st[0] : INFINITY;         // exp(x - inf) = 0: rows beyond S contribute nothing
+            pd = ok ? st[1] : 0.f;
+        }
+    };
+    fetch_q(0);
+    for (int qb = 0; qb < n_qblk; ++qb) {
+        const int q0 = qb * LQ, q_valid = min(LQ, S - q0);
+        __syncthreads();                        // the previous block's images are no longer read
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 512 * u, r = e >> 5, c = e & 31;
+            Qs[r * AB_LD + c] = pq[u];
+            Os[r * AB_LD + c] = po[u];
+        }
+        if (tid < LQ) { Ls[tid] = pl; Ds[tid] = pd; }
+        __syncthreads();
+        if (qb + 1 < n_qblk) fetch_q(qb + 1);
+        // ---- phase 1: S and dP of query tile qi x key tiles 4 hh .. 4 hh + 3 ----------------------------------------------
+        f32x4 p[4], dp[4];
+        {
+            float xq[8], xo[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                xq[j] = Qs[(16 * qi + fi) * AB_LD + 8 * kg + j];
+                xo[j] = Os[(16 * qi + fi) * AB_LD + 8 * kg + j];
+            }
+            const SplitFrag qs = split_frag(xq), os = split_frag(xo);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ct = 4 * hh + c;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                p[c] = split_mfma16(qs, split_load(Kt, TS, 16 * ct + fi, kg), z);
+                dp[c] = split_mfma16(os, split_load(Vt, TS, 16 * ct + fi, kg), z);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * qi + 4 * kg + r;
+            const float lse = Ls[row], dl = Ds[row];
+            const uint64_t mrow = ((uint64_t)prob * S + (uint64_t)(q0 + row)) * (uint64_t)S + (uint64_t)k0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int col = 16 * (4 * hh + c) + fi;
+                const float pv = (col < k_valid) ? __builtin_amdgcn_exp2f(p[c][r] * (scale * LOG2E) - lse) : 0.f;
+                const float f = (drop.thresh == 0 || lime_keep(drop, mrow + (uint64_t)col)) ? drop.scale : 0.f;
+                p[c][r] = pv * f;                                    // what the dV product needs
+                dp[c][r] = scale * pv * (dp[c][r] * f - dl);         // dS
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ps[(16 * qi + 4 * kg + r) * LDP + 16 * (4 * hh + c) + fi] = p[c][r];
+        __syncthreads();
+        // ---- phase 2: dV[j, d] += sum_i P[i, j] dO[i, d], keys R0 .. R0 + 15 ------------------------------------------------
+#pragma unroll 8
+        for (int t = 0; t < LQ / 4; ++t) {
+            const int i = 4 * t + kg;
+            const float a = Ps[i * LDP + R0 + fi];
+            av0 = mfma16(a, Os[i * AB_LD + fi], av0);
+            av1 = mfma16(a, Os[i * AB_LD + 16 + fi], av1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ps[(16 * qi + 4 * kg + r) * LDP + 16 * (4 * hh + c) + fi] = dp[c][r];
+        __syncthreads();
+        // ---- phase 3: dK (keys R0 ..) and this key block's share of dQ (query tile qi, head dims 16 hh .. 16 hh + 15) -----------
+#pragma unroll 8
+        for (int t = 0; t < LQ / 4; ++t) {
+            const int j = 4 * t + kg;
+            const float ds_col = Ps[j * LDP + R0 + fi];
+            ak0 = mfma16(ds_col, Qs[j * AB_LD + fi], ak0);
+            ak1 = mfma16(ds_col, Qs[j * AB_LD + 16 + fi], ak1);
+        }
+        f32x4 aq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int t = 0; t < LB / 4; ++t) {
+            const int j = 4 * t + kg;
+            aq = mfma16(Ps[(16 * qi + fi) * LDP + j], Ks[j * AB_LD + 16 * hh + fi], aq);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * qi + 4 * kg + r;
+            if (row < q_valid && 16 * hh + fi < head_stride) {
+                float* d = kb == 0 ? dq + (row_base + q0 + row) * ldd + (long)head * head_stride
+                                   : dq_slabs + ((long)(kb - 1) * n_tok + row_base + q0 + row) * ((long)n_head * 32) + (long)head * 32;
+                d[16 * hh + fi] = aq[r];
             }
         }
     }
@@ -1735,10 +1916,31 @@ extern "C" int lime_token_attention_bwd_f32(const float* q, const float* k, cons
     hipError_t e = hipSuccess;
     float* const dq_slabs = workspace + lime_token_attention_stats_workspace(n_seq, S, n_head);
     const long n_tok = (long)n_seq * S;
-    attn_stats_kernel<<<(unsigned)(n_prob * n_blk), 512, 0, s>>>(q, k, ld_qkv, out, ld_out, dout, ldo, workspace, S, n_head, head_dim,
-                                                              head_stride, scale, n_blk);
+    const bool spx = (lime_split_mode() & 1) != 0;             // Q K^T / dO V^T as split products on the bf16 matrix cores
+    if (spx) attn_stats_kernel<true><<<(unsigned)(n_prob * n_blk), 512, 0, s>>>(q, k, ld_qkv, out, ld_out, dout, ldo, workspace, S, n_head,
+                                                                             head_dim, head_stride, scale, n_blk);
+    else attn_stats_kernel<false><<<(unsigned)(n_prob * n_blk), 512, 0, s>>>(q, k, ld_qkv, out, ld_out, dout, ldo, workspace, S, n_head,
+                                                                           head_dim, head_stride, scale, n_blk);
     int st = lime_check_launch("attn_stats_kernel");
     if (st != LIME_OK) return st;
+    if (spx) {
+        constexpr int BYTES_SP = (3 * LB * lime_dev::SPLIT_PITCH + LB * AB_LD + 2 * LQ * AB_LD + LQ * (LB + 2) + 2 * LQ) * 4;
+        static bool configured_sp = false;
+        if (!configured_sp) {
+            e = hipFuncSetAttribute((const void*)attn_bwd_long_sp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES_SP);
+            LIME_REQUIRE(e == hipSuccess, LIME_ERR_LAUNCH, "lime_token_attention_bwd_f32: cannot reserve %d bytes of LDS: %s", BYTES_SP,
+                         hipGetErrorString(e));
+            configured_sp = true;
+        }
+        attn_bwd_long_sp_kernel<<<(unsigned)(n_prob * n_blk), 512, BYTES_SP, s>>>(q, k, v, ld_qkv, dout, ldo, workspace, dq, dk, dv, ld_dqkv,
+                                                                                 S, n_head, head_dim, head_stride, scale, n_blk, drop, dq_slabs, n_tok);
+        st = lime_check_launch("attn_bwd_long_sp_kernel");
+        if (st != LIME_OK || n_blk == 1) return st;
+        const long total_sp = n_tok * n_head * head_stride;
+        attn_dq_reduce_kernel<<<(unsigned)((total_sp + 255) / 256 > 8192 ? 8192 : (total_sp + 255) / 256), 256, 0, s>>>(dq, ld_dqkv, dq_slabs, n_tok,
+                                                                                                                  n_head, head_stride, n_blk - 1);
+        return lime_check_launch("attn_dq_reduce_kernel");
+    }
     constexpr int BYTES = (4 * LB * AB_LD + LB * (LB + 2) + 2 * LB) * 4;
     static bool configured = false;
     if (!configured) {
@@ -1779,8 +1981,12 @@ extern "C" int lime_token_attention_dropout_f32(const float* q, const float* k, 
     const int n_blk = (S + LB - 1) / LB;
     const long n_prob = (long)n_seq * n_head;
     LIME_REQUIRE(n_prob * n_blk < 0x7FFFFFFFL, LIME_ERR_UNSUPPORTED, "lime_token_attention_dropout_f32: too many blocks");
-    attn_stats_kernel<<<(unsigned)(n_prob * n_blk), 512, 0, s>>>(q, k, ld_qkv, nullptr, 0, nullptr, 0, workspace, S, n_head, head_dim,
-                                                              head_stride, scale, n_blk);
+    if (lime_split_mode() & 1)
+        attn_stats_kernel<true><<<(unsigned)(n_prob * n_blk), 512, 0, s>>>(q, k, ld_qkv, nullptr, 0, nullptr, 0, workspace, S, n_head, head_dim,
+                                                                        head_stride, scale, n_blk);
+    else
+        attn_stats_kernel<false><<<(unsigned)(n_prob * n_blk), 512, 0, s>>>(q, k, ld_qkv, nullptr, 0, nullptr, 0, workspace, S, n_head, head_dim,
+                                                                         head_stride, scale, n_blk);
     int st = lime_check_launch("attn_stats_kernel");
     if (st != LIME_OK) return st;
     constexpr int BYTES = (3 * LB * AB_LD + LB * (LB + 2)) * 4;
