@@ -569,6 +569,17 @@ int lime_token_attention_bwd_f32(const float* q, const float* k, const float* v,
                                  int64_t workspace_floats, float dropout_p, uint64_t seed, uint32_t site, const uint8_t* key_mask,
                                  void* stream);
 
+/* The pair for a training step whose forward keeps its softmax statistics (S > 128 pays a Q K^T pass of its own for them otherwise):
+ * lime_token_attention_lse_f32 is lime_token_attention_f32 without a key mask that also writes lse [tokens, n_head] -- per (token, head)
+ * the log2-domain log-sum-exp of the scaled scores, max + log2(sum 2^(s - max)) with s = scale * log2(e) * q . k --;
+ * lime_token_attention_bwd_lse_f32 is lime_token_attention_bwd_f32 (no dropout, no key mask) reading it. */
+int lime_token_attention_lse_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, float* out, int64_t ldo, float* lse,
+                                 int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim, int32_t head_stride, float scale, void* stream);
+int lime_token_attention_bwd_lse_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out, int64_t ld_out,
+                                     const float* lse, const float* dout, int64_t ldo, float* dq, float* dk, float* dv, int64_t ld_dqkv,
+                                     int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim, int32_t head_stride, float scale,
+                                     float* workspace, int64_t workspace_floats, void* stream);
+
 /* ---- dropout inside the token encoders in training mode --------------------------------------------------------------
  * Masks are a pure function of (seed, site, element index) (csrc/dropout.h): element e of site `site` is kept iff
  * hash(seed, site, e) >= p * 2^32, kept values are scaled by 1 / (1 - p); the backward regenerates the mask from the same

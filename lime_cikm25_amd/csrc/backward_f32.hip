@@ -1434,6 +1434,34 @@ __global__ __launch_bounds__(512) void attn_bwd_long_sp_kernel(const float* __re
     }
 }
 
+// stats[(token, head)] = (lse from the forward, delta = dO . O): the statistics pass without its Q K^T products, for a forward that
+// kept its log-sum-exp (lime_token_attention_lse_f32)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ out, long ldout, const float* __restrict__ dout, long ldo,
+                                                          const float* __restrict__ lse, float* __restrict__ stats, long n_tok, int n_head,
+                                                          int head_dim) {
+    // one wave per token: coalesced row reads, the products parked in LDS, lane h sums head h's in column order (fixed order:
+    // reproducible bits); n_head * head_dim <= 1024, n_head <= 64
+    __shared__ float prod[4][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int width = n_head * head_dim;
+    for (long row = (long)blockIdx.x * 4 + wave; row < n_tok; row += (long)gridDim.x * 4) {
+        const float* po = out + row * ldout;
+        const float* pd = dout + row * ldo;
+        for (int c = lane; c < width; c += 64) prod[wave][c] = po[c] * pd[c];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < n_head) {
+            float d = 0.f;
+            for (int c = 0; c < head_dim; ++c) d += prod[wave][lane * head_dim + c];
+            const long e = row * n_head + lane;
+            stats[e * 2] = lse[e];
+            stats[e * 2 + 1] = d;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // dq[row, head * hs + j] += sum over slabs 0 .. n_slab - 1 (key blocks 1 ..) of slab[row][head * 32 + j], in slab order
 __global__ __launch_bounds__(256) void attn_dq_reduce_kernel(float* __restrict__ dq, long ldd, const float* __restrict__ slabs, long n_tok,
                                                               int n_head, int hs, int n_slab) {
@@ -1885,11 +1913,11 @@ extern "C" int64_t lime_token_attention_bwd_workspace(int32_t n_seq, int32_t S, 
     return lime_token_attention_stats_workspace(n_seq, S, n_head) + (n_blk - 1) * (int64_t)n_seq * S * n_head * 32;
 }
 
-extern "C" int lime_token_attention_bwd_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out,
-                                            int64_t ld_out, const float* dout, int64_t ldo, float* dq, float* dk, float* dv,
-                                            int64_t ld_dqkv, int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim,
-                                            int32_t head_stride, float scale, float* workspace, int64_t workspace_floats,
-                                            float dropout_p, uint64_t seed, uint32_t site, const uint8_t* key_mask, void* stream) {
+static int attention_bwd(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out,
+                         int64_t ld_out, const float* dout, int64_t ldo, float* dq, float* dk, float* dv,
+                         int64_t ld_dqkv, int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim,
+                         int32_t head_stride, float scale, float* workspace, int64_t workspace_floats,
+                         float dropout_p, uint64_t seed, uint32_t site, const uint8_t* key_mask, const float* lse, void* stream) {
     LIME_REQUIRE(q && k && v && dout && dq && dk && dv, LIME_ERR_BAD_ARG, "lime_token_attention_bwd_f32: null pointer");
     LIME_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, LIME_ERR_BAD_ARG, "lime_token_attention_bwd_f32: dropout_p outside [0, 1)");
     const LimeDropout drop = lime_make_dropout(dropout_p, seed, site);
@@ -1917,7 +1945,11 @@ extern "C" int lime_token_attention_bwd_f32(const float* q, const float* k, cons
     float* const dq_slabs = workspace + lime_token_attention_stats_workspace(n_seq, S, n_head);
     const long n_tok = (long)n_seq * S;
     const bool spx = (lime_split_mode() & 1) != 0;             // Q K^T / dO V^T as split products on the bf16 matrix cores
-    if (spx) attn_stats_kernel<true><<<(unsigned)(n_prob * n_blk), 512, 0, s>>>(q, k, ld_qkv, out, ld_out, dout, ldo, workspace, S, n_head,
+    if (lse) {                                                 // the forward kept its log-sum-exp: only delta = dO . O is left
+        LIME_REQUIRE(n_head <= 64 && n_head * head_dim <= 1024, LIME_ERR_UNSUPPORTED, "lime_token_attention_bwd_lse_f32: n_head > 64 or n_head * head_dim > 1024");
+        attn_delta_kernel<<<(unsigned)((n_tok + 3) / 4 > 8192 ? 8192 : (n_tok + 3) / 4), 256, 0, s>>>(out, ld_out, dout, ldo, lse, workspace, n_tok,
+                                                                                                    n_head, head_dim);
+    } else if (spx) attn_stats_kernel<true><<<(unsigned)(n_prob * n_blk), 512, 0, s>>>(q, k, ld_qkv, out, ld_out, dout, ldo, workspace, S, n_head,
                                                                              head_dim, head_stride, scale, n_blk);
     else attn_stats_kernel<false><<<(unsigned)(n_prob * n_blk), 512, 0, s>>>(q, k, ld_qkv, out, ld_out, dout, ldo, workspace, S, n_head,
                                                                            head_dim, head_stride, scale, n_blk);
@@ -1957,6 +1989,24 @@ extern "C" int lime_token_attention_bwd_f32(const float* q, const float* k, cons
     attn_dq_reduce_kernel<<<(unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256), 256, 0, s>>>(dq, ld_dqkv, dq_slabs, n_tok, n_head,
                                                                                                           head_stride, n_blk - 1);
     return lime_check_launch("attn_dq_reduce_kernel");
+}
+
+extern "C" int lime_token_attention_bwd_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out,
+                                            int64_t ld_out, const float* dout, int64_t ldo, float* dq, float* dk, float* dv,
+                                            int64_t ld_dqkv, int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim,
+                                            int32_t head_stride, float scale, float* workspace, int64_t workspace_floats,
+                                            float dropout_p, uint64_t seed, uint32_t site, const uint8_t* key_mask, void* stream) {
+    return attention_bwd(q, k, v, ld_qkv, out, ld_out, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale,
+                         workspace, workspace_floats, dropout_p, seed, site, key_mask, nullptr, stream);
+}
+
+extern "C" int lime_token_attention_bwd_lse_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, const float* out,
+                                                int64_t ld_out, const float* lse, const float* dout, int64_t ldo, float* dq, float* dk,
+                                                float* dv, int64_t ld_dqkv, int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim,
+                                                int32_t head_stride, float scale, float* workspace, int64_t workspace_floats, void* stream) {
+    LIME_REQUIRE(lse != nullptr, LIME_ERR_BAD_ARG, "lime_token_attention_bwd_lse_f32: lse is NULL");
+    return attention_bwd(q, k, v, ld_qkv, out, ld_out, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale,
+                         workspace, workspace_floats, 0.f, 0, 0, nullptr, lse, stream);
 }
 
 extern "C" int lime_token_attention_dropout_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, float* out, int64_t ldo,

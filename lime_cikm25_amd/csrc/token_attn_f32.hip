@@ -55,6 +55,8 @@ struct AttnP {
     int out_pad;         // BF: zero columns written behind the last head (the next GEMM reads K rounded up to 8)
     const int* row_map;  // MAP: q / k / v row of token (seq * S + t) is row_map[seq * S + t] (padding tokens share S table rows)
     const int* n_seq_dev;  // optional device-side sequence count (min(*n_seq_dev, n_seq) sequences are computed)
+    float* lse;          // optional [tokens, n_head]: log2-domain log-sum-exp of every query's scaled scores (what the blocked backward
+                         // otherwise recomputes with a Q K^T pass of its own)
 #ifdef LIME_STAMPS
     unsigned long long* stamps;
 #endif
@@ -375,6 +377,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
                     }
                     sum += __shfl_xor(sum, 32);
                     inv = 1.0f / sum;
+                    if (p.lse && fh == 0 && qt * 32 + fi < S) p.lse[((long)seq * S + qt * 32 + fi) * p.n_head + head] = m + log2f(sum);
                     ASTAMP(5)
                 } else {
                 // ---- S^T = K Q^T: keys on rows, this lane's query on the column (rows beyond S are zeros in LDS) ------
@@ -423,6 +426,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 3 : (NT <= 4 ? 2 : 1)) void token_
                 }
                 sum += __shfl_xor(sum, 32);
                 inv = 1.0f / sum;
+                if (p.lse && fh == 0 && qt * 32 + fi < S) p.lse[((long)seq * S + qt * 32 + fi) * p.n_head + head] = m + log2f(sum);
                 ASTAMP(4)
                 // ---- O^T = V^T P^T: probability registers are the B operand as they stand --------------------------
 #pragma unroll
@@ -594,6 +598,30 @@ extern "C" int lime_token_attention_count_f32(const float* q, const float* k, co
     return launch<16>(p, s);
 }
 
+
+extern "C" int lime_token_attention_lse_f32(const float* q, const float* k, const float* v, int64_t ld_qkv, float* out, int64_t ldo,
+                                            float* lse, int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim, int32_t head_stride,
+                                            float scale, void* stream) {
+    LIME_REQUIRE(q && k && v && out && lse, LIME_ERR_BAD_ARG, "lime_token_attention_lse_f32: NULL pointer");
+    LIME_REQUIRE(n_seq >= 0 && S > 0 && n_head > 0 && head_dim > 0, LIME_ERR_BAD_ARG,
+                 "lime_token_attention_lse_f32: bad dims n_seq=%d S=%d n_head=%d head_dim=%d", n_seq, S, n_head, head_dim);
+    LIME_REQUIRE(head_dim <= 32 && head_stride >= head_dim && S <= 512, LIME_ERR_UNSUPPORTED,
+                 "lime_token_attention_lse_f32: needs head_dim <= 32, head_stride >= head_dim, S <= 512");
+    LIME_REQUIRE(ld_qkv >= (int64_t)n_head * head_stride && ldo >= (int64_t)n_head * head_dim, LIME_ERR_BAD_ARG,
+                 "lime_token_attention_lse_f32: leading dimension smaller than n_head * head_dim");
+    if (n_seq == 0) return LIME_OK;
+    const int vec2 = (head_dim % 2 == 0) && (head_stride % 2 == 0) && (ld_qkv % 2 == 0) &&
+                     (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 8 == 0);
+    AttnP p{q, k, v, (long)ld_qkv, nullptr, out, (long)ldo, n_seq, S, n_head, head_dim, head_stride, scale, n_seq * n_head, vec2, 0, 0, nullptr, nullptr, lse};
+    hipStream_t s = (hipStream_t)stream;
+    const int nt = (S + 31) / 32;
+    if (nt <= 1) return launch<1>(p, s);
+    if (nt <= 2) return launch<2>(p, s);
+    if (nt <= 3) return launch<3>(p, s);
+    if (nt <= 4) return launch<4>(p, s);
+    if (nt <= 8) return launch<8>(p, s);
+    return launch<16>(p, s);
+}
 
 extern "C" int lime_token_attention_f32(const float* q, const float* k, const float* v, int64_t ld_qkv,
                                         const uint8_t* key_mask, float* out, int64_t ldo, int32_t n_seq, int32_t S,

@@ -206,9 +206,10 @@ def embed_pe(ids, table, pe=None, period=0, out=None):
     return out
 
 
-def token_attention(q, k, v, n_seq, S, n_head, head_dim, scale, key_mask=None, out=None, head_stride=None, n_seq_dev=None):
+def token_attention(q, k, v, n_seq, S, n_head, head_dim, scale, key_mask=None, out=None, head_stride=None, n_seq_dev=None, lse=None):
     """softmax(Q K^T * scale [+mask]) V per (sequence, head); q/k/v: [n_seq*S, n_head*head_stride] views of one pitch
-    (head_stride defaults to head_dim, the packed layout); out: [n_seq*S, n_head*head_dim]."""
+    (head_stride defaults to head_dim, the packed layout); out: [n_seq*S, n_head*head_dim].  ``lse`` (float32 [n_seq*S * n_head], no
+    mask): also filled with the softmax statistics ``token_attention_bwd(..., lse=lse)`` reads instead of recomputing them."""
     lib = _lib.load()
     hs = head_dim if head_stride is None else head_stride
     for t, n in ((q, 'q'), (k, 'k'), (v, 'v')):
@@ -223,6 +224,13 @@ def token_attention(q, k, v, n_seq, S, n_head, head_dim, scale, key_mask=None, o
     m = _mask_u8(key_mask, 'key_mask')
     if m is not None and m.numel() != n_seq * S:
         raise ValueError('key_mask must have n_seq * S elements')
+    if lse is not None:
+        if m is not None or n_seq_dev is not None:
+            raise ValueError('lse goes with the unmasked, host-counted call')
+        _vec(lse, 'lse', n_seq * S * n_head)
+        check(lib.lime_token_attention_lse_f32(_p(q), _p(k), _p(v), _ld(q), _p(out), _ld(out), _p(lse), n_seq, S, n_head, head_dim, hs,
+                                               scale, _stream()), 'lime_token_attention_lse_f32')
+        return out
     if n_seq_dev is not None:                      # a compacted batch: the sequence count lives on the device
         _vec(n_seq_dev, 'n_seq_dev', 1, dtype=torch.int32)
         check(lib.lime_token_attention_count_f32(_p(q), _p(k), _p(v), _ld(q), _p(m), _p(n_seq_dev), _p(out), _ld(out), n_seq, S, n_head,
@@ -1054,7 +1062,7 @@ def relu_bwd_(dh, h, scale=1.0):
 
 
 def token_attention_bwd(q, k, v, dout, n_seq, S, n_head, head_dim, scale, head_stride=None, dqkv=None, out=None,
-                        dropout=None, key_mask=None):
+                        dropout=None, key_mask=None, lse=None):
     """Backward of the unmasked ``token_attention``: q / k / v column views of one packed qkv buffer [tokens, 3 * n_head *
     head_stride]; returns dqkv in the same layout.  ``out``: the forward's result (needed for S > 128).  ``dropout``:
     (p, seed, site) of the ``token_attention_dropout`` forward."""
@@ -1082,6 +1090,14 @@ def token_attention_bwd(q, k, v, dout, n_seq, S, n_head, head_dim, scale, head_s
         if tuple(out.shape) != tuple(dout.shape):
             raise ValueError('out must have the shape of dout')
         ws = _workspace(q.device, need)
+    if lse is not None and need:                   # S > 128 with the forward's statistics: no Q K^T pass for them
+        if dropout or key_mask is not None:
+            raise ValueError('lse goes with the plain (no dropout, no key mask) forward')
+        _vec(lse, 'lse', n_seq * S * n_head)
+        check(lib.lime_token_attention_bwd_lse_f32(_p(q), _p(k), _p(v), _ld(q), _p(out), _ld(out), _p(lse), _p(dout), _ld(dout), _p(dq),
+                                                   _p(dk), _p(dv), _ld(dqkv), n_seq, S, n_head, head_dim, hs, scale, _p(ws), ws.numel(),
+                                                   _stream()), 'lime_token_attention_bwd_lse_f32')
+        return dqkv
     check(lib.lime_token_attention_bwd_f32(_p(q), _p(k), _p(v), _ld(q), _p(out), _ld(out) if out is not None else 0, _p(dout),
                                            _ld(dout), _p(dq), _p(dk), _p(dv), _ld(dqkv), n_seq, S, n_head, head_dim, hs, scale,
                                            _p(ws), ws.numel() if ws is not None else 0, *(dropout or (0.0, 0, 0)),

@@ -275,7 +275,9 @@ class _TokenEncoder(torch.autograd.Function):
         else:
             pew = ops.linear(pe[:S], w_in, b_in)
             qkv = ops.linear(table, w_in, None, a_ids=flat, res=pew, res_mod=S, n_alg=3 * E)
-            ao = ops.token_attention(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, scale, head_stride=hs)
+            # S > 128: the forward keeps its softmax statistics, the blocked backward does not recompute them
+            lse = torch.empty(tok * nhead, dtype=torch.float32, device=dev) if S > 128 else None
+            ao = ops.token_attention(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, scale, head_stride=hs, lse=lse)
             rstd1 = torch.empty(tok, dtype=torch.float32, device=dev)
             x1 = ops.linear(ao, out_w, out_b, res=table, res_ids=flat, res_pe=pe, res_period=S, ln=(n1_w, n1_b), ln_eps=eps1,
                             ln_rstd=rstd1)
@@ -284,6 +286,7 @@ class _TokenEncoder(torch.autograd.Function):
             y = ops.linear(h, l2_w, l2_b, res=x1, ln=(n2_w, n2_b), ln_eps=eps2, ln_rstd=rstd2)
         pooled = ops.mean_pool(y, M, S)
         ctx.dims = (M, S, E, nhead, hd, hs, p, seed)
+        ctx.lse = lse if p == 0 else None
         ctx.save_for_backward(flat, table, pe, w_in, out_w, l1_w, l2_w, n1_w, n1_b, n2_w, n2_b, qkv, ao, x1, rstd1, h, y, rstd2, x0)
         return pooled
 
@@ -318,7 +321,7 @@ class _TokenEncoder(torch.autograd.Function):
             dout_w = ops.linear_wgrad(dt1, ao)
         dao = ops.linear(dt1, out_w.t().contiguous(), None)
         dqkv = ops.token_attention_bwd(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], dao, M, S, nhead, hd, 1.0 / math.sqrt(hd),
-                                       head_stride=hs, out=ao, dropout=(p, seed, _SITE_ATTN) if drop else None)
+                                       head_stride=hs, out=ao, dropout=(p, seed, _SITE_ATTN) if drop else None, lse=ctx.lse)
         del dao, qkv, ao, dt1
         if x0 is None:
             x0 = ops.embed_pe(flat, table, pe, S)                                  # the layer input, re-gathered
@@ -395,13 +398,15 @@ class _EncoderLayer(torch.autograd.Function):
             ops.dropout(h, p, seed, _SITE_FF, out=h)
             y, rstd2 = ops.dropout_add_layernorm(ops.linear(h, l2_w, l2_b), x1, n2_w, n2_b, eps2, p, seed, _SITE_DROP2)
         else:
-            ao = ops.token_attention(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, scale, head_stride=hs)
+            lse = torch.empty(tok * nhead, dtype=torch.float32, device=dev) if S > 128 else None
+            ao = ops.token_attention(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, scale, head_stride=hs, lse=lse)
             rstd1 = torch.empty(tok, dtype=torch.float32, device=dev)
             x1 = ops.linear(ao, out_w, out_b, res=x, ln=(n1_w, n1_b), ln_eps=eps1, ln_rstd=rstd1)
             h = ops.linear(x1, l1_w, l1_b, act='relu')
             rstd2 = torch.empty(tok, dtype=torch.float32, device=dev)
             y = ops.linear(h, l2_w, l2_b, res=x1, ln=(n2_w, n2_b), ln_eps=eps2, ln_rstd=rstd2)
         ctx.dims = (M, S, E, nhead, hd, hs, p, seed)
+        ctx.lse = lse if p == 0 else None
         ctx.save_for_backward(x, w_in, out_w, l1_w, l2_w, n1_w, n1_b, n2_w, n2_b, qkv, ao, x1, rstd1, h, y, rstd2)
         return y
 
@@ -432,7 +437,7 @@ class _EncoderLayer(torch.autograd.Function):
             dout_w = ops.linear_wgrad(dt1, ao)
         dao = ops.linear(dt1, out_w.t().contiguous(), None)
         dqkv = ops.token_attention_bwd(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], dao, M, S, nhead, hd, 1.0 / math.sqrt(hd),
-                                       head_stride=hs, out=ao, dropout=(p, seed, _SITE_ATTN) if drop else None)
+                                       head_stride=hs, out=ao, dropout=(p, seed, _SITE_ATTN) if drop else None, lse=ctx.lse)
         del dao, dt1
         din_w, din_b = ops.linear_wgrad(dqkv, x, want_bias=True)
         din_w, din_b = _unpad_heads(din_w, 3 * nhead, hd, hs), _unpad_heads(din_b, 3 * nhead, hd, hs)

@@ -158,6 +158,15 @@ def _attention_bwd_case(ops, n_seq, S, nh, hd, hs):
     dqkv = ops.token_attention_bwd(g[:, :W], g[:, W:2 * W], g[:, 2 * W:], dout.cuda(), n_seq, S, nh, hd, scale, head_stride=hs,
                                    out=out)
     close(dqkv, want.view(tok, 3 * W), tol=2e-4, what='dqkv')
+    # the pair that hands the softmax statistics from the forward to the backward (what the training path uses for S > 128)
+    lse = torch.empty(tok * nh, device='cuda')
+    out2 = ops.token_attention(g[:, :W], g[:, W:2 * W], g[:, 2 * W:], n_seq, S, nh, hd, scale, head_stride=hs, lse=lse)
+    close(out2, o.detach().float(), what='attention forward (lse variant)')
+    want_lse = torch.logsumexp((q @ k.transpose(-1, -2) * scale).detach(), dim=-1) / math.log(2.0)           # [n_seq, nh, S], log2 domain
+    close(lse.view(n_seq, S, nh).permute(0, 2, 1), want_lse.float(), tol=1e-5, what='lse')
+    dqkv2 = ops.token_attention_bwd(g[:, :W], g[:, W:2 * W], g[:, 2 * W:], dout.cuda(), n_seq, S, nh, hd, scale, head_stride=hs,
+                                    out=out2, lse=lse)
+    close(dqkv2, want.view(tok, 3 * W), tol=2e-4, what='dqkv from the forward statistics')
     if hs > hd:
         assert (dqkv.view(tok, 3, nh, hs)[..., hd:] == 0).all(), 'pad columns must be exact zeros'
 
