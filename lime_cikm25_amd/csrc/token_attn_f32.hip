@@ -554,7 +554,7 @@ extern "C" int lime_token_attention_rows_f32(const float* q, const float* k, con
     if (n_seq == 0) return LIME_OK;
     hipStream_t s = (hipStream_t)stream;
     {   // S <= 128: the split-product kernel (token_attn_sp_f32.hip) unless lime_set_split_gemm(0)
-        const int st = lime_token_attention_sp(q, k, v, (long)ld_qkv, row_map, n_seq_dev, out, (long)ldo, n_seq, S, n_head, head_dim, scale, s);
+        const int st = lime_token_attention_sp(q, k, v, (long)ld_qkv, row_map, n_seq_dev, out, (long)ldo, n_seq, S, n_head, head_dim, scale, nullptr, s);
         if (st != LIME_PP_NOT_APPLICABLE) return st;
     }
     AttnP p{q, k, v, (long)ld_qkv, nullptr, out, (long)ldo, n_seq, S, n_head, head_dim, 32, scale, n_seq * n_head, 1, 0, 0, row_map, n_seq_dev};
@@ -585,7 +585,7 @@ extern "C" int lime_token_attention_count_f32(const float* q, const float* k, co
                      (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 8 == 0);
     hipStream_t s = (hipStream_t)stream;
     if (key_mask == nullptr && head_stride == 32) {   // the encoder layers' shapes: the split-product kernel (token_attn_sp_f32.hip)
-        const int st = lime_token_attention_sp(q, k, v, (long)ld_qkv, nullptr, n_seq_dev, out, (long)ldo, n_seq, S, n_head, head_dim, scale, s);
+        const int st = lime_token_attention_sp(q, k, v, (long)ld_qkv, nullptr, n_seq_dev, out, (long)ldo, n_seq, S, n_head, head_dim, scale, nullptr, s);
         if (st != LIME_PP_NOT_APPLICABLE) return st;
     }
     AttnP p{q, k, v, (long)ld_qkv, key_mask, out, (long)ldo, n_seq, S, n_head, head_dim, head_stride, scale, n_seq * n_head, vec2, 0, 0, nullptr, n_seq_dev};
@@ -612,8 +612,12 @@ extern "C" int lime_token_attention_lse_f32(const float* q, const float* k, cons
     if (n_seq == 0) return LIME_OK;
     const int vec2 = (head_dim % 2 == 0) && (head_stride % 2 == 0) && (ld_qkv % 2 == 0) &&
                      (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 8 == 0);
-    AttnP p{q, k, v, (long)ld_qkv, nullptr, out, (long)ldo, n_seq, S, n_head, head_dim, head_stride, scale, n_seq * n_head, vec2, 0, 0, nullptr, nullptr, lse};
     hipStream_t s = (hipStream_t)stream;
+    if (head_stride == 32) {                          // S = 256 / 512, padded heads: the split-product kernel with key blocks
+        const int st = lime_token_attention_sp(q, k, v, (long)ld_qkv, nullptr, nullptr, out, (long)ldo, n_seq, S, n_head, head_dim, scale, lse, s);
+        if (st != LIME_PP_NOT_APPLICABLE) return st;
+    }
+    AttnP p{q, k, v, (long)ld_qkv, nullptr, out, (long)ldo, n_seq, S, n_head, head_dim, head_stride, scale, n_seq * n_head, vec2, 0, 0, nullptr, nullptr, lse};
     const int nt = (S + 31) / 32;
     if (nt <= 1) return launch<1>(p, s);
     if (nt <= 2) return launch<2>(p, s);

@@ -265,6 +265,170 @@ __global__ __launch_bounds__(256, 2) void token_attn_sp_kernel(const SpAttnP p) 
     }
 }
 
+// Long sequences (S = 256 or 512: the 512-token bodies of BASELINE configs[3]): a task is one (sequence, head) pair x one block of
+// 128 queries (a wave per 32-query tile, its Q split once); the keys go through LDS in blocks of 128 -- K / V images as above, the
+// next block's rows prefetched into registers -- with a running maximum: o and the probability sum are rescaled by 2^(m_old - m_new)
+// when a block raises the maximum.  Optionally writes the log2-domain log-sum-exp of every query (p.lse: what the blocked backward
+// needs, lime_token_attention_lse_f32).
+template <bool MAP>
+__global__ __launch_bounds__(256, 2) void token_attn_sp_long_kernel(const SpAttnP p, float* __restrict__ lse) {
+    constexpr int SP = 128, VP = SP + 8;
+    constexpr int K_TERM = 128 * KP, V_TERM = 32 * VP;
+    __shared__ __attribute__((aligned(16))) unsigned short Ks[3 * K_TERM];
+    __shared__ __attribute__((aligned(16))) unsigned short Vs[3 * V_TERM];
+    __shared__ __attribute__((aligned(16))) float Scr[4 * 32 * LDO];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fi = lane & 31, fh = lane >> 5;
+    const int S = p.S, n_blk = S / 128;
+    int n_pair = p.n_pair;
+    if (p.n_seq_dev) {
+        int ns = __builtin_amdgcn_readfirstlane(*p.n_seq_dev);
+        ns = ns < p.n_seq ? (ns > 0 ? ns : 0) : p.n_seq;
+        n_pair = ns * p.n_head;
+    }
+    const int n_task = n_pair * n_blk;                  // task = pair * n_blk + query block
+    if (n_task == 0) return;
+    const int krow = 4 * fh;
+    const int c = (tid & 7) * 4, rg = tid >> 3, sr = 4 * rg;
+    f32x4 kreg[4], vreg[4];
+    auto fetch = [&](int task, int kb) {                // key block kb of the task's pair: rows 128 kb + sr .. + 3, columns c .. c + 3
+        const int pair = task / n_blk;
+        const int seq = pair / p.n_head, head = pair - seq * p.n_head;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long row = (long)seq * S + kb * 128 + sr + i;
+            if constexpr (MAP) row = p.row_map[row];
+            const long off = row * p.ld + head * 32 + c;
+            kreg[i] = *reinterpret_cast<const f32x4*>(p.k + off);
+            vreg[i] = *reinterpret_cast<const f32x4*>(p.v + off);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x2 h, m, l;
+            split4(kreg[i][0], kreg[i][1], kreg[i][2], kreg[i][3], h, m, l);
+            unsigned short* const d = &Ks[(sr + i) * KP + c];
+            *reinterpret_cast<u32x2*>(d) = h;
+            *reinterpret_cast<u32x2*>(d + K_TERM) = m;
+            *reinterpret_cast<u32x2*>(d + 2 * K_TERM) = l;
+        }
+        const int pos = (sr & ~12) | ((sr & 4) << 1) | ((sr & 8) >> 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32x2 h, m, l;
+            split4(vreg[0][j], vreg[1][j], vreg[2][j], vreg[3][j], h, m, l);
+            unsigned short* const d = &Vs[(c + j) * VP + pos];
+            *reinterpret_cast<u32x2*>(d) = h;
+            *reinterpret_cast<u32x2*>(d + V_TERM) = m;
+            *reinterpret_cast<u32x2*>(d + 2 * V_TERM) = l;
+        }
+    };
+    const unsigned short* const Kg = &Ks[fi * KP + 8 * fh];
+    const unsigned short* const Vg = &Vs[fi * VP + 8 * fh];
+    float* const scr = &Scr[wave * 32 * LDO];
+    const float qscale = p.scale * LOG2E;
+
+    int task = blockIdx.x;
+    if (task < n_task) fetch(task, 0);
+    for (; task < n_task; task += gridDim.x) {
+        const int pair = task / n_blk, qb = task - pair * n_blk;
+        const int seq = pair / p.n_head, head = pair - seq * p.n_head;
+        const int q0 = qb * 128 + wave * 32;            // this wave's 32 queries
+        Split qs[2];
+        {
+            long qrow = (long)seq * S + q0 + fi;
+            if constexpr (MAP) qrow = p.row_map[qrow];
+            const float* const qsrc = p.q + qrow * p.ld + head * 32 + 8 * fh;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(qsrc + 16 * s) * qscale, b = *reinterpret_cast<const f32x4*>(qsrc + 16 * s + 4) * qscale;
+                const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                qs[s] = split8(x);
+            }
+        }
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+        float m = -INFINITY, sum = 0.f;
+        for (int kb = 0; kb < n_blk; ++kb) {
+            stash();
+            lds_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb + 1 < n_blk) fetch(task, kb + 1);                     // the next key block (or the next task's first): in flight under the MFMAs
+            else if (task + (int)gridDim.x < n_task) fetch(task + gridDim.x, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 sc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[t][r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const unsigned short* const kp = Kg + t * 32 * KP + 16 * s;
+                    Split ks;
+                    ks.h = *reinterpret_cast<const bf16x8*>(kp);
+                    ks.m = *reinterpret_cast<const bf16x8*>(kp + K_TERM);
+                    ks.l = *reinterpret_cast<const bf16x8*>(kp + 2 * K_TERM);
+                    sc[t] = mfma6(ks, qs[s], sc[t]);
+                }
+            }
+            float mc = sc[0][0];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mc = fmaxf(mc, sc[t][r]);
+            mc = fmaxf(mc, __shfl_xor(mc, 32));
+            const float m_new = fmaxf(m, mc);
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);       // 0 on the first block (m = -inf), 1 when the maximum stands
+            sum *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] *= alpha;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(sc[t][r] - m_new);
+                    sc[t][r] = e;
+                    sum += e;
+                }
+            }
+            m = m_new;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const float x[8] = {sc[t][8 * s], sc[t][8 * s + 1], sc[t][8 * s + 2], sc[t][8 * s + 3],
+                                        sc[t][8 * s + 4], sc[t][8 * s + 5], sc[t][8 * s + 6], sc[t][8 * s + 7]};
+                    const Split ps = split8(x);
+                    const unsigned short* const vp = Vg + t * 32 + 16 * s;
+                    Split vs;
+                    vs.h = *reinterpret_cast<const bf16x8*>(vp);
+                    vs.m = *reinterpret_cast<const bf16x8*>(vp + V_TERM);
+                    vs.l = *reinterpret_cast<const bf16x8*>(vp + 2 * V_TERM);
+                    o = mfma6(vs, ps, o);
+                }
+            }
+            lds_barrier();                               // everyone is done with this block's images
+        }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+        if (lse && fh == 0) lse[((long)seq * S + q0 + fi) * p.n_head + head] = m + log2f(sum);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scr[fi * LDO + (r & 3) + 8 * (r >> 2) + krow] = o[r] * inv;
+        lds_fence();
+        if (fi < p.hd) {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 2 + fh;
+                p.out[((long)seq * S + q0 + row) * p.ldo + head * p.hd + fi] = scr[row * LDO + fi];
+            }
+        }
+        lds_fence();
+    }
+}
+
 int sp_attn_cus() {
     static int n = 0;
     if (n == 0) {
@@ -290,13 +454,23 @@ int launch(SpAttnP p, hipStream_t s) {
 }  // namespace
 
 // LIME_OK / error: launched; LIME_PP_NOT_APPLICABLE: the caller takes token_attn_f32.hip's kernels (masks, other lengths, unpadded
-// heads, the split product switched off).
+// heads, the split product switched off).  lse (optional, S = 256 / 512 only): [tokens, n_head] log2-domain log-sum-exp.
 int lime_token_attention_sp(const float* q, const float* k, const float* v, long ld, const int* row_map, const int* n_seq_dev,
-                            float* out, long ldo, int n_seq, int S, int n_head, int hd, float scale, hipStream_t s) {
+                            float* out, long ldo, int n_seq, int S, int n_head, int hd, float scale, float* lse, hipStream_t s) {
     if (!(lime_split_mode() & 1)) return LIME_PP_NOT_APPLICABLE;
-    if (!(S == 32 || S == 64 || S == 128)) return LIME_PP_NOT_APPLICABLE;
+    const bool is_long = S == 256 || S == 512;
+    if (!(S == 32 || S == 64 || S == 128 || is_long)) return LIME_PP_NOT_APPLICABLE;
+    if (lse && !is_long) return LIME_PP_NOT_APPLICABLE;
     if (ld % 4 != 0 || ld < (long)n_head * 32 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16) != 0 || hd > 32) return LIME_PP_NOT_APPLICABLE;
     SpAttnP p{q, k, v, ld, out, ldo, n_seq, S, n_head, hd, scale, n_seq * n_head, 0, row_map, n_seq_dev};
+    if (is_long) {
+        const long n_task = (long)p.n_pair * (S / 128);
+        long blocks = (long)sp_attn_cus() * 2;
+        if (blocks > n_task) blocks = n_task;
+        if (row_map) hipLaunchKernelGGL((token_attn_sp_long_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, p, lse);
+        else hipLaunchKernelGGL((token_attn_sp_long_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s, p, lse);
+        return lime_check_launch("token_attn_sp_long_kernel");
+    }
     switch (S / 32) {
         case 1: return launch<1>(p, s);
         case 2: return launch<2>(p, s);

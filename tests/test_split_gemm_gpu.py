@@ -298,12 +298,15 @@ def _attn_ref64(qkv, n_seq, S, h, hd, scale):
     return (torch.softmax(a, dim=-1) @ v).transpose(1, 2).reshape(n_seq * S, E)
 
 
-@pytest.mark.parametrize('S', [32, 64, 128])
+@pytest.mark.parametrize('S', [32, 64, 128, 256, 512])
 @pytest.mark.parametrize('h,hd,n_seq', [(10, 30, 37), (7, 20, 5), (3, 32, 1), (10, 30, 700)])
 def test_token_attention_split_product(ops, S, h, hd, n_seq):
     """The encoder layers' attention (heads padded to 32 columns, no mask) on the bf16 matrix cores: against fp64, and no further
     from it than the fp32-MFMA kernel plus a rounding.  n_seq x h is not a multiple of the pairs per group (partial last group);
-    700 sequences make every persistent workgroup walk several groups (the register prefetch)."""
+    700 sequences make every persistent workgroup walk several groups (the register prefetch).  S = 256 / 512: the key-block
+    kernel with its running maximum."""
+    if S > 128 and n_seq > 100:
+        n_seq = 150                                      # (enough tasks for several per workgroup; 700 x 512 tokens would be 4 GB)
     E, W = h * hd, h * 32
     qkv = rnd(n_seq * S, 3 * E, seed=S + h, scale=2.0)
     padded = ops.pad_heads(dev(qkv.t().contiguous()), 3 * h, hd, 32).t().contiguous()
@@ -333,13 +336,13 @@ def test_token_attention_split_product_wide_scores(ops):
     assert rel_err(got.double().numpy(), want.numpy()) <= TIGHT
 
 
-@pytest.mark.parametrize('S', [32, 128])
+@pytest.mark.parametrize('S', [32, 128, 512])
 def test_token_attention_rows_split_product(ops, S):
     """The row-map variant (compacted batches): bit-identical to the dense call on the materialised rows, device-side sequence count."""
     n_seq, h, hd = 23, 10, 30
     W = h * 32
     g = torch.Generator().manual_seed(S)
-    n_rows = 400
+    n_rows = 400 if S <= 128 else 3000
     qkv = (torch.rand(n_rows, 3 * W, generator=g) * 4 - 2)
     qkv.view(n_rows, 3 * h, 32)[:, :, hd:] = 0
     row_map = torch.randint(0, n_rows, (n_seq * S,), generator=g, dtype=torch.int32)

@@ -22,7 +22,7 @@ def timed(fn, n=20):
 def main():
     h, hd = 10, 30
     W = h * 32
-    for n_seq, S in ((516, 32), (486, 128), (1760, 128), (1760, 32)):
+    for n_seq, S in ((516, 32), (486, 128), (1760, 128), (1760, 32), (440, 512), (1760, 512), (880, 256)):
         qkv = torch.randn(n_seq * S, 3 * W, device='cuda')
         qkv.view(-1, 3 * h, 32)[:, :, hd:] = 0
         out = torch.empty(n_seq * S, h * hd, device='cuda')
