@@ -74,22 +74,34 @@ def layer_norm(x, w, b, eps=1e-5):
     return (x - mu) / torch.sqrt(var + eps) * w + b
 
 
+# Test instrumentation (tests/test_bf16_budget.py): name -> callable applied to that intermediate of the token encoders, e.g. a
+# round-to-bf16, to attribute the error of the bf16 build (BASELINE configs[2]) to its rounding points.  Empty: the reference's
+# arithmetic, untouched.
+ROUND = {}
+
+
+def _tap(name, t):
+    f = ROUND.get(name)
+    return f(t) if f is not None else t
+
+
 def encoder_layer(x, sd, p, nhead):
     """One post-LN ``nn.TransformerEncoderLayer`` (ReLU, eps 1e-5, no mask), as constructed at
     newsEncoders.py:244-247 and called at :316,:320.  x: [M, S, E]."""
     M, S, E = x.shape
     hd = E // nhead
-    qkv = x @ sd[p + 'self_attn.in_proj_weight'].t() + sd[p + 'self_attn.in_proj_bias']
+    W = lambda k: _tap('w:' + k, _tap('weights', sd[p + k]))
+    qkv = _tap('qkv', x @ W('self_attn.in_proj_weight').t() + sd[p + 'self_attn.in_proj_bias'])
     q, k, v = qkv.split(E, dim=-1)
     q = q.view(M, S, nhead, hd).transpose(1, 2) * (1.0 / math.sqrt(hd))
     k = k.view(M, S, nhead, hd).transpose(1, 2)
     v = v.view(M, S, nhead, hd).transpose(1, 2)
     a = torch.softmax(q @ k.transpose(-2, -1), dim=-1)
-    o = (a @ v).transpose(1, 2).reshape(M, S, E)
-    o = o @ sd[p + 'self_attn.out_proj.weight'].t() + sd[p + 'self_attn.out_proj.bias']
+    o = _tap('attn_out', (a @ v).transpose(1, 2).reshape(M, S, E))
+    o = o @ W('self_attn.out_proj.weight').t() + sd[p + 'self_attn.out_proj.bias']
     x = layer_norm(x + o, sd[p + 'norm1.weight'], sd[p + 'norm1.bias'])
-    h = torch.relu(x @ sd[p + 'linear1.weight'].t() + sd[p + 'linear1.bias'])
-    h = h @ sd[p + 'linear2.weight'].t() + sd[p + 'linear2.bias']
+    h = _tap('h', torch.relu(_tap('x1', x) @ W('linear1.weight').t() + sd[p + 'linear1.bias']))
+    h = h @ W('linear2.weight').t() + sd[p + 'linear2.bias']
     return layer_norm(x + h, sd[p + 'norm2.weight'], sd[p + 'norm2.bias'])
 
 
@@ -111,8 +123,8 @@ def crown_news_encoder(sd, p, cfg, title_text, content_text, category, subCatego
     M = B * n
     E = cfg.word_embedding_dim
     emb = sd[p + 'word_embedding.weight']
-    title = emb[title_text.reshape(M, T).long()] + positional_encoding(T, E)          # :311,:315
-    body = emb[content_text.reshape(M, L).long()] + positional_encoding(L, E)        # :312,:319
+    title = _tap('word_rows', emb[title_text.reshape(M, T).long()]) + positional_encoding(T, E)          # :311,:315
+    body = _tap('word_rows', emb[content_text.reshape(M, L).long()]) + positional_encoding(L, E)        # :312,:319
     title_t, body_t = title, body
     for li in range(getattr(cfg, 'num_layers', 1)):                                  # config.py:70 (1 or 2), newsEncoders.py:244-247
         title_t = encoder_layer(title_t, sd, p + 'title_transformer.layers.%d.' % li, cfg.head_num)   # :316

@@ -22,7 +22,8 @@ from test_model_gpu import gpu_model, run
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
-BF16_TOL = 1e-2
+BF16_TOL = 6e-3     # observed 4e-3; tests/test_bf16_budget.py attributes it: the bf16 WEIGHTS (a rounding shared by every token, so the
+                    # token mean does not average it out) are 3.3e-3 of an emulated 3.5e-3, every activation rounding together 1.0e-3
 
 
 def _auc(scores):
