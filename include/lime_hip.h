@@ -580,6 +580,13 @@ int lime_token_attention_bwd_lse_f32(const float* q, const float* k, const float
                                      int32_t n_seq, int32_t S, int32_t n_head, int32_t head_dim, int32_t head_stride, float scale,
                                      float* workspace, int64_t workspace_floats, void* stream);
 
+/* Backward of lime_additive_pool_f32 (layers.Attention over a title's tokens, layers.py:285-300 / newsEncoders.py:591-592; the MHSA content
+ * encoder in training): dhidden [n_seq * S, A], dx [n_seq * S, D] and da2_part [n_seq, A], the per-sequence partial rows of the
+ * affine2 gradient (sum them with lime_colsum_f32).  Masked tokens receive no score gradient (their score is the constant -1e9). */
+int lime_additive_pool_bwd_f32(const float* hidden, int64_t ldh, const float* affine2, int32_t A, const float* x, int64_t ldx, int32_t D,
+                               const uint8_t* mask, const float* dout, int64_t ldo, float* dhidden, int64_t lddh, float* dx, int64_t lddx,
+                               float* da2_part, int32_t n_seq, int32_t S, void* stream);
+
 /* ---- dropout inside the token encoders in training mode --------------------------------------------------------------
  * Masks are a pure function of (seed, site, element index) (csrc/dropout.h): element e of site `site` is kept iff
  * hash(seed, site, e) >= p * 2^32, kept values are scaled by 1 / (1 - p); the backward regenerates the mask from the same

@@ -526,6 +526,71 @@ __global__ __launch_bounds__(256) void sum_candidates_kernel(const float* __rest
 
 int persistent_grid(long rows) { return (int)(rows < 256 ? (rows < 1 ? 1 : rows) : 256); }
 
+// Backward of additive_pool_kernel (small_ops.hip; layers.Attention over the tokens of a title, layers.py:285-300 as called at
+// newsEncoders.py:591-592): one workgroup per sequence recomputes alpha = softmax_t(mask(hidden_t . a2)), then
+//   dalpha_t = dout . x_t,   ds_t = alpha_t (dalpha_t - sum_u alpha_u dalpha_u)   (0 on masked tokens: their score is a constant),
+//   dx_t = alpha_t dout,     dhidden_t = ds_t a2,     da2[seq] = sum_t ds_t hidden_t   (per-sequence partial rows; the caller sums them).
+__global__ __launch_bounds__(256) void additive_pool_bwd_kernel(const float* __restrict__ hidden, long ldh, const float* __restrict__ aff2,
+                                                                 int A, const float* __restrict__ x, long ldx, int D,
+                                                                 const unsigned char* __restrict__ mask, const float* __restrict__ dout,
+                                                                 long ldo, float* __restrict__ dhidden, long lddh, float* __restrict__ dx,
+                                                                 long lddx, float* __restrict__ da2_part, int S) {
+    __shared__ float alpha[512];
+    __shared__ float ds[512];
+    __shared__ float red[4];
+    const long s = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* drow = dout + s * ldo;
+    // scores and dalpha: a wave per token
+    for (int t = wave; t < S; t += 4) {
+        const float* h = hidden + (s * S + t) * ldh;
+        const float* xr = x + (s * S + t) * ldx;
+        float part = 0.f, dal = 0.f;
+        for (int j = lane; j < A; j += 64) part += h[j] * aff2[j];
+        for (int d = lane; d < D; d += 64) dal += drow[d] * xr[d];
+        part = wave_sum(part);
+        dal = wave_sum(dal);
+        if (lane == 0) {
+            alpha[t] = (mask && mask[s * S + t] == 0) ? -1e9f : part;
+            ds[t] = dal;
+        }
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int t = threadIdx.x; t < S; t += 256) mx = fmaxf(mx, alpha[t]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float part = 0.f;
+    for (int t = threadIdx.x; t < S; t += 256) {
+        const float e = expf(alpha[t] - mx);
+        alpha[t] = e;
+        part += e;
+    }
+    const float inv = 1.0f / bsum(part, red);
+    float dotp = 0.f;
+    for (int t = threadIdx.x; t < S; t += 256) {
+        alpha[t] *= inv;
+        dotp += alpha[t] * ds[t];
+    }
+    const float dot = bsum(dotp, red);
+    for (int t = threadIdx.x; t < S; t += 256) ds[t] = (mask && mask[s * S + t] == 0) ? 0.f : alpha[t] * (ds[t] - dot);
+    __syncthreads();
+    for (int t = wave; t < S; t += 4) {
+        const float a = alpha[t], g = ds[t];
+        float* dxr = dx + (s * S + t) * lddx;
+        float* dhr = dhidden + (s * S + t) * lddh;
+        for (int d = lane; d < D; d += 64) dxr[d] = a * drow[d];
+        for (int j = lane; j < A; j += 64) dhr[j] = g * aff2[j];
+    }
+    for (int j = threadIdx.x; j < A; j += 256) {
+        float acc = 0.f;
+        for (int t = 0; t < S; ++t) acc += ds[t] * hidden[(s * S + t) * ldh + j];
+        da2_part[s * A + j] = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t lime_intent_fuse_bwd_workspace(int64_t M, int32_t A) { return (int64_t)persistent_grid(M) * 2 * A; }
@@ -647,4 +712,19 @@ extern "C" int lime_cand_attn_weights_bwd_f32(const float* qp, const float* kp, 
     LIME_REQUIRE(dagg && dqp && dkp, LIME_ERR_BAD_ARG, "lime_cand_attn_weights_bwd_f32: null pointer");
     return cand_attn_train(qp, kp, mask, dagg, nullptr, dqp, dkp, B, N, H, D, n_head, dropout_p, seed, site, 1, stream,
                            "lime_cand_attn_weights_bwd_f32");
+}
+
+/* Backward of lime_additive_pool_f32 (see additive_pool_bwd_kernel): dhidden [n_seq * S, A], dx [n_seq * S, D] and the per-sequence
+ * partial rows of the affine2 gradient da2_part [n_seq, A] (summed by the caller: lime_colsum_f32). */
+extern "C" int lime_additive_pool_bwd_f32(const float* hidden, int64_t ldh, const float* affine2, int32_t A, const float* x, int64_t ldx,
+                                          int32_t D, const uint8_t* mask, const float* dout, int64_t ldo, float* dhidden, int64_t lddh,
+                                          float* dx, int64_t lddx, float* da2_part, int32_t n_seq, int32_t S, void* stream) {
+    LIME_REQUIRE(hidden && affine2 && x && dout && dhidden && dx && da2_part, LIME_ERR_BAD_ARG, "lime_additive_pool_bwd_f32: NULL pointer");
+    LIME_REQUIRE(n_seq >= 0 && S > 0 && A > 0 && D > 0 && ldh >= A && ldx >= D && ldo >= D && lddh >= A && lddx >= D, LIME_ERR_BAD_ARG,
+                 "lime_additive_pool_bwd_f32: bad dims");
+    LIME_REQUIRE(S <= 512, LIME_ERR_UNSUPPORTED, "lime_additive_pool_bwd_f32: S %d > 512", S);
+    if (n_seq == 0) return LIME_OK;
+    hipLaunchKernelGGL(additive_pool_bwd_kernel, dim3((unsigned)n_seq), dim3(256), 0, (hipStream_t)stream, hidden, (long)ldh, affine2, A, x,
+                       (long)ldx, D, mask, dout, (long)ldo, dhidden, (long)lddh, dx, (long)lddx, da2_part, S);
+    return lime_check_launch("lime_additive_pool_bwd_f32");
 }

@@ -455,6 +455,25 @@ def additive_pool(hidden, affine2, x, n_seq, S, mask=None, out=None):
     return out
 
 
+def additive_pool_bwd(hidden, affine2, x, dout, n_seq, S, mask=None):
+    """Backward of ``additive_pool``: -> (dhidden [n_seq * S, A], daffine2 [A], dx [n_seq * S, D])."""
+    lib = _lib.load()
+    _mat(hidden, 'hidden')
+    _mat(x, 'x')
+    _mat(dout, 'dout')
+    A, D = hidden.shape[1], x.shape[1]
+    if hidden.shape[0] != n_seq * S or x.shape[0] != n_seq * S or tuple(dout.shape) != (n_seq, D):
+        raise ValueError('hidden and x must have n_seq * S rows, dout must be [n_seq, D]')
+    dh = torch.empty((n_seq * S, A), dtype=torch.float32, device=x.device)
+    dx = torch.empty((n_seq * S, D), dtype=torch.float32, device=x.device)
+    part = torch.empty((max(n_seq, 1), A), dtype=torch.float32, device=x.device)
+    m = _mask_u8(mask, 'mask')
+    check(lib.lime_additive_pool_bwd_f32(_p(hidden), _ld(hidden), _p(_vec(affine2, 'affine2', A)), A, _p(x), _ld(x), D, _p(m), _p(dout),
+                                         _ld(dout), _p(dh), _ld(dh), _p(dx), _ld(dx), _p(part), n_seq, S, _stream()), 'lime_additive_pool_bwd_f32')
+    da2 = colsum(part[:n_seq]) if n_seq else torch.zeros(A, dtype=torch.float32, device=x.device)
+    return dh, da2, dx
+
+
 CAND_ATTN_BY_HEAD = True      # False: the one-workgroup-per-row kernel (tests compare the two)
 
 

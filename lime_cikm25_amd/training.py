@@ -203,6 +203,25 @@ class _MaskedAttention(torch.autograd.Function):
         return dqkv, None, None, None, None, None
 
 
+class _AdditivePool(torch.autograd.Function):
+    """layers.Attention over the tokens of a sequence (layers.py:285-300 as newsEncoders.py:591-592 calls it): rep [M, D] =
+    sum_t softmax_t(mask(hidden_t . a2)) x_t, one kernel each way (lime_additive_pool_f32 / _bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, hidden, a2, x, mask, n_seq, S):
+        hidden, x, a2 = hidden.contiguous(), x.contiguous(), a2.contiguous()
+        ctx.dims = (n_seq, S)
+        ctx.save_for_backward(hidden, a2, x, mask)
+        return ops.additive_pool(hidden, a2, x, n_seq, S, mask=mask)
+
+    @staticmethod
+    def backward(ctx, dout):
+        hidden, a2, x, mask = ctx.saved_tensors
+        n_seq, S = ctx.dims
+        dh, da2, dx = ops.additive_pool_bwd(hidden, a2, x, dout.contiguous(), n_seq, S, mask=mask)
+        return dh, da2, dx, None, None, None
+
+
 class _InterestMatch(torch.autograd.Function):
     """logits [B, N] = (softmax_h(kp . qp / sqrt(A)) g) . cand * lifetime weight (userEncoders.py:158-169, util.py:23-49)."""
 
@@ -585,8 +604,7 @@ def mhsa_content(enc, title_text, title_mask, category, subCategory):
     if p > 0:
         c = _Dropout.apply(c, p, seed, 1)
     hidden = linear(c, att.affine1, act='tanh')                                                                 # layers.py:288
-    score = (hidden * att.affine2.weight.view(1, -1)).sum(dim=-1).view(M, T).masked_fill(mask == 0, -1e9)
-    rep = (torch.softmax(score, dim=1).unsqueeze(-1) * c.view(M, T, -1)).sum(dim=1)                             # :592
+    rep = _AdditivePool.apply(hidden, att.affine2.weight.view(-1), c, mask, M, T)                               # :592, layers.py:289-300
     cat_e = embedding(enc.category_embedding.weight, category)
     sub_e = embedding(enc.subCategory_embedding.weight, subCategory)
     return torch.cat([rep, enc.dropout(cat_e.clone()), enc.dropout(sub_e.clone())], dim=1)                      # :594

@@ -364,3 +364,24 @@ def test_masked_token_attention_bwd(ops, n_seq, S, nh, hd):
     close(out, o.detach().float(), what='masked attention forward')
     dqkv = ops.token_attention_bwd(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], dout.cuda(), n_seq, S, nh, hd, scale, key_mask=mask.cuda())
     close(dqkv, x.grad.float().reshape(tok, 3 * W), tol=2e-4, what='masked dqkv')
+
+
+@pytest.mark.parametrize('n_seq,S,A,D', [(37, 32, 200, 400), (5, 100, 64, 50), (1, 1, 200, 400)])
+def test_additive_pool_bwd(ops, n_seq, S, A, D):
+    """layers.Attention over a sequence's tokens (layers.py:285-300), masked: forward and all three gradients against torch fp64."""
+    hidden, a2, x = rnd(n_seq * S, A, seed=1), rnd(A, seed=2), rnd(n_seq * S, D, seed=3)
+    g = torch.Generator().manual_seed(4)
+    mask = (torch.rand(n_seq, S, generator=g) > 0.3).to(torch.uint8)
+    mask[:, 0] = 1
+    dout = rnd(n_seq, D, seed=5)
+    h64, a64, x64 = hidden.double().requires_grad_(), a2.double().requires_grad_(), x.double().requires_grad_()
+    score = (h64 @ a64).view(n_seq, S).masked_fill(mask == 0, -1e9)
+    rep = (torch.softmax(score, dim=1).unsqueeze(-1) * x64.view(n_seq, S, D)).sum(dim=1)
+    rep.backward(dout.double())
+    got = ops.additive_pool(hidden.cuda(), a2.cuda(), x.cuda(), n_seq, S, mask=mask.cuda())
+    close(got, rep.detach().float(), what='additive pool')
+    dh, da2, dx = ops.additive_pool_bwd(hidden.cuda(), a2.cuda(), x.cuda(), dout.cuda(), n_seq, S, mask=mask.cuda())
+    close(dh, h64.grad.float(), tol=2e-4, what='d hidden')
+    close(da2, a64.grad.float(), tol=2e-4, what='d affine2')
+    close(dx, x64.grad.float(), tol=2e-4, what='d x')
+    assert (dh.cpu().view(n_seq, S, A)[mask == 0] == 0).all()          # a masked token's score is a constant
