@@ -36,6 +36,7 @@
 #include "common.h"
 #include "gemm_pp.h"
 #include "lds_dma.h"
+#include "split_mfma.h"
 
 using namespace lime_dev;
 
@@ -69,34 +70,10 @@ __device__ __forceinline__ int buf_load_i32(__amdgpu_buffer_rsrc_t r, unsigned v
     return (int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0);
 }
 
-struct Split { bf16x8 h, m, l; };
-__device__ __forceinline__ float lo_half(unsigned p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float hi_half(unsigned p) { return __builtin_bit_cast(float, p & 0xFFFF0000u); }
-// eight floats -> three bf16x8 (11 VALU instructions per pair of elements; every subtraction is exact)
-__device__ __forceinline__ Split split8(const f32x4 x0, const f32x4 x1) {
-    u32x4 h, m, l;
-    const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float a = x[2 * q], b = x[2 * q + 1];
-        const unsigned ph = pack_bf16(a, b);
-        const float ra = a - lo_half(ph), rb = b - hi_half(ph);
-        const unsigned pm = pack_bf16(ra, rb);
-        h[q] = ph;
-        m[q] = pm;
-        l[q] = pack_bf16(ra - lo_half(pm), rb - hi_half(pm));
-    }
-    return Split{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, m), __builtin_bit_cast(bf16x8, l)};
-}
-__device__ __forceinline__ f32x4 mfma6(const Split& w, const Split& a, f32x4 c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.l, a.h, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h, a.l, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.m, a.m, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.m, a.h, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h, a.m, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h, a.h, c, 0, 0, 0);
-    return c;
-}
+// the three-term split and the six-MFMA product: split_mfma.h
+using Split = SplitFrag;
+__device__ __forceinline__ Split split8(const f32x4 x0, const f32x4 x1) { return split_frag(x0, x1); }
+__device__ __forceinline__ f32x4 mfma6(const Split& w, const Split& a, f32x4 c) { return split_mfma16(w, a, c); }
 
 // CT: 16-column tiles per wave (tile width 32 CT).  LN / RELU / RES / POOL / RSTD / CID as in gemm_pp_kernel:
 // RES 0 none, 1 dense fp32 residual rows (r, or r % res_mod; with CID: c_ids[r] % res_mod), 2 rows gathered by res_ids + the fp32

@@ -26,6 +26,17 @@ __device__ __forceinline__ SplitFrag split_frag(const float (&x)[8]) {
     }
     return SplitFrag{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, m), __builtin_bit_cast(bf16x8, l)};
 }
+__device__ __forceinline__ SplitFrag split_frag(const f32x4 x0, const f32x4 x1) {
+    const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+    return split_frag(x);
+}
+// four values -> two packed pairs per term (8 bytes each)
+__device__ __forceinline__ void split_quad(float x0, float x1, float x2, float x3, u32x2& h, u32x2& m, u32x2& l) {
+    const SplitPair a = split_pair(x0, x1), b = split_pair(x2, x3);
+    h = u32x2{a.h, b.h};
+    m = u32x2{a.m, b.m};
+    l = u32x2{a.l, b.l};
+}
 // C (16 x 16) += A (16 x 32) B (32 x 16), both operands in three terms
 __device__ __forceinline__ f32x4 split_mfma16(const SplitFrag& a, const SplitFrag& b, f32x4 c) {
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, c, 0, 0, 0);
@@ -34,6 +45,17 @@ __device__ __forceinline__ f32x4 split_mfma16(const SplitFrag& a, const SplitFra
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.h, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.m, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, c, 0, 0, 0);
+    return c;
+}
+
+// C (32 x 32) += A (32 x 16) B (16 x 32)
+__device__ __forceinline__ f32x16 split_mfma32(const SplitFrag& a, const SplitFrag& b, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, c, 0, 0, 0);
     return c;
 }
 

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "gemm_pp.h"
 #include "lds_dma.h"
+#include "split_mfma.h"
 
 using namespace lime_dev;
 
@@ -31,43 +32,10 @@ struct SpAttnP {
     const int* row_map; const int* n_seq_dev;
 };
 
-struct Split { bf16x8 h, m, l; };
-__device__ __forceinline__ float lo_half(unsigned p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float hi_half(unsigned p) { return __builtin_bit_cast(float, p & 0xFFFF0000u); }
-// two floats -> the three packed bf16 pairs
-struct Pair3 { unsigned h, m, l; };
-__device__ __forceinline__ Pair3 split2(float a, float b) {
-    Pair3 r;
-    r.h = pack_bf16(a, b);
-    const float ra = a - lo_half(r.h), rb = b - hi_half(r.h);
-    r.m = pack_bf16(ra, rb);
-    r.l = pack_bf16(ra - lo_half(r.m), rb - hi_half(r.m));
-    return r;
-}
-__device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, u32x2& h, u32x2& m, u32x2& l) {
-    const Pair3 a = split2(x0, x1), b = split2(x2, x3);
-    h = u32x2{a.h, b.h};
-    m = u32x2{a.m, b.m};
-    l = u32x2{a.l, b.l};
-}
-__device__ __forceinline__ Split split8(const float (&x)[8]) {
-    u32x4 h, m, l;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const Pair3 t = split2(x[2 * q], x[2 * q + 1]);
-        h[q] = t.h; m[q] = t.m; l[q] = t.l;
-    }
-    return Split{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, m), __builtin_bit_cast(bf16x8, l)};
-}
-__device__ __forceinline__ f32x16 mfma6(const Split& w, const Split& a, f32x16 c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.l, a.h, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, a.l, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.m, a.m, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.m, a.h, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, a.m, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.h, a.h, c, 0, 0, 0);
-    return c;
-}
+using Split = SplitFrag;                            // split_mfma.h
+__device__ __forceinline__ Split split8(const float (&x)[8]) { return split_frag(x); }
+__device__ __forceinline__ void split4(float x0, float x1, float x2, float x3, u32x2& h, u32x2& m, u32x2& l) { split_quad(x0, x1, x2, x3, h, m, l); }
+__device__ __forceinline__ f32x16 mfma6(const Split& w, const Split& a, f32x16 c) { return split_mfma32(w, a, c); }
 __device__ __forceinline__ void lds_fence() {          // (see token_attn_f32.hip: wave-level, vmcnt left alone)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "gemm_pp.h"
 #include "lds_dma.h"
+#include "split_mfma.h"
 
 using namespace lime_dev;
 
@@ -28,32 +29,9 @@ constexpr int A_FLOATS = 4 * A_GRP, B_FLOATS = 4 * B_GRP, STAGE = A_FLOATS + B_F
 constexpr int CT = TK / 32;                        // 16-column accumulator tiles per wave along k: 10
 static_assert(2 * STAGE * 4 <= 163840, "LDS budget");
 
-struct Split { bf16x8 h, m, l; };
-__device__ __forceinline__ float lo_half(unsigned p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float hi_half(unsigned p) { return __builtin_bit_cast(float, p & 0xFFFF0000u); }
-__device__ __forceinline__ Split split8(const float (&x)[8]) {          // as in gemm_sp_f32.hip: every subtraction is exact
-    u32x4 h, m, l;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float a = x[2 * q], b = x[2 * q + 1];
-        const unsigned ph = pack_bf16(a, b);
-        const float ra = a - lo_half(ph), rb = b - hi_half(ph);
-        const unsigned pm = pack_bf16(ra, rb);
-        h[q] = ph;
-        m[q] = pm;
-        l[q] = pack_bf16(ra - lo_half(pm), rb - hi_half(pm));
-    }
-    return Split{__builtin_bit_cast(bf16x8, h), __builtin_bit_cast(bf16x8, m), __builtin_bit_cast(bf16x8, l)};
-}
-__device__ __forceinline__ f32x4 mfma6(const Split& w, const Split& a, f32x4 c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.l, a.h, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h, a.l, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.m, a.m, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.m, a.h, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h, a.m, c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h, a.h, c, 0, 0, 0);
-    return c;
-}
+using Split = SplitFrag;                            // split_mfma.h
+__device__ __forceinline__ Split split8(const float (&x)[8]) { return split_frag(x); }
+__device__ __forceinline__ f32x4 mfma6(const Split& w, const Split& a, f32x4 c) { return split_mfma16(w, a, c); }
 // eight floats down a column of the [m][COLS] chunk image: rows 8 kg .. 8 kg + 7 of the lane's group
 template <int COLS>
 __device__ __forceinline__ void column8(const float* p, float (&x)[8]) {
