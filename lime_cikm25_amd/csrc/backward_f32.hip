@@ -1287,6 +1287,7 @@ __global__ __launch_bounds__(512) void attn_bwd_long_kernel(const float* __restr
 // rows (P / dS image 33 KB): phase 1 wave w = query tile w & 3 x key half w >> 2; dV / dK wave w = keys 16 w .. 16 w + 15 as in
 // attn_bwd_long_kernel; dQ wave w = query tile w & 3 x head-dim half w >> 2.  Same slabs, same reduction order over key blocks.
 constexpr int LQ = 64;
+template <int SP_LDP, int SP_AB>
 __global__ __launch_bounds__(512) void attn_bwd_long_sp_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                 const float* __restrict__ v, long ld, const float* __restrict__ dout,
                                                                 long ldo, const float* __restrict__ stats, float* __restrict__ dq,
@@ -1294,14 +1295,17 @@ __global__ __launch_bounds__(512) void attn_bwd_long_sp_kernel(const float* __re
                                                                 int n_head, int head_dim, int head_stride, float scale, int n_blk,
                                                                 LimeDropout drop, float* __restrict__ dq_slabs, long n_tok) {
     using namespace lime_dev;
-    constexpr int LDP = LB + 2, TS = LB * SPLIT_PITCH;
+    // LDS pitches (template parameters for A/B runs): 48 % of this kernel's LDS cycles are bank conflicts of the 16x16x4 fragment walks
+    // (profiles/r03_sp_kernel_counters.txt), but pitches that remove them (P / dS image 145 or 148 or 180 floats, operand images 48)
+    // measured 0 .. +4 % kernel time on one box (profiles/r03_notes.md): the fp32 products of dV / dK / dQ bound it, not the LDS.
+    constexpr int LDP = SP_LDP, AB = SP_AB, TS = LB * SPLIT_PITCH;
     extern __shared__ float smem[];
     unsigned short* const Kt = reinterpret_cast<unsigned short*>(smem);       // three bf16 images of the K block
     unsigned short* const Vt = Kt + 3 * TS;
     float* const Ks = smem + 3 * TS;             // (2 x 3 TS bf16 = 3 TS floats) the K block in fp32: the B operand of dQ
-    float* const Qs = Ks + LB * AB_LD;           // [LQ][AB_LD]
-    float* const Os = Qs + LQ * AB_LD;
-    float* const Ps = Os + LQ * AB_LD;           // [LQ][LDP]: P, then dS
+    float* const Qs = Ks + LB * AB;           // [LQ][AB]
+    float* const Os = Qs + LQ * AB;
+    float* const Ps = Os + LQ * AB;           // [LQ][LDP]: P, then dS
     float* const Ls = Ps + LQ * LDP;
     float* const Ds = Ls + LQ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, kg = lane >> 4;
@@ -1311,7 +1315,10 @@ __global__ __launch_bounds__(512) void attn_bwd_long_sp_kernel(const float* __re
     const long row_base = (long)seq * S;
     const int k0 = kb * LB, k_valid = min(LB, S - k0);
     const int R0 = 16 * wave, qi = wave & 3, hh = wave >> 2;
-    stage_rows(Ks, k, ld, row_base + k0, k_valid, head * head_stride, head_dim, tid);
+    for (int e = tid; e < LB * 32; e += 512) {      // the fp32 K block, pitch AB
+        const int r = e >> 5, c = e & 31;
+        Ks[r * AB + c] = (r < k_valid && c < head_dim) ? k[(row_base + k0 + r) * ld + head * head_stride + c] : 0.f;
+    }
     stage_rows_split(Kt, k, ld, row_base + k0, k_valid, head * head_stride, head_dim, tid);
     stage_rows_split(Vt, v, ld, row_base + k0, k_valid, head * head_stride, head_dim, tid);
     f32x4 av0 = {0.f, 0.f, 0.f, 0.f}, av1 = av0, ak0 = av0, ak1 = av0;
@@ -1342,8 +1349,8 @@ __global__ __launch_bounds__(512) void attn_bwd_long_sp_kernel(const float* __re
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = tid + 512 * u, r = e >> 5, c = e & 31;
-            Qs[r * AB_LD + c] = pq[u];
-            Os[r * AB_LD + c] = po[u];
+            Qs[r * AB + c] = pq[u];
+            Os[r * AB + c] = po[u];
         }
         if (tid < LQ) { Ls[tid] = pl; Ds[tid] = pd; }
         __syncthreads();
@@ -1354,8 +1361,8 @@ __global__ __launch_bounds__(512) void attn_bwd_long_sp_kernel(const float* __re
             float xq[8], xo[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                xq[j] = Qs[(16 * qi + fi) * AB_LD + 8 * kg + j];
-                xo[j] = Os[(16 * qi + fi) * AB_LD + 8 * kg + j];
+                xq[j] = Qs[(16 * qi + fi) * AB + 8 * kg + j];
+                xo[j] = Os[(16 * qi + fi) * AB + 8 * kg + j];
             }
             const SplitFrag qs = split_frag(xq), os = split_frag(xo);
 #pragma unroll
@@ -1390,8 +1397,8 @@ __global__ __launch_bounds__(512) void attn_bwd_long_sp_kernel(const float* __re
         for (int t = 0; t < LQ / 4; ++t) {
             const int i = 4 * t + kg;
             const float a = Ps[i * LDP + R0 + fi];
-            av0 = mfma16(a, Os[i * AB_LD + fi], av0);
-            av1 = mfma16(a, Os[i * AB_LD + 16 + fi], av1);
+            av0 = mfma16(a, Os[i * AB + fi], av0);
+            av1 = mfma16(a, Os[i * AB + 16 + fi], av1);
         }
         __syncthreads();
 #pragma unroll
@@ -1404,14 +1411,14 @@ __global__ __launch_bounds__(512) void attn_bwd_long_sp_kernel(const float* __re
         for (int t = 0; t < LQ / 4; ++t) {
             const int j = 4 * t + kg;
             const float ds_col = Ps[j * LDP + R0 + fi];
-            ak0 = mfma16(ds_col, Qs[j * AB_LD + fi], ak0);
-            ak1 = mfma16(ds_col, Qs[j * AB_LD + 16 + fi], ak1);
+            ak0 = mfma16(ds_col, Qs[j * AB + fi], ak0);
+            ak1 = mfma16(ds_col, Qs[j * AB + 16 + fi], ak1);
         }
         f32x4 aq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
         for (int t = 0; t < LB / 4; ++t) {
             const int j = 4 * t + kg;
-            aq = mfma16(Ps[(16 * qi + fi) * LDP + j], Ks[j * AB_LD + 16 * hh + fi], aq);
+            aq = mfma16(Ps[(16 * qi + fi) * LDP + j], Ks[j * AB + 16 * hh + fi], aq);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1956,16 +1963,19 @@ static int attention_bwd(const float* q, const float* k, const float* v, int64_t
     int st = lime_check_launch("attn_stats_kernel");
     if (st != LIME_OK) return st;
     if (spx) {
-        constexpr int BYTES_SP = (3 * LB * lime_dev::SPLIT_PITCH + LB * AB_LD + 2 * LQ * AB_LD + LQ * (LB + 2) + 2 * LQ) * 4;
+        constexpr int SP_LDP = LB + 2, SP_AB = AB_LD;
+        constexpr int BYTES_SP = (3 * LB * lime_dev::SPLIT_PITCH + LB * SP_AB + 2 * LQ * SP_AB + LQ * SP_LDP + 2 * LQ) * 4;
+        static_assert(BYTES_SP <= 163840, "LDS budget");
         static bool configured_sp = false;
         if (!configured_sp) {
-            e = hipFuncSetAttribute((const void*)attn_bwd_long_sp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES_SP);
+            e = hipFuncSetAttribute((const void*)attn_bwd_long_sp_kernel<SP_LDP, SP_AB>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES_SP);
             LIME_REQUIRE(e == hipSuccess, LIME_ERR_LAUNCH, "lime_token_attention_bwd_f32: cannot reserve %d bytes of LDS: %s", BYTES_SP,
                          hipGetErrorString(e));
             configured_sp = true;
         }
-        attn_bwd_long_sp_kernel<<<(unsigned)(n_prob * n_blk), 512, BYTES_SP, s>>>(q, k, v, ld_qkv, dout, ldo, workspace, dq, dk, dv, ld_dqkv,
-                                                                                 S, n_head, head_dim, head_stride, scale, n_blk, drop, dq_slabs, n_tok);
+        attn_bwd_long_sp_kernel<SP_LDP, SP_AB><<<(unsigned)(n_prob * n_blk), 512, BYTES_SP, s>>>(q, k, v, ld_qkv, dout, ldo, workspace, dq, dk, dv,
+                                                                                                ld_dqkv, S, n_head, head_dim, head_stride, scale,
+                                                                                                n_blk, drop, dq_slabs, n_tok);
         st = lime_check_launch("attn_bwd_long_sp_kernel");
         if (st != LIME_OK || n_blk == 1) return st;
         const long total_sp = n_tok * n_head * head_stride;
