@@ -148,6 +148,13 @@ def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=
     args.M, args.N, args.K = M, N, K
     args.act = LIME_ACT[act]
     args.act_scale = act_scale
+    if ln is not None and M >= 4096 and not _SLOW_LN_WARNED and not _friendly16(a, w, out, res):
+        # the LayerNorm epilogue of a big problem whose operands are not 16-byte friendly runs on the general kernel's 5-tile-wide
+        # instantiation (256 registers in scratch, a tenth of the LDS-DMA kernels' rate): say so once instead of being silently slow
+        import warnings
+        warnings.warn('lime_linear_f32: LayerNorm epilogue on operands that are not 16-byte aligned with leading dimensions that are '
+                      'multiples of 4 (M = %d): this takes the slow general kernel; pass contiguous / aligned views' % M, RuntimeWarning)
+        globals()['_SLOW_LN_WARNED'] = True
     if _build_only:
         return args, out
     if PROFILE is not None:
@@ -161,6 +168,13 @@ def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=
         return out
     check(lib.lime_linear_f32(ctypes.byref(args), _stream()), 'lime_linear_f32')
     return out
+
+
+_SLOW_LN_WARNED = False
+
+
+def _friendly16(*tensors):
+    return all(t is None or (t.data_ptr() % 16 == 0 and _ld(t) % 4 == 0) for t in tensors)
 
 
 GROUP_SMALL_GEMMS = True      # False: linear_group issues its problems one by one (A/B runs, tests)

@@ -889,3 +889,22 @@ def test_linear_group_equals_separate_launches(ops):
     lnp = dict(a=dev(rnd(200, 300, seed=15)), w=dev(rnd(300, 300, seed=16, scale=0.05)), bias=None, ln=(dev(rnd(300, seed=17) + 1.5), dev(rnd(300, seed=18))))
     outs = ops.linear_group([dict(probs[0]), lnp])
     check(outs[1], O.layer_norm(lnp['a'].cpu() @ lnp['w'].cpu().t(), lnp['ln'][0].cpu(), lnp['ln'][1].cpu()), what='fallback')
+
+
+def test_misaligned_layernorm_epilogue_warns_once(ops):
+    """A big LayerNorm GEMM on a view that is not 16-byte aligned still computes (general kernel) but says that it is the slow path."""
+    from lime_cikm25_amd import ops as O
+    M, N, K = 4200, 300, 64
+    wide = dev(rnd(M, K + 4, seed=1))
+    a = wide[:, 1:K + 1]                                   # 4-byte offset: not 16-byte aligned
+    w, res = dev(rnd(N, K, seed=2, scale=0.2)), dev(rnd(M, N, seed=3))
+    g, b = dev(rnd(N, seed=4) * 0.5 + 1.0), dev(rnd(N, seed=5))
+    O._SLOW_LN_WARNED = False
+    with pytest.warns(RuntimeWarning, match='slow general kernel'):
+        got = ops.linear(a, w, None, res=res, ln=(g, b))
+    want = torch.nn.functional.layer_norm(a.cpu().double() @ w.cpu().double().t() + res.cpu().double(), (N,), g.cpu().double(), b.cpu().double())
+    check(got, want.float(), what='misaligned LayerNorm GEMM')
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        ops.linear(a, w, None, res=res, ln=(g, b))          # only once per process
