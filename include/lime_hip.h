@@ -546,6 +546,14 @@ int lime_layernorm_bwd_f32(const float* dy, int64_t lddy, int32_t dy_div, float 
                            const float* gamma, const float* beta, const float* rstd, float* dz, int64_t lddz, int32_t M,
                            int32_t E, float* dgamma, float* dbeta, float* dzsum, int32_t accumulate, float* workspace,
                            int64_t workspace_floats, void* stream);
+/* The same with a second result dz_drop[r, c] = keep(r * E + c) ? dz[r, c] / (1 - p) : 0 -- the gradient through the dropout that sits in
+ * front of the residual add (dropout1 / dropout2 of the encoder layer, newsEncoders.py:244-247) with the forward's (p, seed, site) --
+ * written in the same pass instead of a lime_dropout_f32 pass over dz.  16-byte friendly operands only. */
+int lime_layernorm_bwd_dropout_f32(const float* dy, int64_t lddy, int32_t dy_div, float dy_scale, const float* y, int64_t ldy,
+                                   const float* gamma, const float* beta, const float* rstd, float* dz, int64_t lddz, int32_t M, int32_t E,
+                                   float* dgamma, float* dbeta, float* dzsum, int32_t accumulate, float* workspace,
+                                   int64_t workspace_floats, float* dz_drop, int64_t lddd, float dropout_p, uint64_t seed, uint32_t site,
+                                   void* stream);
 
 /* dh[r, c] = h[r, c] > 0 ? dh[r, c] * scale : 0, in place: ReLU backward on the saved activation of linear1 (scale = 1), or
  * ReLU + the dropout that follows it when h is the dropped-out activation (scale = 1 / (1 - p)) */
@@ -596,6 +604,10 @@ int lime_additive_pool_bwd_f32(const float* hidden, int64_t ldh, const float* af
  * gradient with the forward's (seed, site) -- its backward. */
 int lime_dropout_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int32_t cols, float p, uint64_t seed,
                      uint32_t site, void* stream);
+/* dst = dropout_site2(dropout_site1(src)) in one pass (the same values as two lime_dropout_f32 calls): the backward through the two
+ * input dropouts of an encoder layer (positional, then embedding: newsEncoders.py:311-312, :827). */
+int lime_dropout2_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int32_t cols, float p, uint64_t seed,
+                      uint32_t site1, uint32_t site2, void* stream);
 
 /* out[r, :] = drop_pe(drop_emb(table[ids[r], :]) + pe[r % period, :]): the inplace dropout on the word embeddings
  * (newsEncoders.py:311-312) and PositionalEncoding's dropout (:827) in one pass; element index r * dim + c for both sites. */

@@ -195,6 +195,10 @@ SIGNATURES = {
     'lime_layernorm_bwd_f32': (c_int32, [c_void_p, c_int64, c_int32, c_float, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
                                          c_int64, c_void_p]),
+    'lime_layernorm_bwd_dropout_f32': (c_int32, [c_void_p, c_int64, c_int32, c_float, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                                 c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+                                                 c_int64, c_void_p, c_int64, c_float, c_uint64, c_uint32, c_void_p]),
+    'lime_dropout2_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_float, c_uint64, c_uint32, c_uint32, c_void_p]),
     'lime_relu_bwd_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_float, c_void_p]),
     'lime_token_attention_bwd_workspace': (c_int64, [c_int32, c_int32, c_int32]),
     'lime_token_attention_stats_workspace': (c_int64, [c_int32, c_int32, c_int32]),

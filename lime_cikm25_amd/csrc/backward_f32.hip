@@ -480,7 +480,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
                                                                  const float* __restrict__ y, long ldy,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  const float* __restrict__ rstd, float* __restrict__ dz, long lddz,
-                                                                 int M, int E, float* __restrict__ ws) {
+                                                                 int M, int E, float* __restrict__ ws,
+                                                                 float* __restrict__ dz_drop, long lddd, LimeDropout drop) {
     __shared__ float red[4][3][64 * V4];
     __shared__ __attribute__((aligned(16))) float Gs[64 * V4], Bs[64 * V4], IGs[64 * V4];   // gamma, beta, 1 / gamma (registers are
                                                                                           // for the column sums: occupancy)
@@ -534,6 +535,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
             f32x4v v = (d[j] * *reinterpret_cast<const f32x4v*>(&gs[c]) - s1 - xh[j] * s2) * rs;
             if (!ok) v = zero;
             if (ok) *reinterpret_cast<f32x4v*>(dz + r * lddz + c) = v;
+            if (dz_drop != nullptr && ok) {            // the gradient through the dropout in front of the residual add, written alongside
+                const unsigned keep = lime_keep4(drop, ((uint64_t)r * (uint64_t)E + (uint64_t)c) >> 2);
+                f32x4v t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = (keep >> e) & 1u ? v[e] * drop.scale : 0.f;
+                *reinterpret_cast<f32x4v*>(dz_drop + r * lddd + c) = t;
+            }
             sg[j] += d[j] * xh[j];
             sb[j] += d[j];
             sz[j] += v;
@@ -1811,10 +1819,10 @@ extern "C" int64_t lime_layernorm_bwd_workspace(int32_t M, int32_t E) {
     return (int64_t)ln_blocks(M) * 3 * E;
 }
 
-extern "C" int lime_layernorm_bwd_f32(const float* dy, int64_t lddy, int32_t dy_div, float dy_scale, const float* y, int64_t ldy,
-                                      const float* gamma, const float* beta, const float* rstd, float* dz, int64_t lddz,
-                                      int32_t M, int32_t E, float* dgamma, float* dbeta, float* dzsum, int32_t accumulate,
-                                      float* workspace, int64_t workspace_floats, void* stream) {
+static int layernorm_bwd(const float* dy, int64_t lddy, int32_t dy_div, float dy_scale, const float* y, int64_t ldy,
+                         const float* gamma, const float* beta, const float* rstd, float* dz, int64_t lddz,
+                         int32_t M, int32_t E, float* dgamma, float* dbeta, float* dzsum, int32_t accumulate,
+                         float* workspace, int64_t workspace_floats, float* dz_drop, int64_t lddd, const LimeDropout& drop, void* stream) {
     LIME_REQUIRE(dy && y && gamma && beta && rstd && dz && workspace, LIME_ERR_BAD_ARG, "lime_layernorm_bwd_f32: null pointer");
     LIME_REQUIRE(M > 0 && E > 0 && dy_div >= 1, LIME_ERR_BAD_ARG, "lime_layernorm_bwd_f32: bad dimensions");
     LIME_REQUIRE(E <= 512, LIME_ERR_UNSUPPORTED, "lime_layernorm_bwd_f32: E = %d > 512", E);
@@ -1824,9 +1832,11 @@ extern "C" int lime_layernorm_bwd_f32(const float* dy, int64_t lddy, int32_t dy_
     hipStream_t s = (hipStream_t)stream;
     const bool vec = E % 4 == 0 && lddy % 4 == 0 && ldy % 4 == 0 && lddz % 4 == 0 &&
                      ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)dz) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0;
+    LIME_REQUIRE(dz_drop == nullptr || (vec && lddd % 4 == 0 && (((uintptr_t)dz_drop) & 15) == 0 && lddd >= E), LIME_ERR_UNSUPPORTED,
+                 "lime_layernorm_bwd_dropout_f32: the dropped copy needs 16-byte friendly operands (E, leading dimensions multiples of 4)");
     if (vec) {
         const int v4 = (E + 63) / 64;
-#define LN_BWD_V(C) layernorm_bwd_vec_kernel<C><<<nblk, 256, 0, s>>>(dy, lddy, dy_div, dy_scale, y, ldy, gamma, beta, rstd, dz, lddz, M, E, workspace)
+#define LN_BWD_V(C) layernorm_bwd_vec_kernel<C><<<nblk, 256, 0, s>>>(dy, lddy, dy_div, dy_scale, y, ldy, gamma, beta, rstd, dz, lddz, M, E, workspace, dz_drop, lddd, drop)
         if (v4 <= 2) LN_BWD_V(2); else if (v4 <= 5) LN_BWD_V(5); else LN_BWD_V(8);
 #undef LN_BWD_V
     } else {
@@ -1848,6 +1858,25 @@ extern "C" int lime_layernorm_bwd_f32(const float* dy, int64_t lddy, int32_t dy_
         if (st != LIME_OK) return st;
     }
     return LIME_OK;
+}
+
+extern "C" int lime_layernorm_bwd_f32(const float* dy, int64_t lddy, int32_t dy_div, float dy_scale, const float* y, int64_t ldy,
+                                      const float* gamma, const float* beta, const float* rstd, float* dz, int64_t lddz,
+                                      int32_t M, int32_t E, float* dgamma, float* dbeta, float* dzsum, int32_t accumulate,
+                                      float* workspace, int64_t workspace_floats, void* stream) {
+    return layernorm_bwd(dy, lddy, dy_div, dy_scale, y, ldy, gamma, beta, rstd, dz, lddz, M, E, dgamma, dbeta, dzsum, accumulate, workspace,
+                         workspace_floats, nullptr, 0, lime_make_dropout(0.f, 0, 0), stream);
+}
+
+extern "C" int lime_layernorm_bwd_dropout_f32(const float* dy, int64_t lddy, int32_t dy_div, float dy_scale, const float* y, int64_t ldy,
+                                              const float* gamma, const float* beta, const float* rstd, float* dz, int64_t lddz,
+                                              int32_t M, int32_t E, float* dgamma, float* dbeta, float* dzsum, int32_t accumulate,
+                                              float* workspace, int64_t workspace_floats, float* dz_drop, int64_t lddd, float dropout_p,
+                                              uint64_t seed, uint32_t site, void* stream) {
+    LIME_REQUIRE(dz_drop != nullptr, LIME_ERR_BAD_ARG, "lime_layernorm_bwd_dropout_f32: dz_drop is NULL");
+    LIME_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, LIME_ERR_BAD_ARG, "lime_layernorm_bwd_dropout_f32: dropout_p outside [0, 1)");
+    return layernorm_bwd(dy, lddy, dy_div, dy_scale, y, ldy, gamma, beta, rstd, dz, lddz, M, E, dgamma, dbeta, dzsum, accumulate, workspace,
+                         workspace_floats, dz_drop, lddd, lime_make_dropout(dropout_p, seed, site), stream);
 }
 
 extern "C" int lime_relu_bwd_f32(float* dh, int64_t lddh, const float* h, int64_t ldh, int64_t rows, int32_t cols, float scale,

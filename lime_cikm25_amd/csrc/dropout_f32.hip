@@ -36,6 +36,23 @@ __global__ __launch_bounds__(256) void dropout_vec4_kernel(const float* __restri
     }
 }
 
+// two dropout sites over the same tensor in one pass (the backward through the positional and the embedding dropout of the layer input)
+__global__ __launch_bounds__(256) void dropout2_vec4_kernel(const float* __restrict__ src, long lds, float* __restrict__ dst, long ldd,
+                                                             long rows, int cols, LimeDropout d1, LimeDropout d2) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const int c4n = cols >> 2;
+    const long total = rows * c4n;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+        const long r = q / c4n;
+        const int c = (int)(q - r * c4n) * 4;
+        const unsigned m = lime_keep4(d1, (uint64_t)q) & lime_keep4(d2, (uint64_t)q);
+        v4 v = *reinterpret_cast<const v4*>(src + r * lds + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (m >> e) & 1u ? (v[e] * d1.scale) * d2.scale : 0.f;     // the same two roundings as two passes
+        *reinterpret_cast<v4*>(dst + r * ldd + c) = v;
+    }
+}
+
 // out[r, c] = drop_pe(drop_emb(table[ids[r], c]) + pe[r % period, c])
 __global__ __launch_bounds__(256) void embed_pe_dropout_kernel(const int* __restrict__ ids, const float* __restrict__ table,
                                                                 long ld_table, const float* __restrict__ pe, long ld_pe, int period,
@@ -193,6 +210,22 @@ extern "C" int lime_dropout_f32(const float* src, int64_t lds, float* dst, int64
     else
         dropout_kernel<<<grid_for(rows * cols), 256, 0, (hipStream_t)stream>>>(src, lds, dst, ldd, rows, cols, d);
     return lime_check_launch("dropout_kernel");
+}
+
+extern "C" int lime_dropout2_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int32_t cols, float p, uint64_t seed,
+                                 uint32_t site1, uint32_t site2, void* stream) {
+    LIME_REQUIRE(src && dst, LIME_ERR_BAD_ARG, "lime_dropout2_f32: null pointer");
+    LIME_REQUIRE(rows >= 0 && cols > 0 && lds >= cols && ldd >= cols, LIME_ERR_BAD_ARG, "lime_dropout2_f32: bad dimensions");
+    LIME_REQUIRE(p >= 0.f && p < 1.f, LIME_ERR_BAD_ARG, "lime_dropout2_f32: p = %g outside [0, 1)", (double)p);
+    if (rows == 0) return LIME_OK;
+    if (cols % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) {
+        dropout2_vec4_kernel<<<grid_for(rows * (cols / 4)), 256, 0, (hipStream_t)stream>>>(src, lds, dst, ldd, rows, cols,
+                                                                                          lime_make_dropout(p, seed, site1),
+                                                                                          lime_make_dropout(p, seed, site2));
+        return lime_check_launch("dropout2_vec4_kernel");
+    }
+    const int st = lime_dropout_f32(src, lds, dst, ldd, rows, cols, p, seed, site1, stream);     // other layouts: two passes
+    return st != LIME_OK ? st : lime_dropout_f32(dst, ldd, dst, ldd, rows, cols, p, seed, site2, stream);
 }
 
 extern "C" int lime_embed_pe_dropout_f32(const int32_t* ids, const float* table, int64_t ld_table, const float* pe, int64_t ld_pe,

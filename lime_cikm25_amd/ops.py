@@ -1060,8 +1060,9 @@ def colsum(x, out=None, accumulate=False):
     return out
 
 
-def layernorm_bwd(dy, y, gamma, beta, rstd, dy_div=1, dy_scale=1.0, want_dzsum=True):
-    """Backward of y = LayerNorm(z): returns (dz [M, E], dgamma, dbeta, dzsum or None).  dy: [ceil(M / dy_div), E]."""
+def layernorm_bwd(dy, y, gamma, beta, rstd, dy_div=1, dy_scale=1.0, want_dzsum=True, dropout=None):
+    """Backward of y = LayerNorm(z): returns (dz [M, E], dgamma, dbeta, dzsum or None).  dy: [ceil(M / dy_div), E].
+    ``dropout`` = (p, seed, site): a fifth result, dropout(dz) under that site's mask, written in the same pass."""
     lib = _lib.load()
     _mat(dy, 'dy')
     _mat(y, 'y')
@@ -1077,6 +1078,15 @@ def layernorm_bwd(dy, y, gamma, beta, rstd, dy_div=1, dy_scale=1.0, want_dzsum=T
     dbeta = torch.empty(E, dtype=torch.float32, device=dev)
     dzsum = torch.empty(E, dtype=torch.float32, device=dev) if want_dzsum else None
     ws = _workspace(dev, lib.lime_layernorm_bwd_workspace(M, E))
+    if dropout is not None:
+        if E % 4 or _ld(dy) % 4 or _ld(y) % 4:           # the fused copy needs 16-byte rows: otherwise a dropout pass of its own
+            res = layernorm_bwd(dy, y, gamma, beta, rstd, dy_div, dy_scale, want_dzsum)
+            return res + (globals()['dropout'](res[0], *dropout),)
+        dt = torch.empty((M, E), dtype=torch.float32, device=dev)
+        check(lib.lime_layernorm_bwd_dropout_f32(_p(dy), _ld(dy), dy_div, dy_scale, _p(y), _ld(y), _p(gamma), _p(beta), _p(rstd), _p(dz),
+                                                 _ld(dz), M, E, _p(dgamma), _p(dbeta), _p(dzsum), 0, _p(ws), ws.numel(), _p(dt), _ld(dt),
+                                                 dropout[0], dropout[1], dropout[2], _stream()), 'lime_layernorm_bwd_dropout_f32')
+        return dz, dgamma, dbeta, dzsum, dt
     check(lib.lime_layernorm_bwd_f32(_p(dy), _ld(dy), dy_div, dy_scale, _p(y), _ld(y), _p(gamma), _p(beta), _p(rstd), _p(dz), _ld(dz),
                                      M, E, _p(dgamma), _p(dbeta), _p(dzsum), 0, _p(ws), ws.numel(), _stream()),
           'lime_layernorm_bwd_f32')
@@ -1136,6 +1146,20 @@ def token_attention_bwd(q, k, v, dout, n_seq, S, n_head, head_dim, scale, head_s
                                            _p(ws), ws.numel() if ws is not None else 0, *(dropout or (0.0, 0, 0)),
                                            _p(_mask_u8(key_mask, 'key_mask')), _stream()), 'lime_token_attention_bwd_f32')
     return dqkv
+
+
+def dropout2(src, p, seed, site1, site2, out=None):
+    """dropout_site2(dropout_site1(src)) in one pass; ``out`` may be ``src``."""
+    lib = _lib.load()
+    _mat(src, 'src')
+    if out is None:
+        out = torch.empty(tuple(src.shape), dtype=torch.float32, device=src.device)
+    _mat(out, 'out')
+    if out.shape != src.shape:
+        raise ValueError('out must have the shape of src')
+    check(lib.lime_dropout2_f32(_p(src), _ld(src), _p(out), _ld(out), src.shape[0], src.shape[1], p, seed, site1, site2, _stream()),
+          'lime_dropout2_f32')
+    return out
 
 
 def dropout(src, p, seed, site, out=None):

@@ -318,9 +318,13 @@ class _TokenEncoder(torch.autograd.Function):
         keep_scale = 1.0 / (1.0 - p) if drop else 1.0
         dpooled = dpooled.contiguous()
         # norm2 <- mean pool: every token of a sequence receives dpooled / S
-        dz2, dn2_w, dn2_b, dl2_b = ops.layernorm_bwd(dpooled, y, n2_w, n2_b, rstd2, dy_div=S, dy_scale=1.0 / S, want_dzsum=not drop)
+        if drop:                                                                   # dt2: the branch through dropout2 into linear2, same pass
+            dz2, dn2_w, dn2_b, dl2_b, dt2 = ops.layernorm_bwd(dpooled, y, n2_w, n2_b, rstd2, dy_div=S, dy_scale=1.0 / S, want_dzsum=False,
+                                                             dropout=(p, seed, _SITE_DROP2))
+        else:
+            dz2, dn2_w, dn2_b, dl2_b = ops.layernorm_bwd(dpooled, y, n2_w, n2_b, rstd2, dy_div=S, dy_scale=1.0 / S)
+            dt2 = dz2
         del y
-        dt2 = ops.dropout(dz2, p, seed, _SITE_DROP2) if drop else dz2              # the branch through dropout2 into linear2
         if drop:
             dl2_w, dl2_b = ops.linear_wgrad(dt2, h, want_bias=True)
         else:
@@ -331,9 +335,12 @@ class _TokenEncoder(torch.autograd.Function):
         dl1_w, dl1_b = ops.linear_wgrad(dh, x1, want_bias=True)
         dx1 = ops.linear(dh, l1_w.t().contiguous(), None, res=dz2)                 # through linear1 + the residual branch
         del dh, dz2
-        dz1, dn1_w, dn1_b, dout_b = ops.layernorm_bwd(dx1, x1, n1_w, n1_b, rstd1, want_dzsum=not drop)
+        if drop:
+            dz1, dn1_w, dn1_b, dout_b, dt1 = ops.layernorm_bwd(dx1, x1, n1_w, n1_b, rstd1, want_dzsum=False, dropout=(p, seed, _SITE_DROP1))
+        else:
+            dz1, dn1_w, dn1_b, dout_b = ops.layernorm_bwd(dx1, x1, n1_w, n1_b, rstd1)
+            dt1 = dz1
         del dx1, x1
-        dt1 = ops.dropout(dz1, p, seed, _SITE_DROP1) if drop else dz1
         if drop:
             dout_w, dout_b = ops.linear_wgrad(dt1, ao, want_bias=True)
         else:
@@ -350,9 +357,8 @@ class _TokenEncoder(torch.autograd.Function):
         dx0 = ops.linear(dqkv, w_in.t().contiguous(), None, res=dz1)               # through in_proj + the residual branch
         dtable = None
         if ctx.needs_input_grad[6]:
-            if drop:                                                               # back through the two input dropouts
-                ops.dropout(dx0, p, seed, _SITE_PE, out=dx0)
-                ops.dropout(dx0, p, seed, _SITE_EMB, out=dx0)
+            if drop:                                                               # back through the two input dropouts, one pass
+                ops.dropout2(dx0, p, seed, _SITE_PE, _SITE_EMB, out=dx0)
             dtable = torch.zeros_like(table)
             ops.embed_bwd(flat, dx0, dtable, hot_id=0)
         return (None, None, None, None, None, None, dtable, None, din_w, din_b, dout_w, dout_b, dl1_w, dl1_b, dl2_w, dl2_b, dn1_w,
@@ -381,8 +387,7 @@ class _EmbedPE(torch.autograd.Function):
             return None, None, None, None, None
         dx0 = dx0.contiguous()
         if p > 0:                                                                  # back through the two input dropouts
-            dx0 = ops.dropout(dx0, p, seed, _SITE_PE)
-            ops.dropout(dx0, p, seed, _SITE_EMB, out=dx0)
+            dx0 = ops.dropout2(dx0, p, seed, _SITE_PE, _SITE_EMB)
         dtable = torch.zeros_like(table)
         ops.embed_bwd(flat, dx0, dtable, hot_id=0)
         return None, dtable, None, None, None
@@ -436,8 +441,12 @@ class _EncoderLayer(torch.autograd.Function):
         W = nhead * hs
         drop = p > 0
         keep_scale = 1.0 / (1.0 - p) if drop else 1.0
-        dz2, dn2_w, dn2_b, dl2_b = ops.layernorm_bwd(dy.contiguous(), y, n2_w, n2_b, rstd2, want_dzsum=not drop)
-        dt2 = ops.dropout(dz2, p, seed, _SITE_DROP2) if drop else dz2              # the branch through dropout2 into linear2
+        if drop:                                                                   # dt2: the branch through dropout2 into linear2, same pass
+            dz2, dn2_w, dn2_b, dl2_b, dt2 = ops.layernorm_bwd(dy.contiguous(), y, n2_w, n2_b, rstd2, want_dzsum=False,
+                                                             dropout=(p, seed, _SITE_DROP2))
+        else:
+            dz2, dn2_w, dn2_b, dl2_b = ops.layernorm_bwd(dy.contiguous(), y, n2_w, n2_b, rstd2)
+            dt2 = dz2
         if drop:
             dl2_w, dl2_b = ops.linear_wgrad(dt2, h, want_bias=True)
         else:
@@ -447,9 +456,12 @@ class _EncoderLayer(torch.autograd.Function):
         dl1_w, dl1_b = ops.linear_wgrad(dh, x1, want_bias=True)
         dx1 = ops.linear(dh, l1_w.t().contiguous(), None, res=dz2)                 # through linear1 + the residual branch
         del dh, dz2
-        dz1, dn1_w, dn1_b, dout_b = ops.layernorm_bwd(dx1, x1, n1_w, n1_b, rstd1, want_dzsum=not drop)
+        if drop:
+            dz1, dn1_w, dn1_b, dout_b, dt1 = ops.layernorm_bwd(dx1, x1, n1_w, n1_b, rstd1, want_dzsum=False, dropout=(p, seed, _SITE_DROP1))
+        else:
+            dz1, dn1_w, dn1_b, dout_b = ops.layernorm_bwd(dx1, x1, n1_w, n1_b, rstd1)
+            dt1 = dz1
         del dx1
-        dt1 = ops.dropout(dz1, p, seed, _SITE_DROP1) if drop else dz1
         if drop:
             dout_w, dout_b = ops.linear_wgrad(dt1, ao, want_bias=True)
         else:

@@ -144,3 +144,22 @@ def test_model_trains_with_the_reference_dropout_rate(case, probe):
     assert math.isfinite(l1) and torch.isfinite(g1).all() and float(g1.abs().max()) > 0
     assert l1 == l2 and torch.equal(g1, g2)
     assert l1 != l3 and not torch.equal(g1, g3)
+
+
+def test_fused_dropout_passes_equal_the_separate_ones():
+    """lime_layernorm_bwd_dropout_f32's second result and lime_dropout2_f32 are bit for bit what separate lime_dropout_f32 passes give."""
+    from lime_cikm25_amd import ops
+    g = torch.Generator().manual_seed(3)
+    M, E, p, seed = 5000, 300, 0.2, 1234567
+    dy = (torch.rand(M, E, generator=g) * 2 - 1).cuda()
+    z = (torch.rand(M, E, generator=g) * 2 - 1).cuda()
+    gamma, beta = (torch.rand(E, generator=g) + 0.5).cuda(), (torch.rand(E, generator=g) - 0.5).cuda()
+    y = torch.nn.functional.layer_norm(z, (E,), gamma, beta, 1e-5)
+    rstd = 1.0 / torch.sqrt(z.var(dim=1, unbiased=False) + 1e-5)
+    dz, dg, db, dzs = ops.layernorm_bwd(dy, y, gamma, beta, rstd)
+    dz2, dg2, db2, dzs2, dt = ops.layernorm_bwd(dy, y, gamma, beta, rstd, dropout=(p, seed, 5))
+    assert torch.equal(dz, dz2) and torch.equal(dg, dg2) and torch.equal(db, db2) and torch.equal(dzs, dzs2)
+    assert torch.equal(dt, ops.dropout(dz, p, seed, 5))
+    assert 0.15 < float((dt == 0).float().mean()) < 0.25
+    x = (torch.rand(M, E, generator=g) * 2 - 1).cuda()
+    assert torch.equal(ops.dropout2(x, p, seed, 1, 0), ops.dropout(ops.dropout(x, p, seed, 1), p, seed, 0))
