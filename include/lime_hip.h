@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LIME_ABI_VERSION 6
+#define LIME_ABI_VERSION 7
 
 typedef enum {
     LIME_OK = 0,
@@ -102,6 +102,11 @@ typedef struct {
     float act_scale;      /* LIME_ACT_RELU_GRAD only: the factor on the passed gradient (1 / (1 - p) when the forward ReLU output went
                              through dropout in place: h > 0 <=> ReLU passed AND the mask kept); dH = dY W2 with the ReLU gradient of
                              linear1 applied in the epilogue (trainer.py:145 through newsEncoders.py:244-247).  res = h, dense rows. */
+    float dropout_p;      /* > 0 (act none or ReLU, no residual / LayerNorm / pool32): v = keep(r * N + n) ? v / (1 - p) : 0 behind the activation,
+                             the counter-based mask of (dropout_seed, dropout_site) as lime_dropout_f32 draws it over the [M, N] result --
+                             nn.TransformerEncoderLayer's dropout behind linear1's ReLU in training mode (newsEncoders.py:244-247) */
+    uint64_t dropout_seed;
+    uint32_t dropout_site;
 } lime_linear_args;
 
 int lime_linear_f32(const lime_linear_args* args, void* stream);

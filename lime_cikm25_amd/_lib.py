@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_ui
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'liblime_hip.so')
 
-ABI_VERSION = 6          # LIME_ABI_VERSION of include/lime_hip.h this binding was written against
+ABI_VERSION = 7          # LIME_ABI_VERSION of include/lime_hip.h this binding was written against
 LIME_ACT = {None: 0, 'none': 0, 'relu': 1, 'tanh': 2, 'sigmoid': 3, 'relu_grad': 4}
 
 
@@ -31,6 +31,7 @@ class LinearArgs(Structure):
         ('ln_rstd', c_void_p),
         ('m_dev', c_void_p), ('c_ids', c_void_p),
         ('act_scale', c_float),
+        ('dropout_p', c_float), ('dropout_seed', c_uint64), ('dropout_site', c_uint32),
     ]
 
 

@@ -597,6 +597,8 @@ inline bool aligned(const void* ptr, long ld, int vec) {
 
 extern "C" int lime_relu_bwd_f32(float* dh, int64_t lddh, const float* h, int64_t ldh, int64_t rows, int32_t cols, float scale,
                                  void* stream);          // backward_f32.hip
+extern "C" int lime_dropout_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int32_t cols, float p, uint64_t seed,
+                                uint32_t site, void* stream);           // dropout_f32.hip
 
 extern "C" int lime_linear_f32(const lime_linear_args* a, void* stream) {
     LIME_REQUIRE(a != nullptr, LIME_ERR_BAD_ARG, "lime_linear_f32: args is NULL");
@@ -629,6 +631,19 @@ extern "C" int lime_linear_f32(const lime_linear_args* a, void* stream) {
         const int st = lime_linear_f32(&plain, stream);
         if (st != LIME_OK) return st;
         return lime_relu_bwd_f32(a->c, a->ldc, a->res, a->ldr, a->M, a->N, a->act_scale, stream);
+    }
+
+    if (a->dropout_p != 0.f) {                        // dropout behind the activation: fused in the split-product ReLU kernel, else a pass of its own
+        LIME_REQUIRE(a->dropout_p > 0.f && a->dropout_p < 1.f, LIME_ERR_BAD_ARG, "lime_linear_f32: dropout_p outside [0, 1)");
+        LIME_REQUIRE((a->act == LIME_ACT_NONE || a->act == LIME_ACT_RELU) && !a->res && !a->ln_gamma && !a->pool32 && !a->c_ids && !a->m_dev,
+                     LIME_ERR_BAD_ARG, "lime_linear_f32: dropout_p goes with act none / ReLU and no other epilogue");
+        const int sp = lime_linear_sp(a, (hipStream_t)stream);
+        if (sp != LIME_PP_NOT_APPLICABLE) return sp;
+        lime_linear_args plain = *a;
+        plain.dropout_p = 0.f;
+        const int st = lime_linear_f32(&plain, stream);
+        if (st != LIME_OK) return st;
+        return lime_dropout_f32(a->c, a->ldc, a->c, a->ldc, a->M, a->N, a->dropout_p, a->dropout_seed, a->dropout_site, stream);
     }
 
     // big M, 16-byte friendly operands: two four-wave workgroups per CU with LDS-DMA staging (gemm_pp_f32.hip)

@@ -2,6 +2,7 @@
 // kernel (gemm_pp_f32.hip).
 #pragma once
 #include "common.h"
+#include "dropout.h"
 
 #define LIME_PP_NOT_APPLICABLE 1
 
@@ -18,6 +19,7 @@ struct PPParams {
     int act = 0;         // gemm_sp_kernel only, instantiations without the ReLU template flag: LIME_ACT_TANH / LIME_ACT_SIGMOID at run time
     int res_div = 1;     // gemm_sp_kernel only (RES == 1 without res_mod): residual row = r / res_div (one row broadcast to res_div rows)
     float act_scale = 1.f;   // gemm_sp_kernel, RES == 3 (LIME_ACT_RELU_GRAD): v = res > 0 ? v * act_scale : 0
+    LimeDropout drop = {0, 0, 1.f};   // gemm_sp_kernel, ReLU instantiations without residual: thresh != 0 -> the dropout mask behind the ReLU
 #ifdef LIME_STAMPS
     unsigned long long* stamps;
 #endif

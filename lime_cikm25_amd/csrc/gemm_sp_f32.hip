@@ -354,6 +354,14 @@ __global__ __launch_bounds__(512, 2) void gemm_sp_kernel(const PPParams p) {
                 if constexpr (RELU) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                    if constexpr (!LN && RES == 0) {
+                        if (p.drop.thresh != 0) {      // nn.Dropout behind the ReLU (training mode): one hash per four consecutive columns
+                            const unsigned keep = lime_keep4(p.drop, ((uint64_t)(row0 + 64 * wr + 16 * i + fi) * (uint64_t)p.N +
+                                                                      (uint64_t)(col0 + cw0 + 16 * t + 4 * kg)) >> 2);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = (keep >> j) & 1u ? v[j] * p.drop.scale : 0.f;
+                        }
+                    }
                 } else if constexpr (!LN && RES != 1) {        // Attention.affine1 (tanh), gates (sigmoid): uniform run-time choice
                     if (p.act == LIME_ACT_TANH) {
 #pragma unroll
@@ -572,6 +580,7 @@ int lime_linear_sp(const lime_linear_args* a, hipStream_t s) {
     if (a->a_pe != nullptr) return LIME_PP_NOT_APPLICABLE;
     const bool act_rt = a->act == LIME_ACT_TANH || a->act == LIME_ACT_SIGMOID;       // applied at run time in the epilogue
     const bool relu_grad = a->act == LIME_ACT_RELU_GRAD;
+    if (a->dropout_p > 0.f && !(relu && !has_res && !ln && !a->pool32 && !a->c_ids)) return LIME_PP_NOT_APPLICABLE;
     if (relu_grad && (!has_res || ln || a->res_ids || a->res_mod > 0 || a->res_div > 1 || a->c_ids || a->pool32)) return LIME_PP_NOT_APPLICABLE;
     if (!(a->act == LIME_ACT_NONE || relu_grad || (relu && !has_res) || (act_rt && !ln && (!has_res || a->res_ids)))) return LIME_PP_NOT_APPLICABLE;
     if (a->K % 4 || a->N % 4 || a->K < 64) return LIME_PP_NOT_APPLICABLE;          // >= 2 chunks (row lists, bias image)
@@ -638,6 +647,7 @@ int lime_linear_sp(const lime_linear_args* a, hipStream_t s) {
     p.act = act_rt ? a->act : 0;
     p.res_div = (res == 1 && a->res_div > 1) ? a->res_div : 1;
     p.act_scale = a->act_scale;
+    if (a->dropout_p > 0.f) p.drop = lime_make_dropout(a->dropout_p, a->dropout_seed, a->dropout_site);
     {   // diagnostic: LIME_SP_MASK disables classes of instantiations (bit 0 c_ids, 1 LayerNorm + rstd, 2 LayerNorm, 3 residual,
         // 4 ReLU, 5 plain; bit 6: the 256-column tiles)
         static const int mask = getenv("LIME_SP_MASK") ? atoi(getenv("LIME_SP_MASK")) : 0;

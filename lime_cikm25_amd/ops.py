@@ -69,7 +69,7 @@ def set_split_gemm(on, force=False):
 
 def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=0, res=None, res_div=1, res_ids=None,
            res_pe=None, res_period=0, ln=None, ln_eps=1e-5, res_mod=0, pool32=False, ln_rstd=None, n_alg=None, m_dev=None,
-           c_ids=None, act_scale=1.0, _build_only=False):
+           c_ids=None, act_scale=1.0, dropout=None, _build_only=False):
     """C = epilogue(A . W^T + bias) -- see ``lime_linear_f32`` in include/lime_hip.h.
 
     n_alg: the number of USEFUL output columns when w carries zero padding rows (in_proj with heads padded to 32 columns:
@@ -148,6 +148,8 @@ def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=
     args.M, args.N, args.K = M, N, K
     args.act = LIME_ACT[act]
     args.act_scale = act_scale
+    if dropout is not None and dropout[0] > 0:          # (p, seed, site): nn.Dropout behind the activation, counter-based mask
+        args.dropout_p, args.dropout_seed, args.dropout_site = dropout
     if ln is not None and M >= 4096 and not _SLOW_LN_WARNED and not _friendly16(a, w, out, res):
         # the LayerNorm epilogue of a big problem whose operands are not 16-byte friendly runs on the general kernel's 5-tile-wide
         # instantiation (256 registers in scratch, a tenth of the LDS-DMA kernels' rate): say so once instead of being silently slow

@@ -288,8 +288,7 @@ class _TokenEncoder(torch.autograd.Function):
             ao = ops.token_attention_dropout(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, scale, p, seed, _SITE_ATTN,
                                              head_stride=hs)
             x1, rstd1 = ops.dropout_add_layernorm(ops.linear(ao, out_w, out_b), x0, n1_w, n1_b, eps1, p, seed, _SITE_DROP1)
-            h = ops.linear(x1, l1_w, l1_b, act='relu')
-            ops.dropout(h, p, seed, _SITE_FF, out=h)
+            h = ops.linear(x1, l1_w, l1_b, act='relu', dropout=(p, seed, _SITE_FF))     # the dropout behind the ReLU in the GEMM's epilogue
             y, rstd2 = ops.dropout_add_layernorm(ops.linear(h, l2_w, l2_b), x1, n2_w, n2_b, eps2, p, seed, _SITE_DROP2)
         else:
             pew = ops.linear(pe[:S], w_in, b_in)
@@ -418,8 +417,7 @@ class _EncoderLayer(torch.autograd.Function):
             ao = ops.token_attention_dropout(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, scale, p, seed, _SITE_ATTN,
                                              head_stride=hs)
             x1, rstd1 = ops.dropout_add_layernorm(ops.linear(ao, out_w, out_b), x, n1_w, n1_b, eps1, p, seed, _SITE_DROP1)
-            h = ops.linear(x1, l1_w, l1_b, act='relu')
-            ops.dropout(h, p, seed, _SITE_FF, out=h)
+            h = ops.linear(x1, l1_w, l1_b, act='relu', dropout=(p, seed, _SITE_FF))     # the dropout behind the ReLU in the GEMM's epilogue
             y, rstd2 = ops.dropout_add_layernorm(ops.linear(h, l2_w, l2_b), x1, n2_w, n2_b, eps2, p, seed, _SITE_DROP2)
         else:
             lse = torch.empty(tok * nhead, dtype=torch.float32, device=dev) if S > 128 else None

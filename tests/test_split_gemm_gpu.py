@@ -371,3 +371,18 @@ def test_relu_grad_epilogue(ops, M, N, K, scale):
     assert torch.equal(got == 0, (h <= 0) | (got == 0))                  # gated entries are exact zeros
     two = ops.relu_bwd_(ops.linear(dev(dy), dev(w), None), dev(h), scale).cpu()
     assert rel_err(got.double().numpy(), two.double().numpy()) <= 2e-6
+
+
+@pytest.mark.parametrize('M,N,K', [(5000, 512, 300), (300, 512, 300), (4500, 300, 64)])
+def test_relu_dropout_epilogue(ops, M, N, K):
+    """dropout_p of lime_linear_args: nn.Dropout behind linear1's ReLU (newsEncoders.py:244-247, training mode) in the GEMM's epilogue --
+    the same values as the GEMM followed by lime_dropout_f32 with the same (p, seed, site), fused (split kernel, M >= 4096) or not."""
+    a, w, b = dev(rnd(M, K, seed=1)), dev(rnd(N, K, seed=2, scale=0.2)), dev(rnd(N, seed=3))
+    p, seed, site = 0.2, 987654321, 3
+    got = ops.linear(a, w, b, act='relu', dropout=(p, seed, site))
+    fused = last_kernel().startswith('gemm_sp_kernel')
+    assert fused == (M >= 4096), last_kernel()
+    want = ops.dropout(ops.linear(a, w, b, act='relu'), p, seed, site)
+    assert torch.equal(got, want)
+    frac = float((got == 0).float().mean())
+    assert 0.5 < frac < 0.75                              # about half from the ReLU, a fifth of the rest from the mask
