@@ -2062,6 +2062,10 @@ extern "C" int lime_token_attention_dropout_f32(const float* q, const float* k, 
     if (n_seq == 0) return LIME_OK;
     const LimeDropout drop = lime_make_dropout(dropout_p, seed, site);
     hipStream_t s = (hipStream_t)stream;
+    if (head_stride == 32 && (S == 32 || S == 64 || S == 128)) {       // the split-product forward with the mask on its probability registers
+        const int st = lime_token_attention_sp(q, k, v, (long)ld_qkv, nullptr, nullptr, out, (long)ldo, n_seq, S, n_head, head_dim, scale, nullptr, s, &drop);
+        if (st != LIME_PP_NOT_APPLICABLE) return st;
+    }
     if (S <= 32) return launch_attn_fwd_dropout<32>(q, k, v, ld_qkv, out, ldo, n_seq, S, n_head, head_dim, head_stride, scale, drop, s);
     if (S <= 64) return launch_attn_fwd_dropout<64>(q, k, v, ld_qkv, out, ldo, n_seq, S, n_head, head_dim, head_stride, scale, drop, s);
     if (S <= 128) return launch_attn_fwd_dropout<128>(q, k, v, ld_qkv, out, ldo, n_seq, S, n_head, head_dim, head_stride, scale, drop, s);

@@ -38,4 +38,5 @@ int lime_wgrad_sp_reduce_t(const LimeWgradSpPlan& w, const float* ws, float* dw,
 int lime_split_mode();                                                   // gemm_sp_f32.hip: the lime_set_split_gemm() setting
 // token_attn_sp_f32.hip: unmasked S = 32 / 64 / 128 attention on the split product (LIME_PP_NOT_APPLICABLE: not taken)
 int lime_token_attention_sp(const float* q, const float* k, const float* v, long ld, const int* row_map, const int* n_seq_dev,
-                            float* out, long ldo, int n_seq, int S, int n_head, int hd, float scale, float* lse, hipStream_t s);
+                            float* out, long ldo, int n_seq, int S, int n_head, int hd, float scale, float* lse, hipStream_t s,
+                            const LimeDropout* drop = nullptr);

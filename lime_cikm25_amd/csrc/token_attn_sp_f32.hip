@@ -17,6 +17,7 @@
 #include "gemm_pp.h"
 #include "lds_dma.h"
 #include "split_mfma.h"
+#include "dropout.h"
 
 using namespace lime_dev;
 
@@ -30,6 +31,7 @@ struct SpAttnP {
     const float* q; const float* k; const float* v; long ld;
     float* out; long ldo; int n_seq, S, n_head, hd; float scale; int n_pair, n_group;
     const int* row_map; const int* n_seq_dev;
+    LimeDropout drop;    // thresh != 0 (the S <= 128 kernel): attention-probability dropout, element (pair, query, key) of the mask
 };
 
 using Split = SplitFrag;                            // split_mfma.h
@@ -197,6 +199,20 @@ __global__ __launch_bounds__(256, 2) void token_attn_sp_kernel(const SpAttnP p) 
             }
             sum += __shfl_xor(sum, 32);
             const float inv = 1.0f / sum;
+            if (p.drop.thresh != 0) {
+                // nn.MultiheadAttention's dropout on the probabilities (newsEncoders.py:244-247, training mode): keep / (1 - p) goes
+                // onto the unnormalised e (the sum above is over all of them).  Registers 4 g .. 4 g + 3 of a tile are four consecutive
+                // keys: one hash each, element index (pair S + query) S + key as the backward regenerates it.
+                const uint64_t mrow = ((uint64_t)pair * (uint64_t)S + (uint64_t)(qt * 32 + fi)) * (uint64_t)S;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const unsigned keep = lime_keep4(p.drop, (mrow + (uint64_t)(32 * t + 8 * gq + krow)) >> 2);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sc[t][4 * gq + e] = (keep >> e) & 1u ? sc[t][4 * gq + e] * p.drop.scale : 0.f;
+                    }
+            }
             // ---- O^T = V^T P^T: registers 8 s .. 8 s + 7 of a probability tile are the B operand of step s ----------------
             f32x16 o;
 #pragma unroll
@@ -424,13 +440,15 @@ int launch(SpAttnP p, hipStream_t s) {
 // LIME_OK / error: launched; LIME_PP_NOT_APPLICABLE: the caller takes token_attn_f32.hip's kernels (masks, other lengths, unpadded
 // heads, the split product switched off).  lse (optional, S = 256 / 512 only): [tokens, n_head] log2-domain log-sum-exp.
 int lime_token_attention_sp(const float* q, const float* k, const float* v, long ld, const int* row_map, const int* n_seq_dev,
-                            float* out, long ldo, int n_seq, int S, int n_head, int hd, float scale, float* lse, hipStream_t s) {
+                            float* out, long ldo, int n_seq, int S, int n_head, int hd, float scale, float* lse, hipStream_t s,
+                            const LimeDropout* drop) {
     if (!(lime_split_mode() & 1)) return LIME_PP_NOT_APPLICABLE;
     const bool is_long = S == 256 || S == 512;
     if (!(S == 32 || S == 64 || S == 128 || is_long)) return LIME_PP_NOT_APPLICABLE;
     if (lse && !is_long) return LIME_PP_NOT_APPLICABLE;
+    if (drop && drop->thresh != 0 && (is_long || row_map)) return LIME_PP_NOT_APPLICABLE;       // probability dropout: the S <= 128 kernel only
     if (ld % 4 != 0 || ld < (long)n_head * 32 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16) != 0 || hd > 32) return LIME_PP_NOT_APPLICABLE;
-    SpAttnP p{q, k, v, ld, out, ldo, n_seq, S, n_head, hd, scale, n_seq * n_head, 0, row_map, n_seq_dev};
+    SpAttnP p{q, k, v, ld, out, ldo, n_seq, S, n_head, hd, scale, n_seq * n_head, 0, row_map, n_seq_dev, drop ? *drop : LimeDropout{0, 0, 1.f}};
     if (is_long) {
         const long n_task = (long)p.n_pair * (S / 128);
         long blocks = (long)sp_attn_cus() * 2;
