@@ -396,6 +396,10 @@ int lime_intent_fuse_f32(const float* intents, const float* att_hidden, const fl
  */
 int lime_additive_pool_f32(const float* hidden, int64_t ldh, const float* affine2, int32_t A, const float* x, int64_t ldx,
                            int32_t D, const uint8_t* mask, float* out, int64_t ldo, int32_t n_seq, int32_t S, void* stream);
+/* the same with an optional device-side sequence count: sequences >= min(*n_seq_dev, n_seq) are skipped, their output rows untouched (the
+ * compacted batch of newsEncoders.MHSA: the rows behind the live sequences hold stale data) */
+int lime_additive_pool_count_f32(const float* hidden, int64_t ldh, const float* affine2, int32_t A, const float* x, int64_t ldx, int32_t D,
+                                 const uint8_t* mask, const int32_t* n_seq_dev, float* out, int64_t ldo, int32_t n_seq, int32_t S, void* stream);
 
 /*
  * lime_cand_attn_weights_f32: the attention-weight part of CandidateAware_ClickedNewsAttention.forward

@@ -152,6 +152,8 @@ SIGNATURES = {
                                        c_int32, c_void_p]),
     'lime_additive_pool_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p,
                                          c_void_p, c_int64, c_int32, c_int32, c_void_p]),
+    'lime_additive_pool_count_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p,
+                                               c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     'lime_cand_attn_weights_workspace': (c_int64, [c_int32, c_int32, c_int32, c_int32]),
     'lime_cand_attn_weights_ws_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                                 c_int64, c_void_p]),

@@ -289,10 +289,12 @@ __global__ __launch_bounds__(256) void intent_fuse_kernel(const float* __restric
 __global__ __launch_bounds__(256) void additive_pool_kernel(const float* __restrict__ hidden, long ldh,
                                                              const float* __restrict__ aff2, int A, const float* __restrict__ x,
                                                              long ldx, int D, const unsigned char* __restrict__ mask,
-                                                             float* __restrict__ out, long ldo, int S) {
+                                                             float* __restrict__ out, long ldo, int S, const int* __restrict__ n_seq_dev) {
     __shared__ float alpha[512];
     __shared__ float red[4];
     const long s = blockIdx.x;
+    // a compacted batch: only min(*n_seq_dev, grid) sequences are live (the rows behind them hold stale data: 100 MB of reads at config 2)
+    if (n_seq_dev != nullptr && (int)blockIdx.x >= *n_seq_dev) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int t = wave; t < S; t += 4) {
         const float* h = hidden + (s * S + t) * ldh;
@@ -1219,16 +1221,26 @@ extern "C" int lime_intent_fuse_f32(const float* intents, const float* att_hidde
     return lime_check_launch("lime_intent_fuse_f32");
 }
 
+extern "C" int lime_additive_pool_count_f32(const float* hidden, int64_t ldh, const float* affine2, int32_t A, const float* x,
+                                            int64_t ldx, int32_t D, const uint8_t* mask, const int32_t* n_seq_dev, float* out, int64_t ldo,
+                                            int32_t n_seq, int32_t S, void* stream);
+
 extern "C" int lime_additive_pool_f32(const float* hidden, int64_t ldh, const float* affine2, int32_t A, const float* x,
                                       int64_t ldx, int32_t D, const uint8_t* mask, float* out, int64_t ldo, int32_t n_seq,
                                       int32_t S, void* stream) {
+    return lime_additive_pool_count_f32(hidden, ldh, affine2, A, x, ldx, D, mask, nullptr, out, ldo, n_seq, S, stream);
+}
+
+extern "C" int lime_additive_pool_count_f32(const float* hidden, int64_t ldh, const float* affine2, int32_t A, const float* x,
+                                            int64_t ldx, int32_t D, const uint8_t* mask, const int32_t* n_seq_dev, float* out, int64_t ldo,
+                                            int32_t n_seq, int32_t S, void* stream) {
     LIME_REQUIRE(hidden && affine2 && x && out, LIME_ERR_BAD_ARG, "lime_additive_pool_f32: NULL pointer");
     LIME_REQUIRE(n_seq >= 0 && S > 0 && A > 0 && D > 0 && ldh >= A && ldx >= D && ldo >= D, LIME_ERR_BAD_ARG,
                  "lime_additive_pool_f32: bad dims");
     LIME_REQUIRE(S <= 512, LIME_ERR_UNSUPPORTED, "lime_additive_pool_f32: S %d > 512", S);
     if (n_seq == 0) return LIME_OK;
     hipLaunchKernelGGL(additive_pool_kernel, dim3((unsigned)n_seq), dim3(256), 0, (hipStream_t)stream, hidden, (long)ldh, affine2, A,
-                       x, (long)ldx, D, mask, out, (long)ldo, S);
+                       x, (long)ldx, D, mask, out, (long)ldo, S, n_seq_dev);
     return lime_check_launch("lime_additive_pool_f32");
 }
 

@@ -980,7 +980,7 @@ class MHSA(NewsEncoder):
         qkv = mha.project(table=self.word_embedding.weight, ids=ids_c, m_dev=cmp.n_rows)
         c = mha.attend(qkv, n + 1, T, mask_c, n_seq_dev=cmp.n_compact)
         hidden = ops.linear(c, self.attention.affine1.weight, self.attention.affine1.bias, act='tanh', m_dev=cmp.n_rows)
-        pooled_c = ops.additive_pool(hidden, self.attention.affine2.weight.view(-1), c, n + 1, T, mask=mask_c)
+        pooled_c = ops.additive_pool(hidden, self.attention.affine2.weight.view(-1), c, n + 1, T, mask=mask_c, n_seq_dev=cmp.n_compact)
         ops.gather_rows(cmp.seq_inv, pooled_c, out)
 
     def _compact_applicable(self, ids, n, T):

@@ -455,7 +455,9 @@ def intent_fuse(intents, att_hidden, affine2_t, affine2_b, content, M, k, D, A):
     return content
 
 
-def additive_pool(hidden, affine2, x, n_seq, S, mask=None, out=None):
+def additive_pool(hidden, affine2, x, n_seq, S, mask=None, out=None, n_seq_dev=None):
+    """layers.Attention over the S tokens of each sequence (layers.py:285-300).  ``n_seq_dev`` (int32 device tensor, 1 element): only
+    that many sequences are pooled (a compacted batch), the other output rows are left alone."""
     lib = _lib.load()
     _mat(hidden, 'hidden')
     _mat(x, 'x')
@@ -466,8 +468,10 @@ def additive_pool(hidden, affine2, x, n_seq, S, mask=None, out=None):
         out = torch.empty((n_seq, D), dtype=torch.float32, device=x.device)
     _mat(out, 'out')
     m = _mask_u8(mask, 'mask')
-    check(lib.lime_additive_pool_f32(_p(hidden), _ld(hidden), _p(_vec(affine2, 'affine2', A)), A, _p(x), _ld(x), D, _p(m),
-                                     _p(out), _ld(out), n_seq, S, _stream()), 'lime_additive_pool_f32')
+    if n_seq_dev is not None:
+        _vec(n_seq_dev, 'n_seq_dev', 1, dtype=torch.int32)
+    check(lib.lime_additive_pool_count_f32(_p(hidden), _ld(hidden), _p(_vec(affine2, 'affine2', A)), A, _p(x), _ld(x), D, _p(m),
+                                           _p(n_seq_dev), _p(out), _ld(out), n_seq, S, _stream()), 'lime_additive_pool_f32')
     return out
 
 
