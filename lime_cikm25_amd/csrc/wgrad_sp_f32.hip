@@ -174,7 +174,15 @@ __global__ __launch_bounds__(256) void reduce_partials_t_kernel(const float* __r
         const int k = (int)(e / rows), n = (int)(e - (long)k * rows);
         const float* p = ws + (long)k * ldw + n;
         float t = 0.f;
-        for (int s = 0; s < splits; ++s) t += p[(long)s * split_stride];
+        int s = 0;
+        for (; s + 8 <= splits; s += 8) {                  // eight independent loads in flight, summed in split order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(long)(s + u) * split_stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+        }
+        for (; s < splits; ++s) t += p[(long)s * split_stride];
         float* const q = out + (long)n * ldo + k;
         *q = accumulate ? *q + t : t;
     }
