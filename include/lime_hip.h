@@ -129,7 +129,8 @@ const char* lime_last_linear_kernel(void);
  *                exponent range, 2.7x the fp32 matrix rate;
  *   0          : csrc/gemm_pp_f32.hip -- v_mfma_f32_16x16x4_f32 (an fp32 fma chain).
  *   1 | 2      : as 1, and also the gathered-residual LayerNorm GEMM (out_proj), which is slower there and stays on the fp32 kernel by default;
- *   1 | 4      : as 1, without the rules that leave badly filling launches (few 256-row tiles) to the 128- / 64-row tile kernels (tests, A/B runs).
+ *   1 | 4      : as 1, without the rules that leave badly filling launches (few 256-row tiles) to the 128- / 64-row tile kernels (tests, A/B runs);
+ *   4          : as 0, without the rule that hands big-M problems with few 128-row tiles to the 64-row-tile kernel (tests).
  * Process-wide; returns the previous setting; any other argument only queries.  LIME_SPLIT_GEMM=0 in the environment sets the start value. */
 int lime_set_split_gemm(int on);
 

@@ -646,6 +646,14 @@ extern "C" int lime_linear_f32(const lime_linear_args* a, void* stream) {
         return lime_dropout_f32(a->c, a->ldc, a->c, a->ldc, a->M, a->N, a->dropout_p, a->dropout_seed, a->dropout_site, stream);
     }
 
+    // 4096 <= M with few 128-row tiles (M = 6400, N = 400: 100 tiles on 512 workgroup slots took 60 us on the big-M kernel, 32 us in
+    // 64 x 64 tiles): the mid-M kernel first, for the problems it takes (no LayerNorm / pooling / scatter)
+    if (a->M >= 4096 && !a->ln_gamma && !a->pool32 && !a->c_ids && !a->a_pe && !(lime_split_mode() & 4) &&       // (bit 2: tests pin kernels)
+        (((long)a->M + 127) / 128) * (((long)a->N + 255) / 256) < 160) {
+        const int st = lime_linear_mid(a, (hipStream_t)stream);
+        if (st != LIME_PP_NOT_APPLICABLE) return st;
+    }
+
     // big M, 16-byte friendly operands: two four-wave workgroups per CU with LDS-DMA staging (gemm_pp_f32.hip)
     static const bool pp_off = getenv("LIME_GEMM_NO_PP") != nullptr;          // A/B switch for tools/, not a product option
     if (!pp_off || a->pool32) {

@@ -63,8 +63,9 @@ def _mask_u8(mask, name):
 def set_split_gemm(on, force=False):
     """Route the big lime_linear_f32 problems through the split-product kernel (True, the default: fp32-level products on the bf16
     matrix cores, csrc/gemm_sp_f32.hip) or the fp32-MFMA kernels (False).  ``force``: also the launches the dispatcher leaves to the
-    other kernels because few 256-row tiles would fill the chip badly (tests).  Returns the previous setting (True / False)."""
-    return bool(_lib.load().lime_set_split_gemm((5 if force else 1) if on else 0) & 1)
+    other kernels because few 256-row tiles would fill the chip badly, and -- with ``on`` False -- the big-M fp32 kernel for problems the
+    dispatcher gives to the 64-row-tile kernel for the same reason (tests).  Returns the previous setting (True / False)."""
+    return bool(_lib.load().lime_set_split_gemm((5 if force else 1) if on else (4 if force else 0)) & 1)
 
 
 def linear(a, w, bias=None, act=None, out=None, a_ids=None, a_pe=None, a_period=0, res=None, res_div=1, res_ids=None,

@@ -29,7 +29,7 @@ def ops():
 def _fp32_mfma_kernels(ops):
     """This module pins the fp32-MFMA GEMM kernels (gemm_pp / gemm_mid / gemm_f32) by name; the split-product kernel that takes the
     big problems by default has its own module (test_split_gemm_gpu.py)."""
-    prev = ops.set_split_gemm(False)
+    prev = ops.set_split_gemm(False, force=True)       # force: also the problems the fill rules would hand to the 64-row-tile kernel
     yield
     ops.set_split_gemm(prev)
 

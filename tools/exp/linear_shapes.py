@@ -7,6 +7,8 @@ import bench
 from lime_cikm25_amd import ops, newsEncoders
 
 name = sys.argv[1] if len(sys.argv) > 1 else 'cfg3'
+if name.startswith('B'):                              # e.g. B128: the config-2b shape at another batch size
+    bench.WORKLOADS[name] = (dict(batch_size=max(int(name[1:]), 64)), int(name[1:]), 5, 'batch sweep')
 run = bench.Run(name, 0, 1)
 run.step(); run.step()
 prof = []
