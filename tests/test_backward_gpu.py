@@ -171,11 +171,14 @@ def _attention_bwd_case(ops, n_seq, S, nh, hd, hs):
         assert (dqkv.view(tok, 3, nh, hs)[..., hd:] == 0).all(), 'pad columns must be exact zeros'
 
 
-def test_embed_bwd(ops):
-    V, D, rows = 500, 300, 20000
+@pytest.mark.parametrize('rows,first', [(20000, 0), (60000, 0), (60000, 7), (9000, 0)])
+def test_embed_bwd(ops, rows, first):
+    """40 % of the positions carry one id (the padding word in the model; `first` = 7: some other smallest id): above 8192 of them the
+    sorted back end sums that run in its own pass (256 slices + an ordered sum), below it in the chunk passes."""
+    V, D = 500, 300
     g = torch.Generator().manual_seed(3)
-    ids = torch.randint(1, V, (rows,), generator=g, dtype=torch.int32)
-    ids[torch.rand(rows, generator=g) < 0.4] = 0                  # the padding word dominates
+    ids = torch.randint(first + 1, V, (rows,), generator=g, dtype=torch.int32)
+    ids[torch.rand(rows, generator=g) < 0.4] = first              # the padding word dominates
     dx = rnd(rows, D, seed=4)
     want = torch.zeros(V, D, dtype=torch.float64).index_add_(0, ids.long(), dx.double()).float()
     got = ops.embed_bwd(ids.cuda(), dx.cuda(), torch.zeros(V, D, device='cuda'), hot_id=0)
