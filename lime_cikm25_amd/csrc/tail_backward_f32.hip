@@ -24,20 +24,32 @@ __device__ __forceinline__ float bsum(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-// out[c] (+)= sum_s part[s * stride + c].  A workgroup owns 64 columns; its four waves take the splits s = wave, wave + 4, ...
-// (coalesced 256-byte reads) and the four sums are added in a fixed order.
-__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ part, long stride, int splits, float* __restrict__ out,
-                                                           int cols, int accumulate) {
-    __shared__ float red[4][64];
+// out[c] (+)= sum_s part[s * stride + c].  A workgroup owns 64 columns; its sixteen waves take the splits s = wave, wave + 16, ...
+// (coalesced 256-byte reads; with four waves a 768-split sum was 192 loads per lane: 18 us, five of them per training step) and the
+// sixteen sums are added in a fixed order.
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(const float* __restrict__ part, long stride, int splits, float* __restrict__ out,
+                                                            int cols, int accumulate) {
+    __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    if (c < cols)
-        for (int i = g; i < splits; i += 4) s += part[(long)i * stride + c];
+    if (c < cols) {
+        int i = g;
+        for (; i + 112 < splits; i += 128) {               // eight loads in flight, added in split order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(long)(i + 16 * u) * stride + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; i < splits; i += 16) s += part[(long)i * stride + c];
+    }
     red[g][lane] = s;
     __syncthreads();
     if (g == 0 && c < cols) {
-        const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        float t = red[0][lane];
+#pragma unroll
+        for (int u = 1; u < 16; ++u) t += red[u][lane];
         out[c] = accumulate ? out[c] + t : t;
     }
 }
@@ -524,7 +536,10 @@ __global__ __launch_bounds__(256) void sum_candidates_kernel(const float* __rest
     }
 }
 
-int persistent_grid(long rows) { return (int)(rows < 256 ? (rows < 1 ? 1 : rows) : 256); }
+// workgroups of the row-walking backward kernels: three per CU (with one per CU the 1760 news rows of a config-2b step were seven rows
+// per workgroup, one latency chain of ~17 us each, back to back: 121 us; one row per workgroup makes the partial-row sums behind them --
+// reduce_rows_kernel over as many rows -- cost more than it saves)
+int persistent_grid(long rows) { return (int)(rows < 768 ? (rows < 1 ? 1 : rows) : 768); }
 
 // Backward of additive_pool_kernel (small_ops.hip; layers.Attention over the tokens of a title, layers.py:285-300 as called at
 // newsEncoders.py:591-592): one workgroup per sequence recomputes alpha = softmax_t(mask(hidden_t . a2)), then
@@ -615,8 +630,8 @@ extern "C" int lime_intent_fuse_bwd_f32(const float* intents, const float* hidde
                                                                          d_hidden, workspace, M, k, D, A);
     int st = lime_check_launch("intent_fuse_bwd_kernel");
     if (st != LIME_OK) return st;
-    reduce_rows_kernel<<<(A + 63) / 64, 256, 0, s>>>(workspace, 2L * A, grid, d_aff2_title, A, 0);
-    reduce_rows_kernel<<<(A + 63) / 64, 256, 0, s>>>(workspace + A, 2L * A, grid, d_aff2_body, A, 0);
+    reduce_rows_kernel<<<(A + 63) / 64, 1024, 0, s>>>(workspace, 2L * A, grid, d_aff2_title, A, 0);
+    reduce_rows_kernel<<<(A + 63) / 64, 1024, 0, s>>>(workspace + A, 2L * A, grid, d_aff2_body, A, 0);
     return lime_check_launch("reduce_rows_kernel");
 }
 
@@ -642,7 +657,7 @@ extern "C" int lime_gate_ln_bwd_f32(const float* y, const float* x, const float*
     int st = lime_check_launch("gate_ln_bwd_kernel");
     if (st != LIME_OK) return st;
     float* outs[3] = {dbias, dgamma, dbeta};
-    for (int i = 0; i < 3; ++i) reduce_rows_kernel<<<(D + 63) / 64, 256, 0, s>>>(workspace + (long)i * D, 3L * D, grid, outs[i], D, 0);
+    for (int i = 0; i < 3; ++i) reduce_rows_kernel<<<(D + 63) / 64, 1024, 0, s>>>(workspace + (long)i * D, 3L * D, grid, outs[i], D, 0);
     return lime_check_launch("reduce_rows_kernel");
 }
 
