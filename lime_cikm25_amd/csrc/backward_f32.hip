@@ -72,12 +72,14 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 // The same with four consecutive outputs per lane (16-byte accesses; cols % 4 == 0 so a group never leaves its row) and four
 // splits of a wave in flight: the scalar version reads 256 B per wave and load, 0.7 TB/s on the 39 MB of in_proj's 32 partial
 // tiles.  Same association as above (a wave sums its splits in order, the four waves' sums are added pairwise): same bits.
+// `extra` (optional): column `cols` of the partial grid also holds a sum -- the ones column's bias gradient -- and goes to extra[r] in the
+// same launch (a second launch per weight gradient for N floats was 19 launches of 6 us per training step).
 __global__ __launch_bounds__(256) void reduce_partials_vec4_kernel(const float* __restrict__ ws, long split_stride, int splits,
                                                                     long ldw, float* __restrict__ out, long ldo, int rows, int cols,
-                                                                    int accumulate) {
+                                                                    int accumulate, float* __restrict__ extra) {
     __shared__ f32x4v red4[4][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int c4 = cols >> 2;
+    const int c4 = (cols >> 2) + (extra != nullptr ? 1 : 0);
     const long e = (long)blockIdx.x * 64 + lane;                 // group of four columns
     const bool ok = e < (long)rows * c4;
     const int r = ok ? (int)(e / c4) : 0, c = ok ? (int)(e - (long)r * c4) * 4 : 0;
@@ -98,8 +100,12 @@ __global__ __launch_bounds__(256) void reduce_partials_vec4_kernel(const float* 
     __syncthreads();
     if (g == 0 && ok) {
         const f32x4v t = (red4[0][lane] + red4[1][lane]) + (red4[2][lane] + red4[3][lane]);
-        f32x4v* o = reinterpret_cast<f32x4v*>(out + (long)r * ldo + c);
-        *o = accumulate ? *o + t : t;
+        if (c == cols) {                                   // the extra column (only with `extra`)
+            extra[r] = accumulate ? extra[r] + t[0] : t[0];
+        } else {
+            f32x4v* o = reinterpret_cast<f32x4v*>(out + (long)r * ldo + c);
+            *o = accumulate ? *o + t : t;
+        }
     }
 }
 
@@ -1708,13 +1714,19 @@ int launch_wgrad(const WgradPlan& w, const float* dy, long ldy, const float* x, 
     return lime_check_launch("wgrad_kernel");
 }
 
+// extra (optional): column `cols` of the partial grid summed into extra[rows] as well (the caller guarantees the grid has that column)
 int launch_reduce(const float* ws, long split_stride, int splits, long ldw, float* out, long ldo, int rows, int cols,
-                  int accumulate, hipStream_t s) {
+                  int accumulate, hipStream_t s, float* extra = nullptr) {
     const long total = (long)rows * cols;
     if (cols % 4 == 0 && ldw % 4 == 0 && ldo % 4 == 0 && split_stride % 4 == 0 && ((((uintptr_t)ws) | ((uintptr_t)out)) & 15) == 0) {
-        const int grid4 = (int)((total / 4 + 63) / 64);
-        reduce_partials_vec4_kernel<<<grid4, 256, 0, s>>>(ws, split_stride, splits, ldw, out, ldo, rows, cols, accumulate);
+        const long groups = (long)rows * (cols / 4 + (extra ? 1 : 0));
+        const int grid4 = (int)((groups + 63) / 64);
+        reduce_partials_vec4_kernel<<<grid4, 256, 0, s>>>(ws, split_stride, splits, ldw, out, ldo, rows, cols, accumulate, extra);
         return lime_check_launch("reduce_partials");
+    }
+    if (extra) {                                            // scalar layout: the extra column as a launch of its own
+        const int st = launch_reduce(ws, split_stride, splits, ldw, out, ldo, rows, cols, accumulate, s);
+        return st != LIME_OK ? st : launch_reduce(ws + cols, split_stride, splits, ldw, extra, 1, rows, 1, accumulate, s);
     }
     const int grid = (int)((total + 63) / 64);
     reduce_partials_kernel<<<grid, 256, 0, s>>>(ws, split_stride, splits, ldw, out, ldo, rows, cols, accumulate);
@@ -1775,9 +1787,8 @@ extern "C" int lime_linear_wgrad_f32(const float* dy, int64_t ldy, const float* 
         if (st != LIME_OK) return st;
         const int64_t used = (int64_t)sp.splits * sp.np * sp.kp;
         if (sp.swap) st = lime_wgrad_sp_reduce_t(sp, workspace, dw, lddw, N, K, accumulate, s);
-        else st = launch_reduce(workspace, sp.np * sp.kp, sp.splits, sp.kp, dw, lddw, N, K, accumulate, s);
-        if (st != LIME_OK || db == nullptr) return st;
-        if (ones) return launch_reduce(workspace + K, sp.np * sp.kp, sp.splits, sp.kp, db, 1, N, 1, accumulate, s);
+        else st = launch_reduce(workspace, sp.np * sp.kp, sp.splits, sp.kp, dw, lddw, N, K, accumulate, s, ones ? db : nullptr);
+        if (st != LIME_OK || db == nullptr || ones) return st;
         return lime_colsum_f32(dy, ldy, M, N, db, accumulate, workspace + used, workspace_floats - used, stream);
     }
     const int ones_col = (db != nullptr && K < w.kp) ? 1 : 0;          // room for a ones column in the padded tile grid
@@ -1787,10 +1798,8 @@ extern "C" int lime_linear_wgrad_f32(const float* dy, int64_t ldy, const float* 
     if (w.nkt == 5) st = WGRAD(5); else if (w.nkt == 3) st = WGRAD(3); else st = WGRAD(4);
 #undef WGRAD
     if (st != LIME_OK) return st;
-    st = launch_reduce(workspace, w.np * w.kp, w.splits, w.kp, dw, lddw, N, K, accumulate, s);
-    if (st != LIME_OK || db == nullptr) return st;
-    if (ones_col)                                                         // column K of the partial tiles
-        return launch_reduce(workspace + K, w.np * w.kp, w.splits, w.kp, db, 1, N, 1, accumulate, s);
+    st = launch_reduce(workspace, w.np * w.kp, w.splits, w.kp, dw, lddw, N, K, accumulate, s, ones_col ? db : nullptr);   // db: column K of the partial tiles
+    if (st != LIME_OK || db == nullptr || ones_col) return st;
     float* cws = workspace + (int64_t)w.splits * w.np * w.kp;             // K fills its tiles: a separate column-sum pass
     return lime_colsum_f32(dy, ldy, M, N, db, accumulate, cws, workspace_floats - (int64_t)w.splits * w.np * w.kp, stream);
 }
