@@ -326,6 +326,12 @@ int lime_token_attention_rows_f32(const float* q, const float* k, const float* v
  */
 int lime_compact_sequences(const int32_t* ids, int32_t n_seq, int32_t S, int32_t pad_base, int32_t* seq_inv, int32_t* ids_c,
                            int32_t* row_map, int32_t* tok_ids, int32_t* tok_rows, int32_t* counts, int32_t* work, void* stream);
+
+/* dst[r, 0 .. cols) = src[r % S, 0 .. cols) for every row r < rows with ids[r] == 0 (the padding word); other rows are left alone.  The q / k / v
+ * rows of a padding token depend on its position only (table[0] W^T + (PE W^T + b)[t]): the training forward runs in_proj over the live
+ * tokens (lime_linear_f32 with c_ids) and copies the S padding rows into the rest with this.  cols % 4 == 0, 16-byte aligned rows. */
+int lime_fill_pad_rows_f32(const int32_t* ids, const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int32_t S, int32_t cols,
+                           void* stream);
 int64_t lime_compact_sequences_workspace(int32_t n_seq);
 
 /* lime_token_attention_rows_bf16: lime_token_attention_bf16 over compacted sequences (row_map / n_seq_dev as in

@@ -208,6 +208,7 @@ SIGNATURES = {
     'lime_token_attention_bwd_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                                c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_float,
                                                c_void_p, c_int64, c_float, c_uint64, c_uint32, c_void_p, c_void_p]),
+    'lime_fill_pad_rows_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p]),
     'lime_additive_pool_bwd_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64,
                                              c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_void_p]),
     'lime_token_attention_lse_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_int32,

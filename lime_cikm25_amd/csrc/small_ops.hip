@@ -284,6 +284,21 @@ __global__ __launch_bounds__(256) void intent_fuse_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------
+// dst[r, :] = src[r % S, :] for the rows whose id is the padding word (0): the q / k / v rows of padding tokens depend on the position
+// only, so the training forward computes in_proj over the live tokens and copies these S rows into the rest (cols % 4 == 0, 16-byte rows)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fill_pad_rows_kernel(const int* __restrict__ ids, const float* __restrict__ src, long lds,
+                                                             float* __restrict__ dst, long ldd, long rows, int S, int c4n) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const long total = rows * c4n;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+        const long r = q / c4n;
+        const int c = (int)(q - r * c4n) * 4;
+        if (ids[r] == 0) *reinterpret_cast<v4*>(dst + r * ldd + c) = *reinterpret_cast<const v4*>(src + (r % S) * lds + c);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // additive attention pooling over the tokens of a sequence (MHSA news encoder): one workgroup / sequence
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void additive_pool_kernel(const float* __restrict__ hidden, long ldh,
@@ -1376,4 +1391,18 @@ extern "C" int lime_pad_heads_f32(const float* src, int64_t lds, float* dst, int
     hipLaunchKernelGGL(pad_heads_kernel, dim3(grid_for((long)n_blk * head_stride * cols, 256)), dim3(256), 0, (hipStream_t)stream, src,
                        (long)lds, dst, (long)ldd, n_blk, head_dim, head_stride, cols);
     return lime_check_launch("lime_pad_heads_f32");
+}
+
+extern "C" int lime_fill_pad_rows_f32(const int32_t* ids, const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int32_t S,
+                                      int32_t cols, void* stream) {
+    LIME_REQUIRE(ids && src && dst, LIME_ERR_BAD_ARG, "lime_fill_pad_rows_f32: NULL pointer");
+    LIME_REQUIRE(rows >= 0 && S > 0 && cols > 0 && lds >= cols && ldd >= cols, LIME_ERR_BAD_ARG, "lime_fill_pad_rows_f32: bad dimensions");
+    LIME_REQUIRE(cols % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0, LIME_ERR_UNSUPPORTED,
+                 "lime_fill_pad_rows_f32: needs 16-byte aligned rows and cols % 4 == 0");
+    if (rows == 0) return LIME_OK;
+    const long total = rows * (cols / 4);
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(fill_pad_rows_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream, ids, src,
+                       (long)lds, dst, (long)ldd, (long)rows, S, cols / 4);
+    return lime_check_launch("lime_fill_pad_rows_f32");
 }

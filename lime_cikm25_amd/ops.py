@@ -476,6 +476,19 @@ def additive_pool(hidden, affine2, x, n_seq, S, mask=None, out=None, n_seq_dev=N
     return out
 
 
+def fill_pad_rows(ids, src, dst, S):
+    """dst[r] = src[r % S] for the rows r whose id is the padding word 0 (``lime_fill_pad_rows_f32``); returns dst."""
+    lib = _lib.load()
+    _vec(ids, 'ids', dtype=torch.int32)
+    _mat(src, 'src')
+    _mat(dst, 'dst')
+    if dst.shape[0] != ids.numel() or src.shape[0] < S or src.shape[1] != dst.shape[1]:
+        raise ValueError('fill_pad_rows: dst must be [len(ids), cols], src [>= S, cols]')
+    check(lib.lime_fill_pad_rows_f32(_p(ids), _p(src), _ld(src), _p(dst), _ld(dst), ids.numel(), S, dst.shape[1], _stream()),
+          'lime_fill_pad_rows_f32')
+    return dst
+
+
 def additive_pool_bwd(hidden, affine2, x, dout, n_seq, S, mask=None):
     """Backward of ``additive_pool``: -> (dhidden [n_seq * S, A], daffine2 [A], dx [n_seq * S, D])."""
     lib = _lib.load()

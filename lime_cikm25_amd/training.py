@@ -267,7 +267,12 @@ class _TokenEncoder(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ids, nhead, eps1, eps2, p, seed, table, pe, in_w, in_b, out_w, out_b, l1_w, l1_b, l2_w, l2_b, n1_w, n1_b, n2_w,
-                n2_b):
+                n2_b, *live):
+        # live (optional, p = 0): (ids, rows) of the non-padding tokens (int32 device tensors, lime_compact_sequences' tok_ids / tok_rows cut
+        # to their count): in_proj then runs over those only and the padding tokens' q / k / v rows -- a function of the position alone --
+        # are copied in from S rows (the reference's batch is 72 % padding tokens: newsEncoders.py:311-312 embeds them all the same)
+        ctx.n_extra = len(live)
+        live = live[0] if live else None
         M, S = ids.shape
         E = table.shape[1]
         hd = E // nhead
@@ -292,7 +297,14 @@ class _TokenEncoder(torch.autograd.Function):
             y, rstd2 = ops.dropout_add_layernorm(ops.linear(h, l2_w, l2_b), x1, n2_w, n2_b, eps2, p, seed, _SITE_DROP2)
         else:
             pew = ops.linear(pe[:S], w_in, b_in)
-            qkv = ops.linear(table, w_in, None, a_ids=flat, res=pew, res_mod=S, n_alg=3 * E)
+            if live is not None and live[0].numel() >= 4096:
+                tok_ids, tok_rows = live
+                qkv = torch.empty((tok, 3 * W), dtype=torch.float32, device=dev)
+                ops.linear(table, w_in, None, a_ids=tok_ids, res=pew, res_mod=S, n_alg=3 * E, c_ids=tok_rows, out=qkv)
+                pad_rows = ops.linear(table, w_in, None, a_ids=torch.zeros(S, dtype=torch.int32, device=dev), res=pew, res_mod=S)
+                ops.fill_pad_rows(flat, pad_rows, qkv, S)
+            else:
+                qkv = ops.linear(table, w_in, None, a_ids=flat, res=pew, res_mod=S, n_alg=3 * E)
             # S > 128: the forward keeps its softmax statistics, the blocked backward does not recompute them
             lse = torch.empty(tok * nhead, dtype=torch.float32, device=dev) if S > 128 else None
             ao = ops.token_attention(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], M, S, nhead, hd, scale, head_stride=hs, lse=lse)
@@ -361,7 +373,7 @@ class _TokenEncoder(torch.autograd.Function):
             dtable = torch.zeros_like(table)
             ops.embed_bwd(flat, dx0, dtable, hot_id=0)
         return (None, None, None, None, None, None, dtable, None, din_w, din_b, dout_w, dout_b, dl1_w, dl1_b, dl2_w, dl2_b, dn1_w,
-                dn1_b, dn2_w, dn2_b)
+                dn1_b, dn2_w, dn2_b) + (None,) * ctx.n_extra
 
 
 class _EmbedPE(torch.autograd.Function):
@@ -510,10 +522,10 @@ def _dedup_sequences(ids):
     if not newsEncoders.DEDUP or ids.shape[0] < 64:
         return None
     cmp = ops.compact_sequences(ids)
-    n_c, _, _, n_live = (int(v) for v in cmp.counts[:4].tolist())      # one host read per encoder call (the step is eager)
+    n_c, _, n_tok, n_live = (int(v) for v in cmp.counts[:4].tolist())  # one host read per encoder call (the step is eager)
     if n_c >= ids.shape[0]:
         return None                                                    # nothing repeats
-    return cmp, n_c, n_live
+    return cmp, n_c, n_live, n_tok
 
 
 def _draw_seed():
@@ -540,10 +552,11 @@ def encode_tokens(ids, table, pos_encoder, transformer, nhead, p_embedding=0.0):
     if len(layers) == 1:
         layer = layers[0]
         sa = layer.self_attn
-        run = lambda rows: _TokenEncoder.apply(rows, nhead, layer.norm1.eps, layer.norm2.eps, p, _draw_seed() if p > 0 else 0, table,
-                                               pos_encoder.table(), sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias,
-                                               layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias,
-                                               layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias)
+        run = lambda rows, *live: _TokenEncoder.apply(rows, nhead, layer.norm1.eps, layer.norm2.eps, p, _draw_seed() if p > 0 else 0, table,
+                                                      pos_encoder.table(), sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight,
+                                                      sa.out_proj.bias, layer.linear1.weight, layer.linear1.bias, layer.linear2.weight,
+                                                      layer.linear2.bias, layer.norm1.weight, layer.norm1.bias, layer.norm2.weight,
+                                                      layer.norm2.bias, *live)
     else:
         def run(rows):                                  # num_layers = 2 (config.py:70): materialised input, one node per layer, mean pool
             M, S = rows.shape
@@ -557,9 +570,12 @@ def encode_tokens(ids, table, pos_encoder, transformer, nhead, p_embedding=0.0):
             return x.view(M, S, -1).mean(dim=1)                                                                 # :317 / :321
     if dd is None:
         return run(ids)
-    cmp, n_c, n_live = dd
+    cmp, n_c, n_live, n_tok = dd
     S = ids.shape[1]
-    pooled_c = run(cmp.ids_c[:n_c * S].view(n_c, S))
+    if len(layers) == 1:                                 # the live tokens' (id, compact row) lists: in_proj over them only
+        pooled_c = run(cmp.ids_c[:n_c * S].view(n_c, S), (cmp.tok_ids[:n_tok], cmp.tok_rows[:n_tok]))
+    else:
+        pooled_c = run(cmp.ids_c[:n_c * S].view(n_c, S))
     return _SeqExpand.apply(pooled_c, cmp.seq_inv, cmp.seq_src, n_live)
 
 

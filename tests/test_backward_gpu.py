@@ -388,3 +388,43 @@ def test_additive_pool_bwd(ops, n_seq, S, A, D):
     close(da2, a64.grad.float(), tol=2e-4, what='d affine2')
     close(dx, x64.grad.float(), tol=2e-4, what='d x')
     assert (dh.cpu().view(n_seq, S, A)[mask == 0] == 0).all()          # a masked token's score is a constant
+
+
+def test_fill_pad_rows(ops):
+    """Rows whose id is the padding word take src[r % S]; the others are left alone."""
+    S, cols, n_seq = 32, 960, 41
+    g = torch.Generator().manual_seed(2)
+    ids = torch.randint(0, 5, (n_seq * S,), generator=g, dtype=torch.int32)
+    src, dst0 = rnd(S, cols, seed=1), rnd(n_seq * S, cols, seed=2)
+    got = ops.fill_pad_rows(ids.cuda(), src.cuda(), dst0.clone().cuda(), S).cpu()
+    want = torch.where((ids == 0).unsqueeze(1), src.repeat(n_seq, 1), dst0)
+    assert torch.equal(got, want)
+
+
+def test_training_forward_over_live_tokens_equals_the_dense_one(ops):
+    """_TokenEncoder with the live-token lists (in_proj over the non-padding tokens + copied padding rows) against the same node without
+    them: pooled output and every gradient within fp32 rounding of each other."""
+    from lime_cikm25_amd import training as T
+    M, S, E, nh, Fd, V = 400, 32, 300, 10, 512, 400
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(1, V, (M, S), generator=g, dtype=torch.int32)
+    ids[torch.rand(M, S, generator=g) < 0.6] = 0
+    names = ['table', 'in_w', 'in_b', 'out_w', 'out_b', 'l1_w', 'l1_b', 'l2_w', 'l2_b', 'n1_w', 'n1_b', 'n2_w', 'n2_b']
+    shapes = [(V, E), (3 * E, E), (3 * E,), (E, E), (E,), (Fd, E), (Fd,), (E, Fd), (E,), (E,), (E,), (E,), (E,)]
+    vals = {n: rnd(*sh, seed=20 + i, scale=0.5 if n == 'table' else (1.0 / math.sqrt(sh[-1]) if len(sh) == 2 else 0.1)) + (1.0 if n in ('n1_w', 'n2_w') else 0.0)
+            for i, (n, sh) in enumerate(zip(names, shapes))}
+    pe, G = rnd(S, E, seed=40).cuda(), rnd(M, E, seed=41).cuda()
+    flat = ids.reshape(-1)
+    rows = torch.nonzero(flat != 0).reshape(-1).to(torch.int32)
+    assert rows.numel() >= 4096                              # (the node itself falls back below 4096 live tokens)
+    res = []
+    for live in (None, (flat[rows.long()].contiguous().cuda(), rows.cuda())):
+        dev = {n: v.clone().cuda().requires_grad_(True) for n, v in vals.items()}
+        extra = () if live is None else (live,)
+        pooled = T._TokenEncoder.apply(ids.cuda(), nh, 1e-5, 1e-5, 0.0, 0, dev['table'], pe, *[dev[n] for n in names[1:]], *extra)
+        (pooled * G).sum().backward()
+        res.append((pooled.detach().cpu(), {n: dev[n].grad.cpu() for n in names}))
+    close(res[1][0], res[0][0], tol=1e-5, what='pooled')
+    for n in names:
+        scale = float(res[0][1][n].abs().max())
+        assert float((res[1][1][n] - res[0][1][n]).abs().max()) <= 2e-5 * max(scale, 1e-6), n
