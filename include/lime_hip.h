@@ -424,6 +424,10 @@ int lime_cand_attn_weights_f32(const float* qp, const float* kp, const uint8_t* 
 int64_t lime_cand_attn_weights_workspace(int32_t B, int32_t N, int32_t H, int32_t n_head);
 int lime_cand_attn_weights_ws_f32(const float* qp, const float* kp, const uint8_t* mask, float* agg, int32_t B, int32_t N, int32_t H,
                                   int32_t D, int32_t n_head, float* workspace, int64_t workspace_floats, void* stream);
+/* the same with ONE history (kp [B / hist_div, H, D], mask [B / hist_div, H]) shared by hist_div consecutive rows: the K candidate rows of an
+ * impression in Model.score_impressions -- their key projections and topic representations are computed once per impression, not per row */
+int lime_cand_attn_weights_shared_f32(const float* qp, const float* kp, const uint8_t* mask, float* agg, int32_t B, int32_t N, int32_t H,
+                                      int32_t D, int32_t n_head, int32_t hist_div, float* workspace, int64_t workspace_floats, void* stream);
 
 /*
  * lime_gate_ln_f32: the gated residual + LayerNorm of CandidateAware_ClickedNewsAttention (layers.py:84-89), one

@@ -157,6 +157,8 @@ SIGNATURES = {
     'lime_cand_attn_weights_workspace': (c_int64, [c_int32, c_int32, c_int32, c_int32]),
     'lime_cand_attn_weights_ws_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                                 c_int64, c_void_p]),
+    'lime_cand_attn_weights_shared_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                                    c_int32, c_void_p, c_int64, c_void_p]),
     'lime_cand_attn_weights_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                                              c_int32, c_void_p]),
     'lime_gate_ln_sage_f32': (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,

@@ -566,13 +566,15 @@ __global__ __launch_bounds__(256) void cand_attn_weights_kernel(const float* __r
 
 // ---- the same weights with (row, head) parallelism: B = 32 rows put 32 workgroups on 256 CUs and the launch took 64 us ------------
 // pass 1: one wave per (row b, head): that head's softmaxed weights P[b][head][n][h] and its share of ||Q_n||^2 -> workspace
+// hist_div > 1: kp / mask hold ONE history for hist_div consecutive rows b (Model.score_impressions: the K candidates of an impression)
 __global__ __launch_bounds__(64) void cand_attn_head_kernel(const float* __restrict__ qp, const float* __restrict__ kp,
                                                             const unsigned char* __restrict__ mask, float* __restrict__ ws,
-                                                            int N, int H, int D, int n_head) {
+                                                            int N, int H, int D, int n_head, int hist_div) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int hd = D / n_head, hdp = hd + 1;       // odd pitch: conflict-free column walks
     const int lane = threadIdx.x;
     const int b = blockIdx.x / n_head, head = blockIdx.x - b * n_head;
+    const long bh = b / hist_div;                  // the history (keys, mask) of this row
     float* Qh = sm;                                // [N][hdp]
     float* Kh = sm + N * hdp;                      // [H][hdp]
     float* P = ws + ((long)blockIdx.x * N) * (H + 1);             // [N][H] probabilities, then [N] squared-norm shares behind them
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(64) void cand_attn_head_kernel(const float* __restr
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int r = r0 + u;
-                const float* src = r < N ? qp + ((long)b * N + r) * D + head * hd : kp + ((long)b * H + (r - N)) * D + head * hd;
+                const float* src = r < N ? qp + ((long)b * N + r) * D + head * hd : kp + (bh * H + (r - N)) * D + head * hd;
                 t[u] = r < N + H ? src[j] : 0.f;
             }
 #pragma unroll
@@ -611,7 +613,7 @@ __global__ __launch_bounds__(64) void cand_attn_head_kernel(const float* __restr
                 float dot = 0.f;
                 for (int j = 0; j < hd; ++j) dot += Qh[n * hdp + j] * Kh[h * hdp + j];
                 v = dot * inv_scale;
-                if (mask[(long)b * H + h] == 0) v = -1e9f;           // layers.py:72
+                if (mask[bh * H + h] == 0) v = -1e9f;                // layers.py:72
             }
             sc[c] = v;
             mx = fmaxf(mx, v);
@@ -1287,8 +1289,19 @@ extern "C" int64_t lime_cand_attn_weights_workspace(int32_t B, int32_t N, int32_
     return (int64_t)B * n_head * N * (H + 1);
 }
 
+extern "C" int lime_cand_attn_weights_shared_f32(const float* qp, const float* kp, const uint8_t* mask, float* agg, int32_t B, int32_t N,
+                                                 int32_t H, int32_t D, int32_t n_head, int32_t hist_div, float* workspace,
+                                                 int64_t workspace_floats, void* stream);
+
 extern "C" int lime_cand_attn_weights_ws_f32(const float* qp, const float* kp, const uint8_t* mask, float* agg, int32_t B, int32_t N, int32_t H,
                                              int32_t D, int32_t n_head, float* workspace, int64_t workspace_floats, void* stream) {
+    return lime_cand_attn_weights_shared_f32(qp, kp, mask, agg, B, N, H, D, n_head, 1, workspace, workspace_floats, stream);
+}
+
+extern "C" int lime_cand_attn_weights_shared_f32(const float* qp, const float* kp, const uint8_t* mask, float* agg, int32_t B, int32_t N,
+                                                 int32_t H, int32_t D, int32_t n_head, int32_t hist_div, float* workspace,
+                                                 int64_t workspace_floats, void* stream) {
+    LIME_REQUIRE(hist_div >= 1, LIME_ERR_BAD_ARG, "lime_cand_attn_weights_shared_f32: hist_div < 1");
     LIME_REQUIRE(qp && kp && mask && agg && workspace, LIME_ERR_BAD_ARG, "lime_cand_attn_weights_ws_f32: NULL pointer");
     LIME_REQUIRE(B >= 0 && N > 0 && H > 0 && D > 0 && n_head > 0 && D % n_head == 0, LIME_ERR_BAD_ARG, "lime_cand_attn_weights_ws_f32: bad dims");
     LIME_REQUIRE(N <= 128 && H <= 512, LIME_ERR_UNSUPPORTED, "lime_cand_attn_weights_ws_f32: N <= 128, H <= 512 (N=%d H=%d)", N, H);
@@ -1297,7 +1310,7 @@ extern "C" int lime_cand_attn_weights_ws_f32(const float* qp, const float* kp, c
     if (B == 0) return LIME_OK;
     const size_t lds1 = (size_t)(N + H) * (D / n_head + 1) * sizeof(float);
     LIME_REQUIRE(lds1 <= 64 * 1024, LIME_ERR_UNSUPPORTED, "lime_cand_attn_weights_ws_f32: %zu B of LDS needed", lds1);
-    hipLaunchKernelGGL(cand_attn_head_kernel, dim3((unsigned)(B * n_head)), dim3(64), lds1, (hipStream_t)stream, qp, kp, mask, workspace, N, H, D, n_head);
+    hipLaunchKernelGGL(cand_attn_head_kernel, dim3((unsigned)(B * n_head)), dim3(64), lds1, (hipStream_t)stream, qp, kp, mask, workspace, N, H, D, n_head, hist_div);
     hipLaunchKernelGGL(cand_attn_finish_kernel, dim3((unsigned)B), dim3(256), (size_t)(N + H + 4) * sizeof(float), (hipStream_t)stream,
                        (const float*)workspace, agg, N, H, n_head);
     return lime_check_launch("lime_cand_attn_weights_ws_f32");

@@ -42,16 +42,18 @@ class CandidateAware_ClickedNewsAttention(nn.Module):
         nn.init.xavier_uniform_(self.gate_proj.weight)
         nn.init.zeros_(self.gate_proj.bias)
 
-    def attention_weights(self, clicked_news_topic_embeddings, candidate_topic_embeddings, mask=None):
-        """agg [B, H] of layers.py:66-81: topic projections, per-head masked softmax, query-norm weighting, outer softmax."""
-        B, H, _ = clicked_news_topic_embeddings.shape
+    def attention_weights(self, clicked_news_topic_embeddings, candidate_topic_embeddings, mask=None, hist_div=1):
+        """agg [B, H] of layers.py:66-81: topic projections, per-head masked softmax, query-norm weighting, outer softmax.
+        ``hist_div`` > 1: the history side ([B / hist_div, H, .], mask [B / hist_div, H]) is shared by hist_div consecutive candidate rows."""
+        Bh, H, _ = clicked_news_topic_embeddings.shape
+        B = Bh * hist_div
         N = candidate_topic_embeddings.shape[1]
         D = self.news_embedding_dim
         if mask is None:
-            mask = torch.ones(B, H, dtype=torch.bool, device=clicked_news_topic_embeddings.device)
+            mask = torch.ones(Bh, H, dtype=torch.bool, device=clicked_news_topic_embeddings.device)
         qp = ops.linear(candidate_topic_embeddings.reshape(B * N, -1), self.query_proj.weight, self.query_proj.bias)
-        kp = ops.linear(clicked_news_topic_embeddings.reshape(B * H, -1), self.key_proj.weight, self.key_proj.bias)
-        return ops.cand_attn_weights(qp, kp, mask, B, N, H, D, self.num_heads)
+        kp = ops.linear(clicked_news_topic_embeddings.reshape(Bh * H, -1), self.key_proj.weight, self.key_proj.bias)
+        return ops.cand_attn_weights(qp, kp, mask, B, N, H, D, self.num_heads, hist_div=hist_div)
 
     def refine(self, clicked_news_embeddings, agg):
         """layers.py:83-91: weighted history, gated residual, LayerNorm."""

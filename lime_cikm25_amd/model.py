@@ -179,9 +179,9 @@ class Model(nn.Module):
         for b0 in range(0, B, per):
             b1 = min(B, b0 + per)
             n = (b1 - b0) * K
-            rep = lambda t: t[b0:b1].repeat_interleave(K, dim=0)                      # per-row ids / masks (the history itself is shared: hist_div)
+            # the history side (embeddings, topic ids, mask) is shared by the K candidate rows of an impression: hist_div
             _, logits = ue.match(hist[b0:b1], news_category[b0:b1].reshape(n, 1), news_subCategory[b0:b1].reshape(n, 1),
-                                 rep(user_category), rep(user_subCategory), rep(user_history_mask),
+                                 user_category[b0:b1], user_subCategory[b0:b1], user_history_mask[b0:b1],
                                  cand[b0:b1].reshape(n, 1, -1), remaining_lifetime=rl[b0:b1].reshape(n, 1),
                                  weighting=self.remaining_lifetime_weighting, n_src=n_src, hist_div=K,
                                  gate_y=None if gate_y is None else gate_y[b0 * H:b1 * H])

@@ -511,20 +511,28 @@ def additive_pool_bwd(hidden, affine2, x, dout, n_seq, S, mask=None):
 CAND_ATTN_BY_HEAD = True      # False: the one-workgroup-per-row kernel (tests compare the two)
 
 
-def cand_attn_weights(qp, kp, mask, B, N, H, D, n_head):
+def cand_attn_weights(qp, kp, mask, B, N, H, D, n_head, hist_div=1):
+    """agg [B, H] of layers.py:66-81.  ``hist_div`` > 1: kp [B / hist_div, H, D] and mask [B / hist_div, H] hold one history for hist_div
+    consecutive rows (the candidates of one impression)."""
     lib = _lib.load()
+    if B % hist_div:
+        raise ValueError('B must be a multiple of hist_div')
+    Bh = B // hist_div
     _vec(qp, 'qp', B * N * D)
-    _vec(kp, 'kp', B * H * D)
+    _vec(kp, 'kp', Bh * H * D)
     m = _mask_u8(mask, 'mask')
-    if m.numel() != B * H:
-        raise ValueError('mask must be [B, H]')
+    if m.numel() != Bh * H:
+        raise ValueError('mask must be [B / hist_div, H]')
     agg = torch.empty((B, H), dtype=torch.float32, device=qp.device)
-    if CAND_ATTN_BY_HEAD and (N + H) * (D // n_head + 1) * 4 <= 64 * 1024:
+    by_head = (N + H) * (D // n_head + 1) * 4 <= 64 * 1024
+    if hist_div > 1 and not (CAND_ATTN_BY_HEAD and by_head):
+        kp, m, hist_div = kp.view(Bh, H * D).repeat_interleave(hist_div, dim=0).view(-1), m.view(Bh, H).repeat_interleave(hist_div, dim=0), 1
+    if CAND_ATTN_BY_HEAD and by_head:
         # (row, head)-parallel: two short launches through a workspace (B = 32 rows alone leave 7 of 8 CUs idle)
         n_ws = int(lib.lime_cand_attn_weights_workspace(B, N, H, n_head))
         ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=qp.device)
-        check(lib.lime_cand_attn_weights_ws_f32(_p(qp), _p(kp), _p(m), _p(agg), B, N, H, D, n_head, _p(ws), n_ws, _stream()),
-              'lime_cand_attn_weights_ws_f32')
+        check(lib.lime_cand_attn_weights_shared_f32(_p(qp), _p(kp), _p(m), _p(agg), B, N, H, D, n_head, hist_div, _p(ws), n_ws, _stream()),
+              'lime_cand_attn_weights_shared_f32')
         return agg
     check(lib.lime_cand_attn_weights_f32(_p(qp), _p(kp), _p(m), _p(agg), B, N, H, D, n_head, _stream()),
           'lime_cand_attn_weights_f32')

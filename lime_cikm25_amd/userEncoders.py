@@ -106,7 +106,7 @@ class CROWN(UserEncoder):
                             ne.category_affine.weight, ne.category_affine.bias)
         return rep.view(*shape, -1)
 
-    def attention_weights(self, category, subCategory, user_category, user_subCategory, user_history_mask):
+    def attention_weights(self, category, subCategory, user_category, user_subCategory, user_history_mask, hist_div=1):
         """The candidate-aware attention weights agg [B, H] (layers.py:66-81).  They depend on the topic ids and the
         history mask only -- not on any news embedding -- so the model computes them on a side stream while the token
         encoders run."""
@@ -117,7 +117,7 @@ class CROWN(UserEncoder):
                                       '(layers.py:36,74) runs on the differentiable path (user_encoder(...) / Model.forward)')
         cand_topic = self._topic(category, subCategory)
         hist_topic = self._topic(user_category, user_subCategory)
-        return self.candidate_aware_attn.attention_weights(hist_topic, cand_topic, user_history_mask)
+        return self.candidate_aware_attn.attention_weights(hist_topic, cand_topic, user_history_mask, hist_div=hist_div)
 
     def match(self, history_embedding, category, subCategory, user_category, user_subCategory, user_history_mask,
               candidate_news_representation, remaining_lifetime=None, weighting=None, agg=None, n_src=None, hist_div=1,
@@ -129,7 +129,8 @@ class CROWN(UserEncoder):
         ``agg``: precomputed ``attention_weights(...)``.  ``n_src``: how many node slots the GraphSAGE mean runs over
         (Q7: the reference uses the number of rows of the forward; default B).
         ``hist_div`` > 1 (Model.score_impressions): ``history_embedding`` is [B / hist_div, H, D] -- ONE copy of a history for the
-        hist_div consecutive rows (candidates) that share it; everything per row (attention weights, masks, topic ids) stays [B, ...].
+        hist_div consecutive rows (candidates) that share it, and so are the history's topic ids and mask ([B / hist_div, H]); the
+        candidates' own ids and ``agg`` (if given) are per row [B, ...].
         ``gate_y``: ``gate_projection(history_embedding)`` computed by the caller (one GEMM over all passes' histories).
         """
         if self.training and (self.dropout_rate > 0 or (self.use_candidate_aware_attn and self.candidate_aware_attn.dropout.p > 0)):
@@ -156,7 +157,8 @@ class CROWN(UserEncoder):
             with torch.cuda.stream(side6):
                 qp = ops.linear(cand.view(B * N, D), self.Q.weight, self.Q.bias)                             # :162
         if caa is not None and agg is None:
-            agg = self.attention_weights(category, subCategory, user_category, user_subCategory, user_history_mask)
+            # (hist_div > 1: user_category / user_subCategory / user_history_mask are [B / hist_div, H] -- one history per hist_div rows)
+            agg = self.attention_weights(category, subCategory, user_category, user_subCategory, user_history_mask, hist_div=hist_div)
         conv = self.graph_sage.convs[0]
         if fused:
             # gate_proj sees the history alone (the row scale commutes: layers.py:85-87), so it runs once per HISTORY; the gated

@@ -908,3 +908,17 @@ def test_misaligned_layernorm_epilogue_warns_once(ops):
     with warnings.catch_warnings():
         warnings.simplefilter('error')
         ops.linear(a, w, None, res=res, ln=(g, b))          # only once per process
+
+
+def test_cand_attn_weights_shared_history(ops):
+    """hist_div: one history (key projections, mask) for hist_div consecutive rows equals the call on the repeated history, bit for bit."""
+    Bh, K, N, H, D, nh = 6, 5, 1, 50, 400, 10
+    B = Bh * K
+    qp, kp = dev(rnd(B * N, D, seed=1)), dev(rnd(Bh * H, D, seed=2))
+    g = torch.Generator().manual_seed(3)
+    mask = (torch.rand(Bh, H, generator=g) > 0.3)
+    mask[:, 0] = True
+    shared = ops.cand_attn_weights(qp.view(-1), kp.view(-1), dev(mask), B, N, H, D, nh, hist_div=K)
+    full = ops.cand_attn_weights(qp.view(-1), kp.view(Bh, H * D).repeat_interleave(K, dim=0).reshape(-1), dev(mask.repeat_interleave(K, dim=0)),
+                                 B, N, H, D, nh)
+    assert torch.equal(shared, full)
