@@ -362,6 +362,10 @@ int lime_pad_heads_f32(const float* src, int64_t lds, float* dst, int64_t ldd, i
 /* lime_mean_pool_f32: out[s, :] = mean_t x[(s * S + t), :]   (newsEncoders.py:317,321; padding included) */
 int lime_mean_pool_f32(const float* x, int64_t ldx, float* out, int64_t ldo, int32_t n_seq, int32_t S, int32_t dim,
                        void* stream);
+/* the same over the first min(n_seq, *n_seq_dev) sequences (a compacted batch: device-side count, the rows behind it are not
+ * read and their outputs not written); S <= 16 rows per sequence (the block means `pool32` leaves), dim % 4 == 0 */
+int lime_mean_pool_count_f32(const float* x, int64_t ldx, float* out, int64_t ldo, int32_t n_seq, int32_t S, int32_t dim,
+                             const int32_t* n_seq_dev, void* stream);
 
 /*
  * lime_bucketize_f32: b = min(trunc(log(max(x,1)) / log(86400) * (10/7)), 9)  (newsEncoders.py:53-58),

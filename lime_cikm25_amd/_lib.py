@@ -141,6 +141,7 @@ SIGNATURES = {
     'lime_compact_sequences_workspace': (c_int64, [c_int32]),
     'lime_pad_heads_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'lime_mean_pool_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p]),
+    'lime_mean_pool_count_f32': (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     'lime_bucketize_f32': (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     'lime_mhsa_live_ids': (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     'lime_mhsa_compact_mask': (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),

@@ -1976,7 +1976,14 @@ static int attention_bwd(const float* q, const float* k, const float* v, int64_t
     hipStream_t s = (hipStream_t)stream;
     if (S <= 32) return launch_attn_bwd<32>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, drop, key_mask, s);
     if (S <= 64) return launch_attn_bwd<64>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, drop, key_mask, s);
-    if (S <= 128) return launch_attn_bwd<128>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, drop, key_mask, s);
+    if (S <= 128) {
+        if (key_mask == nullptr && (lime_split_mode() & 1)) {      // every product on the bf16 matrix cores (token_attn_bwd_sp_f32.hip)
+            const int st = lime_token_attention_bwd_sp(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride,
+                                                       scale, drop, s);
+            if (st != LIME_PP_NOT_APPLICABLE) return st;
+        }
+        return launch_attn_bwd<128>(q, k, v, ld_qkv, dout, ldo, dq, dk, dv, ld_dqkv, n_seq, S, n_head, head_dim, head_stride, scale, drop, key_mask, s);
+    }
     // blocked path
     LIME_REQUIRE(key_mask == nullptr, LIME_ERR_UNSUPPORTED, "lime_token_attention_bwd_f32: a key mask needs S <= 128");
     LIME_REQUIRE(out && ld_out >= (int64_t)n_head * head_dim, LIME_ERR_BAD_ARG,

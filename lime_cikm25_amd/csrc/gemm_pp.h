@@ -40,3 +40,7 @@ int lime_split_mode();                                                   // gemm
 int lime_token_attention_sp(const float* q, const float* k, const float* v, long ld, const int* row_map, const int* n_seq_dev,
                             float* out, long ldo, int n_seq, int S, int n_head, int hd, float scale, float* lse, hipStream_t s,
                             const LimeDropout* drop = nullptr);
+// token_attn_bwd_sp_f32.hip: the one-pass attention backward (64 < S <= 128, no key mask) with all its products on the split product
+int lime_token_attention_bwd_sp(const float* q, const float* k, const float* v, long ld, const float* dout, long ldo, float* dq, float* dk,
+                                float* dv, long ldd, int n_seq, int S, int n_head, int head_dim, int head_stride, float scale,
+                                const LimeDropout& drop, hipStream_t s);

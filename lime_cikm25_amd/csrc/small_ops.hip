@@ -91,15 +91,24 @@ __global__ __launch_bounds__(256) void mean_pool_vec4_kernel(const float* __rest
 // short "sequences" (the S / 32 block rows the pooled GEMM epilogue leaves: 4 rows at S = 128, 16 at S = 512): one thread per
 // (sequence, four columns), rows summed in order -- a workgroup per sequence would be 8,000+ workgroups of almost no work
 __global__ __launch_bounds__(256) void mean_pool_flat_kernel(const float* __restrict__ x, long ldx, float* __restrict__ out,
-                                                              long ldo, long n_seq, int S, int dim) {
+                                                              long ldo, long n_seq, int S, int dim, const int* __restrict__ n_seq_dev) {
     const int nc = dim >> 2;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (n_seq_dev) n_seq = min(n_seq, (long)*n_seq_dev);               // compacted batch: the sequences behind the count hold nothing
     if (e >= n_seq * nc) return;
     const long s = e / nc;
     const int c = (int)(e - s * nc) * 4;
     const float* px = x + s * S * ldx + c;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < S; ++t) acc += *reinterpret_cast<const f32x4*>(px + (long)t * ldx);
+    int t = 0;
+    for (; t + 4 <= S; t += 4) {                                        // four rows in flight, added in row order
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(px + (long)t * ldx);
+        const f32x4 r1 = *reinterpret_cast<const f32x4*>(px + (long)(t + 1) * ldx);
+        const f32x4 r2 = *reinterpret_cast<const f32x4*>(px + (long)(t + 2) * ldx);
+        const f32x4 r3 = *reinterpret_cast<const f32x4*>(px + (long)(t + 3) * ldx);
+        acc += r0; acc += r1; acc += r2; acc += r3;
+    }
+    for (; t < S; ++t) acc += *reinterpret_cast<const f32x4*>(px + (long)t * ldx);
     const float inv = 1.0f / (float)S;
     float* po = out + s * ldo + c;
     po[0] = acc[0] * inv; po[1] = acc[1] * inv; po[2] = acc[2] * inv; po[3] = acc[3] * inv;
@@ -977,22 +986,35 @@ extern "C" int lime_embed_pe_f32(const int32_t* ids, const float* table, int64_t
     return lime_check_launch("lime_embed_pe_f32");
 }
 
-extern "C" int lime_mean_pool_f32(const float* x, int64_t ldx, float* out, int64_t ldo, int32_t n_seq, int32_t S, int32_t dim,
-                                  void* stream) {
+static int mean_pool(const float* x, int64_t ldx, float* out, int64_t ldo, int32_t n_seq, int32_t S, int32_t dim, const int32_t* n_seq_dev,
+                     void* stream, const char* who) {
     LIME_REQUIRE(x && out, LIME_ERR_BAD_ARG, "lime_mean_pool_f32: NULL pointer");
     LIME_REQUIRE(n_seq >= 0 && S > 0 && dim > 0 && ldx >= dim && ldo >= dim, LIME_ERR_BAD_ARG, "lime_mean_pool_f32: bad dims");
     if (n_seq == 0) return LIME_OK;
     const bool v4 = dim % 4 == 0 && dim <= 1024 && ldx % 4 == 0 && ((uintptr_t)x % 16 == 0);
-    if (v4 && S <= 16 && n_seq >= 512)
+    LIME_REQUIRE(!n_seq_dev || (v4 && S <= 16), LIME_ERR_BAD_ARG,
+                 "lime_mean_pool_count_f32: the counted form covers S <= 16 rows per sequence, dim %% 4 == 0, 16-byte aligned rows");
+    if (v4 && S <= 16 && (n_seq >= 512 || n_seq_dev))
         hipLaunchKernelGGL(mean_pool_flat_kernel, dim3((unsigned)(((long)n_seq * (dim >> 2) + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           x, (long)ldx, out, (long)ldo, (long)n_seq, S, dim);
+                           x, (long)ldx, out, (long)ldo, (long)n_seq, S, dim, n_seq_dev);
     else if (v4)
         hipLaunchKernelGGL(mean_pool_vec4_kernel, dim3((unsigned)n_seq), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, out,
                            (long)ldo, S, dim);
     else
         hipLaunchKernelGGL(mean_pool_kernel, dim3((unsigned)n_seq), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, out, (long)ldo,
                            S, dim);
-    return lime_check_launch("lime_mean_pool_f32");
+    return lime_check_launch(who);
+}
+
+extern "C" int lime_mean_pool_f32(const float* x, int64_t ldx, float* out, int64_t ldo, int32_t n_seq, int32_t S, int32_t dim,
+                                  void* stream) {
+    return mean_pool(x, ldx, out, ldo, n_seq, S, dim, nullptr, stream, "lime_mean_pool_f32");
+}
+
+extern "C" int lime_mean_pool_count_f32(const float* x, int64_t ldx, float* out, int64_t ldo, int32_t n_seq, int32_t S, int32_t dim,
+                                        const int32_t* n_seq_dev, void* stream) {
+    LIME_REQUIRE(n_seq_dev, LIME_ERR_BAD_ARG, "lime_mean_pool_count_f32: NULL count");
+    return mean_pool(x, ldx, out, ldo, n_seq, S, dim, n_seq_dev, stream, "lime_mean_pool_count_f32");
 }
 
 extern "C" int lime_bucketize_f32(const float* x, int32_t* out, int64_t n, void* stream) {

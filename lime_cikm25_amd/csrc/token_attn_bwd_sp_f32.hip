@@ -1,0 +1,327 @@
+// lime_token_attention_bwd_f32 for 64 < S <= 128 with ALL FIVE products on the bf16 matrix cores as split products (split_mfma.h:
+// three bf16 terms per fp32 value, six v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block, fp32 accumulation).  gfx950 only.
+//
+// token_attn_bwd_kernel (backward_f32.hip) keeps P / dS as an fp32 image in LDS and takes dV, dQ, dK from v_mfma_f32_16x16x4_f32
+// (256 matrix cycles per 16 x 16 x 32 block against 96 here); three workgroup barriers per (sequence, head).  Here a 16 x 16 result
+// tile never leaves the registers before it is an operand again.  The MFMA result layout puts a tile's COLUMN on the lane (fi) and
+// its ROWS on the lane group and the registers (4 kg + r), and the k index of the next MFMA is only a summation label: registers
+// of two row tiles ARE the eight k values of a B operand, for a product that sums over the tile's rows and keeps its column.  So
+// the scores are computed in both orientations, each by the wave that owns the column:
+//   phase A (a wave's 16 queries i on the columns, all keys j on the rows):
+//       S^T = K Q^T, dP^T = V dO^T  ->  softmax over j and delta_i = sum_j P~ dP in the lane + two shuffles  ->  dS^T
+//       dQ^T[d, i] = sum_j K^T[d, j] dS^T[j, i]                                         (K^T: transposed LDS reads, below)
+//   phase B (a wave's 16 keys j on the columns, all queries i on the rows; row maximum, 1 / sum and delta of phase A through LDS):
+//       S = Q K^T, dP = dO V^T  ->  P~, dS
+//       dV^T[d, j] = sum_i dO^T[d, i] P~[i, j],   dK^T[d, j] = sum_i Q^T[d, i] dS[i, j]
+// Seven products instead of five, all at the split rate (56 blocks x 96 cycles per wave against 40 x 256), ONE barrier between
+// the phases, no P image.  Q, K, V, dO are split once per (sequence, head) on their way into LDS: three bf16 images [128][32]
+// each (pitch 80 B).  The row-major image serves both operand kinds: as rows (ds_read_b128: eight consecutive head dims of one
+// token) for the score products, and TRANSPOSED for the gradient products through ds_read_b64_tr_b16 -- per 16-lane group a block
+// of four token rows x 16 head dims, delivered column-major: lane fi gets head dim fi of rows 4 kg .. 4 kg + 3 of a 16-row tile,
+// which is exactly the k order the result registers carry.  The results come out transposed (head dims on the registers): a lane
+// stores four consecutive head dims of its token, 16 bytes.
+// The attention-probability dropout mask is regenerated from the element index as in the fp32 kernel (same seed / site / index).
+#include "common.h"
+#include "gemm_pp.h"
+#include "lds_dma.h"
+#include "split_mfma.h"
+#include "dropout.h"
+
+using namespace lime_dev;
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int SPB = 128;                              // rows per image
+constexpr int TERM = SPB * SPLIT_PITCH;               // one bf16 image (unsigned shorts)
+constexpr int IMG = 3 * TERM;                         // the three terms of one operand
+constexpr int LDS_BYTES = 4 * IMG * 2 + 3 * SPB * 4;  // Q, K, V, dO + the row statistics
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+struct BwdSpP {
+    const float* q; const float* k; const float* v; long ld;
+    const float* dout; long ldo;
+    float* dq; float* dk; float* dv; long ldd;
+    int n_seq, S, n_head, head_dim; float scale;
+    LimeDropout drop;
+};
+
+// the A operand (rows = head dims 16 c + fi) of a product that sums over token rows: k values = rows 16 t0 + 4 kg + {0..3} and
+// 16 (t0 + 1) + 4 kg + {0..3} of the row-major image -- two transposed block reads per term.  `p0` is this lane's address in
+// the first block (row 16 t0 + 4 kg + (fi >> 2), column 16 c + 4 (fi & 3)); EXEC is all ones at every call.
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned short* p0) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 16 * SPLIT_PITCH));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ SplitFrag tr_load(const unsigned short* img, int t0, int c, int fi, int kg) {
+    const unsigned short* const p0 = img + (16 * t0 + 4 * kg + (fi >> 2)) * SPLIT_PITCH + 16 * c + 4 * (fi & 3);
+    SplitFrag f;
+    f.h = tr_pair(p0);
+    f.m = tr_pair(p0 + TERM);
+    f.l = tr_pair(p0 + 2 * TERM);
+    return f;
+}
+
+__global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const BwdSpP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    unsigned short* const Qi = smem;
+    unsigned short* const Ki = Qi + IMG;
+    unsigned short* const Vi = Ki + IMG;
+    unsigned short* const Oi = Vi + IMG;
+    float* const st_mx = reinterpret_cast<float*>(Oi + IMG);
+    float* const st_inv = st_mx + SPB;
+    float* const st_dl = st_inv + SPB;
+
+    const int tid0 = threadIdx.x;
+    const int S = p.S;
+    const long n_prob = (long)p.n_seq * p.n_head;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const float c2 = p.scale * LOG2E;
+    const bool dropping = p.drop.thresh != 0;
+
+    // the next problem's rows travel in registers while this one computes: q / k / v rows are 32 floats on 16-byte boundaries (heads
+    // 32 columns apart, zero pad columns), dO rows head_dim floats on 8-byte boundaries
+    f32x4 rq[2], rk[2], rv[2];
+    f32x2 ro[4];
+    auto fetch = [&](long prob) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));                 // (addresses recomputed per problem, see below)
+        const int seq = (int)(prob / p.n_head), head = (int)(prob % p.n_head);
+        const long row_base = (long)seq * S;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 512 * u, r = e >> 3, c = (e & 7) * 4;
+            const bool ok = r < S;
+            const long g = (row_base + (ok ? r : 0)) * p.ld + (long)head * 32 + c;
+            rq[u] = ok ? *reinterpret_cast<const f32x4*>(p.q + g) : z4;
+            rk[u] = ok ? *reinterpret_cast<const f32x4*>(p.k + g) : z4;
+            rv[u] = ok ? *reinterpret_cast<const f32x4*>(p.v + g) : z4;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 512 * u, r = e >> 4, c = (e & 15) * 2;
+            f32x2 d = {0.f, 0.f};
+            if (r < S && c < p.head_dim) d = *reinterpret_cast<const f32x2*>(p.dout + (row_base + r) * p.ldo + (long)head * p.head_dim + c);
+            ro[u] = d;
+        }
+    };
+    auto commit = [&]() {                             // registers -> the split images
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 512 * u, r = e >> 3, c = (e & 7) * 4;
+            u32x2 h, m, l;
+            split_quad(rq[u][0], rq[u][1], rq[u][2], rq[u][3], h, m, l);
+            unsigned short* d = Qi + r * SPLIT_PITCH + c;
+            *reinterpret_cast<u32x2*>(d) = h; *reinterpret_cast<u32x2*>(d + TERM) = m; *reinterpret_cast<u32x2*>(d + 2 * TERM) = l;
+            split_quad(rk[u][0], rk[u][1], rk[u][2], rk[u][3], h, m, l);
+            d = Ki + r * SPLIT_PITCH + c;
+            *reinterpret_cast<u32x2*>(d) = h; *reinterpret_cast<u32x2*>(d + TERM) = m; *reinterpret_cast<u32x2*>(d + 2 * TERM) = l;
+            split_quad(rv[u][0], rv[u][1], rv[u][2], rv[u][3], h, m, l);
+            d = Vi + r * SPLIT_PITCH + c;
+            *reinterpret_cast<u32x2*>(d) = h; *reinterpret_cast<u32x2*>(d + TERM) = m; *reinterpret_cast<u32x2*>(d + 2 * TERM) = l;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 512 * u, r = e >> 4, c = (e & 15) * 2;
+            split_store2(Oi, TERM, r, c, ro[u][0], ro[u][1]);
+        }
+    };
+
+    if ((long)blockIdx.x < n_prob) fetch(blockIdx.x);
+    for (long prob = blockIdx.x; prob < n_prob; prob += gridDim.x) {
+        const int seq = (int)(prob / p.n_head), head = (int)(prob % p.n_head);
+        commit();
+        __syncthreads();
+        if (prob + gridDim.x < n_prob) fetch(prob + gridDim.x);
+        // per-lane offsets are recomputed per problem from a laundered lane id: hoisted out of this loop they are ~100 registers of
+        // loop-invariant addresses and mask indices (spilled)
+        int tl = tid0;
+        asm volatile("" : "+v"(tl));
+        int lane = tl & 63;
+        const int X0 = 16 * __builtin_amdgcn_readfirstlane(tl >> 6);      // this wave's 16 queries (phase A) / keys (phase B)
+
+        // ================= phase A: this wave's queries on the columns =================================================
+        {
+            const int fi = lane & 15, kg = lane >> 4;
+            const SplitFrag qB = split_load(Qi, TERM, X0 + fi, kg), oB = split_load(Oi, TERM, X0 + fi, kg);
+            f32x4 st[8], dt[8];                       // S^T / P^T and dP^T / dS^T: [key 16 t + 4 kg + r][query X0 + fi]
+            SplitFrag kA[2], vA[2];                   // the next tile's fragments are requested before this tile's MFMAs
+            kA[0] = split_load(Ki, TERM, fi, kg); vA[0] = split_load(Vi, TERM, fi, kg);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t + 1 < 8) { kA[(t + 1) & 1] = split_load(Ki, TERM, 16 * (t + 1) + fi, kg); vA[(t + 1) & 1] = split_load(Vi, TERM, 16 * (t + 1) + fi, kg); }
+                st[t] = split_mfma16(kA[t & 1], qB, z4);
+                dt[t] = split_mfma16(vA[t & 1], oB, z4);
+                __builtin_amdgcn_sched_barrier(0);    // two tiles' fragments at a time (unrolled, hipcc hoists all 192 registers of them)
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sv = (16 * t + 4 * kg + r < S) ? st[t][r] * c2 : -INFINITY;
+                    st[t][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(st[t][r] - mx);
+                    st[t][r] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+            // the forward multiplied keep * P / (1 - p) into V: dP~ = keep * dP / (1 - p), delta = sum_j P dP~, dS = scale P (dP~ - delta)
+            const uint64_t mrow = ((uint64_t)prob * S + (uint64_t)(X0 + fi)) * (uint64_t)S;
+            float dl = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const unsigned keep = dropping ? lime_keep4(p.drop, (mrow + (uint64_t)(16 * t + 4 * kg)) >> 2) : 0xFu;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = st[t][r] * inv;
+                    const float dpv = dropping ? ((keep >> r) & 1u ? dt[t][r] * p.drop.scale : 0.f) : dt[t][r];
+                    st[t][r] = pv;
+                    dt[t][r] = dpv;
+                    dl += pv * dpv;
+                }
+            }
+            dl += __shfl_xor(dl, 16); dl += __shfl_xor(dl, 32);
+            if (kg == 0) { st_mx[X0 + fi] = mx; st_inv[X0 + fi] = inv; st_dl[X0 + fi] = dl; }
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dt[t][r] = p.scale * st[t][r] * (dt[t][r] - dl);
+            // dQ^T[d, i] = sum_j K^T[d, j] dS^T[j, i]
+            f32x4 aq0 = z4, aq1 = z4;
+            SplitFrag b[2];                           // a step: K^T fragments requested, the NEXT step's dS^T registers split under that
+            b[0] = split_frag(dt[0], dt[1]);          // latency, then the step's twelve MFMAs
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const SplitFrag a0 = tr_load(Ki, 2 * s, 0, fi, kg), a1 = tr_load(Ki, 2 * s, 1, fi, kg);
+                if (s + 1 < 4) b[(s + 1) & 1] = split_frag(dt[2 * s + 2], dt[2 * s + 3]);
+                aq0 = split_mfma16(a0, b[s & 1], aq0);
+                aq1 = split_mfma16(a1, b[s & 1], aq1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (X0 + fi < S) {
+                float* const d = p.dq + ((long)seq * S + X0 + fi) * p.ldd + (long)head * 32 + 4 * kg;
+                *reinterpret_cast<f32x4*>(d) = aq0;
+                *reinterpret_cast<f32x4*>(d + 16) = aq1;
+            }
+        }
+        __syncthreads();                              // every query's statistics are in LDS
+
+        // ================= phase B: this wave's keys on the columns ====================================================
+        {
+            asm volatile("" : "+v"(lane));
+            const int fi = lane & 15, kg = lane >> 4;
+            const SplitFrag kB = split_load(Ki, TERM, X0 + fi, kg), vB = split_load(Vi, TERM, X0 + fi, kg);
+            f32x4 pt[8], ds[8];                       // S / P~ and dP / dS: [query 16 t + 4 kg + r][key X0 + fi]
+            SplitFrag qA[2], oA[2];
+            qA[0] = split_load(Qi, TERM, fi, kg); oA[0] = split_load(Oi, TERM, fi, kg);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t + 1 < 8) { qA[(t + 1) & 1] = split_load(Qi, TERM, 16 * (t + 1) + fi, kg); oA[(t + 1) & 1] = split_load(Oi, TERM, 16 * (t + 1) + fi, kg); }
+                pt[t] = split_mfma16(qA[t & 1], kB, z4);
+                ds[t] = split_mfma16(oA[t & 1], vB, z4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const bool key_ok = X0 + fi < S;
+            const int jq = (X0 + fi) >> 2, jb = fi & 3;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const f32x4 mx4 = *reinterpret_cast<const f32x4*>(st_mx + 16 * t + 4 * kg);
+                const f32x4 inv4 = *reinterpret_cast<const f32x4*>(st_inv + 16 * t + 4 * kg);
+                const f32x4 dl4 = *reinterpret_cast<const f32x4*>(st_dl + 16 * t + 4 * kg);
+                // the mask is hashed per four consecutive KEYS of one query: the four lanes of a quad (keys 4 jq .. 4 jq + 3) need the same
+                // four hashes (queries r = 0..3) -- each lane computes the one of query r = its position, the quad exchanges them by DPP
+                unsigned k0 = 0xFu, k1 = 0xFu, k2 = 0xFu, k3 = 0xFu;
+                if (dropping) {
+                    const uint64_t idx4 = (((uint64_t)prob * S + (uint64_t)(16 * t + 4 * kg + jb)) * (uint64_t)S >> 2) + (uint64_t)jq;
+                    const int mine = (int)lime_keep4(p.drop, idx4);
+                    k0 = (unsigned)__builtin_amdgcn_mov_dpp(mine, 0x00, 0xF, 0xF, true);      // quad_perm [0, 0, 0, 0]
+                    k1 = (unsigned)__builtin_amdgcn_mov_dpp(mine, 0x55, 0xF, 0xF, true);      // [1, 1, 1, 1]
+                    k2 = (unsigned)__builtin_amdgcn_mov_dpp(mine, 0xAA, 0xF, 0xF, true);      // [2, 2, 2, 2]
+                    k3 = (unsigned)__builtin_amdgcn_mov_dpp(mine, 0xFF, 0xF, 0xF, true);      // [3, 3, 3, 3]
+                }
+                const unsigned kr[4] = {k0, k1, k2, k3};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = key_ok ? __builtin_amdgcn_exp2f(pt[t][r] * c2 - mx4[r]) * inv4[r] : 0.f;
+                    const float f = dropping ? ((kr[r] >> jb) & 1u ? p.drop.scale : 0.f) : 1.f;
+                    const float dpv = ds[t][r] * f;
+                    pt[t][r] = pv * f;
+                    ds[t][r] = p.scale * pv * (dpv - dl4[r]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // dV^T[d, j] = sum_i dO^T[d, i] P~[i, j];  dK^T[d, j] = sum_i Q^T[d, i] dS[i, j]
+            f32x4 av0 = z4, av1 = z4, ak0 = z4, ak1 = z4;
+            SplitFrag b[2];
+            b[0] = split_frag(pt[0], pt[1]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const SplitFrag o0 = tr_load(Oi, 2 * s, 0, fi, kg), o1 = tr_load(Oi, 2 * s, 1, fi, kg);
+                b[(s + 1) & 1] = s + 1 < 4 ? split_frag(pt[2 * s + 2], pt[2 * s + 3]) : split_frag(ds[0], ds[1]);
+                av0 = split_mfma16(o0, b[s & 1], av0);
+                av1 = split_mfma16(o1, b[s & 1], av1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const SplitFrag q0 = tr_load(Qi, 2 * s, 0, fi, kg), q1 = tr_load(Qi, 2 * s, 1, fi, kg);
+                if (s + 1 < 4) b[(s + 1) & 1] = split_frag(ds[2 * s + 2], ds[2 * s + 3]);
+                ak0 = split_mfma16(q0, b[s & 1], ak0);
+                ak1 = split_mfma16(q1, b[s & 1], ak1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (key_ok) {
+                const long o = ((long)seq * S + X0 + fi) * p.ldd + (long)head * 32 + 4 * kg;
+                *reinterpret_cast<f32x4*>(p.dv + o) = av0;
+                *reinterpret_cast<f32x4*>(p.dv + o + 16) = av1;
+                *reinterpret_cast<f32x4*>(p.dk + o) = ak0;
+                *reinterpret_cast<f32x4*>(p.dk + o + 16) = ak1;
+            }
+        }
+        __syncthreads();                              // the images are free for the next problem
+    }
+}
+
+}  // namespace
+
+// LIME_PP_NOT_APPLICABLE: the caller takes token_attn_bwd_kernel (shapes / alignments outside this build)
+int lime_token_attention_bwd_sp(const float* q, const float* k, const float* v, long ld, const float* dout, long ldo, float* dq, float* dk,
+                                float* dv, long ldd, int n_seq, int S, int n_head, int head_dim, int head_stride, float scale,
+                                const LimeDropout& drop, hipStream_t s) {
+    if (!(S > 64 && S <= SPB && S % 4 == 0 && head_stride == 32 && head_dim <= 32 && head_dim % 2 == 0)) return LIME_PP_NOT_APPLICABLE;
+    if (ld % 4 != 0 || ldd % 4 != 0 || ldo % 2 != 0) return LIME_PP_NOT_APPLICABLE;
+    if (((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)dq) | ((uintptr_t)dk) | ((uintptr_t)dv)) & 15) != 0 || (((uintptr_t)dout) & 7) != 0)
+        return LIME_PP_NOT_APPLICABLE;
+    static_assert(LDS_BYTES <= 163840, "LDS budget");
+    static bool configured = false;
+    static int n_cu = 256;
+    if (!configured) {
+        const hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_sp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        LIME_REQUIRE(e == hipSuccess, LIME_ERR_LAUNCH, "lime_token_attention_bwd_f32: cannot reserve %d bytes of LDS: %s", LDS_BYTES,
+                     hipGetErrorString(e));
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            n_cu = cus;
+        configured = true;
+    }
+    const long n_prob = (long)n_seq * n_head;
+    BwdSpP p{q, k, v, ld, dout, ldo, dq, dk, dv, ldd, n_seq, S, n_head, head_dim, scale, drop};
+    attn_bwd_sp_kernel<<<(unsigned)(n_prob < n_cu ? n_prob : n_cu), 512, LDS_BYTES, s>>>(p);
+    return lime_check_launch("attn_bwd_sp_kernel");
+}

@@ -609,7 +609,7 @@ def compact_run(prep, table, pe, transformer, nhead, pooled_out):
             continue
         blocks = ops.linear(h, layer.linear2.weight, layer.linear2.bias, res=x1, ln=(layer.norm2.weight, layer.norm2.bias),
                             ln_eps=layer.norm2.eps, pool32=True, m_dev=cmp.n_rows)                     # [cap / 32, E] block means
-    pooled_c = blocks if S == 32 else ops.mean_pool(blocks, M + 1, S // 32)
+    pooled_c = blocks if S == 32 else ops.mean_pool(blocks, M + 1, S // 32, n_seq_dev=cmp.n_compact)
     ops.gather_rows(cmp.seq_inv, pooled_c, pooled_out)
     return None
 
@@ -760,7 +760,7 @@ def encode_tokens_bf16_compact(ids, table_bf16, pe, transformer, nhead, pooled_o
                                         res_kind=2, res_ids=cmp.ids_c, w1p=w1p, w2p=w2p, b2=layer.linear2.bias,
                                         ln2=(layer.norm2.weight, layer.norm2.bias), ln2_eps=layer.norm2.eps, E=E, pool32=True,
                                         m_dev=cmp.n_rows)                       # fp32 [cap / 32, EP] block means
-        pooled_c = ops.mean_pool(blocks[:, :E], M + 1, S // 32)
+        pooled_c = ops.mean_pool(blocks[:, :E], M + 1, S // 32, n_seq_dev=cmp.n_compact)
         ops.gather_rows(cmp.seq_inv, pooled_c, pooled_out)
         return None
     if _inproj_applicable(3 * W, EP):
@@ -781,7 +781,7 @@ def encode_tokens_bf16_compact(ids, table_bf16, pe, transformer, nhead, pooled_o
                                         layer.norm1.eps, res=table_bf16, res_kind=2, res_ids=cmp.ids_c, w1p=w1p,
                                         w2p=w2p, b2=layer.linear2.bias, ln2=(layer.norm2.weight, layer.norm2.bias), ln2_eps=layer.norm2.eps,
                                         E=E, pool32=True, m_dev=cmp.n_rows)     # fp32 [cap / 32, EP] block means
-        pooled_c = ops.mean_pool(blocks[:, :E], M + 1, S // 32)
+        pooled_c = ops.mean_pool(blocks[:, :E], M + 1, S // 32, n_seq_dev=cmp.n_compact)
         ops.gather_rows(cmp.seq_inv, pooled_c, pooled_out)
         return None
     w_o = ops.to_bf16(sa.out_proj.weight, rows_out=EP, cols_out=EP)
@@ -797,7 +797,7 @@ def encode_tokens_bf16_compact(ids, table_bf16, pe, transformer, nhead, pooled_o
         blocks = ops.linear_bf16(h, ops.to_bf16(layer.linear2.weight, rows_out=EP), padv(layer.linear2.bias), res=x1, res_kind=3,
                                  ln=(padv(layer.norm2.weight), padv(layer.norm2.bias)), ln_eps=layer.norm2.eps, ln_count=E, pool32=True,
                                  n_alg=E, m_dev=cmp.n_rows)
-    pooled_c = ops.mean_pool(blocks[:, :E], M + 1, S // 32)
+    pooled_c = ops.mean_pool(blocks[:, :E], M + 1, S // 32, n_seq_dev=cmp.n_compact)
     ops.gather_rows(cmp.seq_inv, pooled_c, pooled_out)
     return None
 

@@ -331,7 +331,9 @@ def pad_heads(src, n_blk, head_dim, head_stride):
     return dst.view(-1) if vec else dst
 
 
-def mean_pool(x, n_seq, S, out=None):
+def mean_pool(x, n_seq, S, out=None, n_seq_dev=None):
+    """out[s] = mean of the S rows of sequence s.  n_seq_dev: optional device-side int32 count (a compacted batch): only the
+    first min(n_seq, count) sequences are read and written."""
     lib = _lib.load()
     _mat(x, 'x')
     if x.shape[0] != n_seq * S:
@@ -340,7 +342,12 @@ def mean_pool(x, n_seq, S, out=None):
     if out is None:
         out = torch.empty((n_seq, dim), dtype=torch.float32, device=x.device)
     _mat(out, 'out')
-    check(lib.lime_mean_pool_f32(_p(x), _ld(x), _p(out), _ld(out), n_seq, S, dim, _stream()), 'lime_mean_pool_f32')
+    if n_seq_dev is not None:
+        _vec(n_seq_dev, 'n_seq_dev', dtype=torch.int32)
+        check(lib.lime_mean_pool_count_f32(_p(x), _ld(x), _p(out), _ld(out), n_seq, S, dim, _p(n_seq_dev), _stream()),
+              'lime_mean_pool_count_f32')
+    else:
+        check(lib.lime_mean_pool_f32(_p(x), _ld(x), _p(out), _ld(out), n_seq, S, dim, _stream()), 'lime_mean_pool_f32')
     return out
 
 

@@ -124,11 +124,13 @@ def test_relu_bwd(ops):
 
 @pytest.mark.parametrize('n_seq,S,nh,hd,hs', [(3, 16, 10, 30, 32), (5, 32, 10, 30, 32), (2, 50, 4, 20, 20), (3, 64, 10, 30, 32),
                                               (2, 128, 10, 30, 32), (1, 100, 2, 32, 32), (37, 32, 10, 30, 32),
-                                              (2, 512, 10, 30, 32), (3, 200, 3, 30, 32), (1, 129, 2, 20, 20), (2, 256, 4, 32, 32)])
+                                              (2, 512, 10, 30, 32), (3, 200, 3, 30, 32), (1, 129, 2, 20, 20), (2, 256, 4, 32, 32),
+                                              (30, 128, 10, 30, 32), (3, 96, 10, 30, 32), (2, 68, 4, 30, 32), (2, 70, 4, 30, 32)])
 @pytest.mark.parametrize('split', [True, False], ids=['split_product', 'fp32_mfma'])
 def test_token_attention_bwd(ops, n_seq, S, nh, hd, hs, split):
-    """split=True (the default setting): the forward for S = 32 / 64 / 128 and, for S > 128, the row statistics and the Q K^T / dO V^T
-    products of the blocked backward run as split products on the bf16 matrix cores; split=False: every product on the fp32 MFMA."""
+    """split=True (the default setting): the forward for S = 32 / 64 / 128, the whole one-pass backward for 64 < S <= 128 (S % 4 == 0, heads
+    32 columns apart: token_attn_bwd_sp_f32.hip) and, for S > 128, the row statistics and the Q K^T / dO V^T products of the blocked
+    backward run as split products on the bf16 matrix cores; split=False: every product on the fp32 MFMA."""
     prev = ops.set_split_gemm(split)
     try:
         _attention_bwd_case(ops, n_seq, S, nh, hd, hs)

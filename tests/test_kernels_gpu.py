@@ -922,3 +922,21 @@ def test_cand_attn_weights_shared_history(ops):
     full = ops.cand_attn_weights(qp.view(-1), kp.view(Bh, H * D).repeat_interleave(K, dim=0).reshape(-1), dev(mask.repeat_interleave(K, dim=0)),
                                  B, N, H, D, nh)
     assert torch.equal(shared, full)
+
+
+@pytest.mark.parametrize('S', [2, 3, 4, 8, 16])
+def test_mean_pool_counted(ops, S):
+    """lime_mean_pool_count_f32: the first *n_seq_dev sequences bit-equal to lime_mean_pool_f32's rows, nothing written behind the count."""
+    n_seq, E = 700, 300
+    x = dev(rnd(n_seq * S, 304, seed=S))[:, :E]
+    full = ops.mean_pool(x, n_seq, S)
+    want = x.view(n_seq, S, E).double().mean(dim=1)
+    assert rel_err(full.cpu().numpy(), want.cpu().numpy()) < 1e-6
+    for live in (0, 1, 333, 700, 900):
+        out = torch.full((n_seq, E), -7.0, device='cuda')
+        ops.mean_pool(x, n_seq, S, out=out, n_seq_dev=torch.tensor([live], dtype=torch.int32, device='cuda'))
+        k = min(live, n_seq)
+        assert torch.equal(out[:k], full[:k])
+        assert bool((out[k:] == -7.0).all())
+    with pytest.raises(Exception):
+        ops.mean_pool(dev(rnd(4 * 32, 300, seed=1)), 4, 32, n_seq_dev=torch.tensor([2], dtype=torch.int32, device='cuda'))
