@@ -15,7 +15,7 @@
 //       dV^T[d, j] = sum_i dO^T[d, i] P~[i, j],   dK^T[d, j] = sum_i Q^T[d, i] dS[i, j]
 // Seven products instead of five, all at the split rate (56 blocks x 96 cycles per wave against 40 x 256), ONE barrier between
 // the phases, no P image.  Q, K, V, dO are split once per (sequence, head) on their way into LDS: three bf16 images [128][32]
-// each (pitch 80 B).  The row-major image serves both operand kinds: as rows (ds_read_b128: eight consecutive head dims of one
+// each (64-byte rows, chunks swizzled: below).  The row-major image serves both operand kinds: as rows (ds_read_b128: eight consecutive head dims of one
 // token) for the score products, and TRANSPOSED for the gradient products through ds_read_b64_tr_b16 -- per 16-lane group a block
 // of four token rows x 16 head dims, delivered column-major: lane fi gets head dim fi of rows 4 kg .. 4 kg + 3 of a 16-row tile,
 // which is exactly the k order the result registers carry.  The results come out transposed (head dims on the registers): a lane
@@ -33,7 +33,8 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int SPB = 128;                              // rows per image
-constexpr int TERM = SPB * SPLIT_PITCH;               // one bf16 image (unsigned shorts)
+constexpr int ROW = 32;                               // image rows: 32 bf16 = 64 bytes = four 16-byte chunks
+constexpr int TERM = SPB * ROW;                       // one bf16 image (unsigned shorts)
 constexpr int IMG = 3 * TERM;                         // the three terms of one operand
 constexpr int LDS_BYTES = 4 * IMG * 2 + 3 * SPB * 4;  // Q, K, V, dO + the row statistics
 
@@ -49,16 +50,34 @@ struct BwdSpP {
     LimeDropout drop;
 };
 
+// Image layout: row r = 64 bytes, its 16-byte chunk ch at position ch ^ swz(r), swz(r) = 2 * bit 2 of r + bit 3 of r.  Rows 4 apart
+// share their banks (64-byte rows, 64 banks): bit 2 moves them to the other half of the bank group, bit 3 to the other chunk of the
+// half -- the row reads (ds_read_b128: 16 lanes = 16 rows, one chunk), the transposed block reads (a 32-lane half = 8 consecutive
+// rows x 32 bytes) and the 8-byte staging writes are all conflict free.
+__device__ __forceinline__ int swz(int r) { return ((r >> 1) & 2) | ((r >> 3) & 1); }
+__device__ __forceinline__ int img_off(int r, int c) { return r * ROW + (((c >> 3) ^ swz(r)) << 3) + (c & 7); }
+
+// the fragment of row r, k values 8 kg .. 8 kg + 7 (one chunk)
+__device__ __forceinline__ SplitFrag row_load(const unsigned short* img, int r, int kg) {
+    const unsigned short* const p = img + r * ROW + ((kg ^ swz(r)) << 3);
+    SplitFrag f;
+    f.h = *reinterpret_cast<const bf16x8*>(p);
+    f.m = *reinterpret_cast<const bf16x8*>(p + TERM);
+    f.l = *reinterpret_cast<const bf16x8*>(p + 2 * TERM);
+    return f;
+}
+
 // the A operand (rows = head dims 16 c + fi) of a product that sums over token rows: k values = rows 16 t0 + 4 kg + {0..3} and
-// 16 (t0 + 1) + 4 kg + {0..3} of the row-major image -- two transposed block reads per term.  `p0` is this lane's address in
-// the first block (row 16 t0 + 4 kg + (fi >> 2), column 16 c + 4 (fi & 3)); EXEC is all ones at every call.
+// 16 (t0 + 1) + 4 kg + {0..3} of the row-major image -- two transposed block reads per term (ds_read_b64_tr_b16: lane 4 q + p of a
+// 16-lane group supplies the address of row q, columns 4 p .. 4 p + 3 of the block and receives column (lane & 15) of its four rows).
+// The swizzle is the same for the rows of a block and for rows 16 apart.  EXEC is all ones at every call.
 __device__ __forceinline__ bf16x8 tr_pair(const unsigned short* p0) {
     const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
-    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 16 * SPLIT_PITCH));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 16 * ROW));
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 __device__ __forceinline__ SplitFrag tr_load(const unsigned short* img, int t0, int c, int fi, int kg) {
-    const unsigned short* const p0 = img + (16 * t0 + 4 * kg + (fi >> 2)) * SPLIT_PITCH + 16 * c + 4 * (fi & 3);
+    const unsigned short* const p0 = img + img_off(16 * t0 + 4 * kg + (fi >> 2), 16 * c + 4 * (fi & 3));
     SplitFrag f;
     f.h = tr_pair(p0);
     f.m = tr_pair(p0 + TERM);
@@ -66,6 +85,7 @@ __device__ __forceinline__ SplitFrag tr_load(const unsigned short* img, int t0, 
     return f;
 }
 
+template <bool FULL>      // S == 128: no rows beyond S to mask
 __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const BwdSpP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
     unsigned short* const Qi = smem;
@@ -82,6 +102,7 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const BwdSpP p) {
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     const float c2 = p.scale * LOG2E;
     const bool dropping = p.drop.thresh != 0;
+    constexpr bool full = FULL;
 
     // the next problem's rows travel in registers while this one computes: q / k / v rows are 32 floats on 16-byte boundaries (heads
     // 32 columns apart, zero pad columns), dO rows head_dim floats on 8-byte boundaries
@@ -117,19 +138,21 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const BwdSpP p) {
             const int e = tid + 512 * u, r = e >> 3, c = (e & 7) * 4;
             u32x2 h, m, l;
             split_quad(rq[u][0], rq[u][1], rq[u][2], rq[u][3], h, m, l);
-            unsigned short* d = Qi + r * SPLIT_PITCH + c;
+            unsigned short* d = Qi + img_off(r, c);
             *reinterpret_cast<u32x2*>(d) = h; *reinterpret_cast<u32x2*>(d + TERM) = m; *reinterpret_cast<u32x2*>(d + 2 * TERM) = l;
             split_quad(rk[u][0], rk[u][1], rk[u][2], rk[u][3], h, m, l);
-            d = Ki + r * SPLIT_PITCH + c;
+            d = Ki + img_off(r, c);
             *reinterpret_cast<u32x2*>(d) = h; *reinterpret_cast<u32x2*>(d + TERM) = m; *reinterpret_cast<u32x2*>(d + 2 * TERM) = l;
             split_quad(rv[u][0], rv[u][1], rv[u][2], rv[u][3], h, m, l);
-            d = Vi + r * SPLIT_PITCH + c;
+            d = Vi + img_off(r, c);
             *reinterpret_cast<u32x2*>(d) = h; *reinterpret_cast<u32x2*>(d + TERM) = m; *reinterpret_cast<u32x2*>(d + 2 * TERM) = l;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = tid + 512 * u, r = e >> 4, c = (e & 15) * 2;
-            split_store2(Oi, TERM, r, c, ro[u][0], ro[u][1]);
+            const SplitPair t = split_pair(ro[u][0], ro[u][1]);
+            unsigned short* const d = Oi + img_off(r, c);
+            *reinterpret_cast<unsigned*>(d) = t.h; *reinterpret_cast<unsigned*>(d + TERM) = t.m; *reinterpret_cast<unsigned*>(d + 2 * TERM) = t.l;
         }
     };
 
@@ -137,7 +160,7 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const BwdSpP p) {
     for (long prob = blockIdx.x; prob < n_prob; prob += gridDim.x) {
         const int seq = (int)(prob / p.n_head), head = (int)(prob % p.n_head);
         commit();
-        __syncthreads();
+        lds_barrier();                                // (LDS only: the dq / dk / dv stores and the prefetch stay in flight)
         if (prob + gridDim.x < n_prob) fetch(prob + gridDim.x);
         // per-lane offsets are recomputed per problem from a laundered lane id: hoisted out of this loop they are ~100 registers of
         // loop-invariant addresses and mask indices (spilled)
@@ -147,69 +170,73 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const BwdSpP p) {
         const int X0 = 16 * __builtin_amdgcn_readfirstlane(tl >> 6);      // this wave's 16 queries (phase A) / keys (phase B)
 
         // ================= phase A: this wave's queries on the columns =================================================
+        // Every loop body pairs one tile's MFMAs with the arithmetic of the tile before it (independent instruction streams in one
+        // scheduling region): the two waves of a SIMD run the same code in step, so whatever is not interleaved inside a wave is serial.
         {
             const int fi = lane & 15, kg = lane >> 4;
-            const SplitFrag qB = split_load(Qi, TERM, X0 + fi, kg), oB = split_load(Oi, TERM, X0 + fi, kg);
-            f32x4 st[8], dt[8];                       // S^T / P^T and dP^T / dS^T: [key 16 t + 4 kg + r][query X0 + fi]
-            SplitFrag kA[2], vA[2];                   // the next tile's fragments are requested before this tile's MFMAs
-            kA[0] = split_load(Ki, TERM, fi, kg); vA[0] = split_load(Vi, TERM, fi, kg);
+            const SplitFrag qB = row_load(Qi, X0 + fi, kg), oB = row_load(Oi, X0 + fi, kg);
+            f32x4 st[8], dt[8];                       // S^T -> exp2 terms, dP^T -> dS^T: [key 16 t + 4 kg + r][query X0 + fi]
+            SplitFrag fa[2];                          // the next tile's fragments are requested before this tile's MFMAs
+            // ---- S^T = K Q^T and the row maximum (on the raw scores: scale > 0)
+            float mxr = -INFINITY;
+            auto tile_max = [&](int t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mxr = fmaxf(mxr, (full || 16 * t + 4 * kg + r < S) ? st[t][r] : -INFINITY);
+            };
+            fa[0] = row_load(Ki, fi, kg);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                if (t + 1 < 8) { kA[(t + 1) & 1] = split_load(Ki, TERM, 16 * (t + 1) + fi, kg); vA[(t + 1) & 1] = split_load(Vi, TERM, 16 * (t + 1) + fi, kg); }
-                st[t] = split_mfma16(kA[t & 1], qB, z4);
-                dt[t] = split_mfma16(vA[t & 1], oB, z4);
-                __builtin_amdgcn_sched_barrier(0);    // two tiles' fragments at a time (unrolled, hipcc hoists all 192 registers of them)
+                if (t + 1 < 8) fa[(t + 1) & 1] = row_load(Ki, 16 * (t + 1) + fi, kg);
+                st[t] = split_mfma16(fa[t & 1], qB, z4);
+                if (t > 0) tile_max(t - 1);
+                __builtin_amdgcn_sched_barrier(0);    // (unrolled: hipcc otherwise hoists all the fragments, 192 registers)
             }
-            float mx = -INFINITY;
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float sv = (16 * t + 4 * kg + r < S) ? st[t][r] * c2 : -INFINITY;
-                    st[t][r] = sv;
-                    mx = fmaxf(mx, sv);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
-            float sum = 0.f;
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(st[t][r] - mx);
-                    st[t][r] = e;
-                    sum += e;
-                }
-            sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
-            const float inv = 1.0f / sum;
-            // the forward multiplied keep * P / (1 - p) into V: dP~ = keep * dP / (1 - p), delta = sum_j P dP~, dS = scale P (dP~ - delta)
+            tile_max(7);
+            mxr = fmaxf(mxr, __shfl_xor(mxr, 16)); mxr = fmaxf(mxr, __shfl_xor(mxr, 32));
+            const float mx = mxr * c2, nmx = -mx;
+            // ---- dP^T = V dO^T;  e = exp2(s - max), sum e, sum e dP~  (dP~ = keep * dP / (1 - p): the forward multiplied keep * P / (1 - p) into V)
             const uint64_t mrow = ((uint64_t)prob * S + (uint64_t)(X0 + fi)) * (uint64_t)S;
-            float dl = 0.f;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            float sum = 0.f, dlu = 0.f;
+            auto tile_exp = [&](int t) {
                 const unsigned keep = dropping ? lime_keep4(p.drop, (mrow + (uint64_t)(16 * t + 4 * kg)) >> 2) : 0xFu;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = st[t][r] * inv;
+                    const float e = (full || 16 * t + 4 * kg + r < S) ? __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][r], c2, nmx)) : 0.f;
                     const float dpv = dropping ? ((keep >> r) & 1u ? dt[t][r] * p.drop.scale : 0.f) : dt[t][r];
-                    st[t][r] = pv;
+                    st[t][r] = e;
                     dt[t][r] = dpv;
-                    dl += pv * dpv;
+                    sum += e;
+                    dlu = __builtin_fmaf(e, dpv, dlu);
                 }
+            };
+            fa[0] = row_load(Vi, fi, kg);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t + 1 < 8) fa[(t + 1) & 1] = row_load(Vi, 16 * (t + 1) + fi, kg);
+                dt[t] = split_mfma16(fa[t & 1], oB, z4);
+                if (t > 0) tile_exp(t - 1);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            dl += __shfl_xor(dl, 16); dl += __shfl_xor(dl, 32);
-            if (kg == 0) { st_mx[X0 + fi] = mx; st_inv[X0 + fi] = inv; st_dl[X0 + fi] = dl; }
+            tile_exp(7);
+            sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+            dlu += __shfl_xor(dlu, 16); dlu += __shfl_xor(dlu, 32);
+            const float inv = 1.0f / sum, dl = dlu * inv, si = p.scale * inv, ndl = -dl * si;
+            if (kg == 0) { st_mx[X0 + fi] = mx; st_inv[X0 + fi] = inv; st_dl[X0 + fi] = dl * p.scale; }
+            // ---- dS^T = scale P (dP~ - delta);  dQ^T[d, i] = sum_j K^T[d, j] dS^T[j, i]: a step's twelve MFMAs beside the next step's
+            // dS^T and its split
+            auto pair_ds = [&](int s2) {
+                float x[8];
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dt[t][r] = p.scale * st[t][r] * (dt[t][r] - dl);
-            // dQ^T[d, i] = sum_j K^T[d, j] dS^T[j, i]
+                for (int e = 0; e < 8; ++e) x[e] = st[2 * s2 + (e >> 2)][e & 3] * __builtin_fmaf(dt[2 * s2 + (e >> 2)][e & 3], si, ndl);
+                return split_frag(x);
+            };
             f32x4 aq0 = z4, aq1 = z4;
-            SplitFrag b[2];                           // a step: K^T fragments requested, the NEXT step's dS^T registers split under that
-            b[0] = split_frag(dt[0], dt[1]);          // latency, then the step's twelve MFMAs
+            SplitFrag b[2];
+            b[0] = pair_ds(0);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const SplitFrag a0 = tr_load(Ki, 2 * s, 0, fi, kg), a1 = tr_load(Ki, 2 * s, 1, fi, kg);
-                if (s + 1 < 4) b[(s + 1) & 1] = split_frag(dt[2 * s + 2], dt[2 * s + 3]);
+                if (s + 1 < 4) b[(s + 1) & 1] = pair_ds(s + 1);
                 aq0 = split_mfma16(a0, b[s & 1], aq0);
                 aq1 = split_mfma16(a1, b[s & 1], aq1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -220,27 +247,17 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const BwdSpP p) {
                 *reinterpret_cast<f32x4*>(d + 16) = aq1;
             }
         }
-        __syncthreads();                              // every query's statistics are in LDS
+        lds_barrier();                                // every query's statistics are in LDS
 
         // ================= phase B: this wave's keys on the columns ====================================================
         {
             asm volatile("" : "+v"(lane));
             const int fi = lane & 15, kg = lane >> 4;
-            const SplitFrag kB = split_load(Ki, TERM, X0 + fi, kg), vB = split_load(Vi, TERM, X0 + fi, kg);
-            f32x4 pt[8], ds[8];                       // S / P~ and dP / dS: [query 16 t + 4 kg + r][key X0 + fi]
-            SplitFrag qA[2], oA[2];
-            qA[0] = split_load(Qi, TERM, fi, kg); oA[0] = split_load(Oi, TERM, fi, kg);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                if (t + 1 < 8) { qA[(t + 1) & 1] = split_load(Qi, TERM, 16 * (t + 1) + fi, kg); oA[(t + 1) & 1] = split_load(Oi, TERM, 16 * (t + 1) + fi, kg); }
-                pt[t] = split_mfma16(qA[t & 1], kB, z4);
-                ds[t] = split_mfma16(oA[t & 1], vB, z4);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            const SplitFrag kB = row_load(Ki, X0 + fi, kg), vB = row_load(Vi, X0 + fi, kg);
+            f32x4 pt[8], ds[8];                       // S -> P~ and dP -> dS: [query 16 t + 4 kg + r][key X0 + fi]
             const bool key_ok = X0 + fi < S;
             const int jq = (X0 + fi) >> 2, jb = fi & 3;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            auto tile_pds = [&](int t) {
                 const f32x4 mx4 = *reinterpret_cast<const f32x4*>(st_mx + 16 * t + 4 * kg);
                 const f32x4 inv4 = *reinterpret_cast<const f32x4*>(st_inv + 16 * t + 4 * kg);
                 const f32x4 dl4 = *reinterpret_cast<const f32x4*>(st_dl + 16 * t + 4 * kg);
@@ -258,14 +275,24 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const BwdSpP p) {
                 const unsigned kr[4] = {k0, k1, k2, k3};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = key_ok ? __builtin_amdgcn_exp2f(pt[t][r] * c2 - mx4[r]) * inv4[r] : 0.f;
+                    const float pv = (full || key_ok) ? __builtin_amdgcn_exp2f(__builtin_fmaf(pt[t][r], c2, -mx4[r])) * inv4[r] : 0.f;
                     const float f = dropping ? ((kr[r] >> jb) & 1u ? p.drop.scale : 0.f) : 1.f;
-                    const float dpv = ds[t][r] * f;
-                    pt[t][r] = pv * f;
-                    ds[t][r] = p.scale * pv * (dpv - dl4[r]);
+                    const float dpv = dropping ? ds[t][r] * f : ds[t][r];
+                    pt[t][r] = dropping ? pv * f : pv;
+                    ds[t][r] = pv * __builtin_fmaf(dpv, p.scale, -dl4[r]);        // st_dl holds scale * delta
                 }
+            };
+            SplitFrag qA[2], oA[2];
+            qA[0] = row_load(Qi, fi, kg); oA[0] = row_load(Oi, fi, kg);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t + 1 < 8) { qA[(t + 1) & 1] = row_load(Qi, 16 * (t + 1) + fi, kg); oA[(t + 1) & 1] = row_load(Oi, 16 * (t + 1) + fi, kg); }
+                pt[t] = split_mfma16(qA[t & 1], kB, z4);
+                ds[t] = split_mfma16(oA[t & 1], vB, z4);
+                if (t > 0) tile_pds(t - 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            tile_pds(7);
             // dV^T[d, j] = sum_i dO^T[d, i] P~[i, j];  dK^T[d, j] = sum_i Q^T[d, i] dS[i, j]
             f32x4 av0 = z4, av1 = z4, ak0 = z4, ak1 = z4;
             SplitFrag b[2];
@@ -294,7 +321,7 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const BwdSpP p) {
                 *reinterpret_cast<f32x4*>(p.dk + o + 16) = ak1;
             }
         }
-        __syncthreads();                              // the images are free for the next problem
+        lds_barrier();                                // the images are free for the next problem
     }
 }
 
@@ -312,7 +339,8 @@ int lime_token_attention_bwd_sp(const float* q, const float* k, const float* v, 
     static bool configured = false;
     static int n_cu = 256;
     if (!configured) {
-        const hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_sp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_sp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_sp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         LIME_REQUIRE(e == hipSuccess, LIME_ERR_LAUNCH, "lime_token_attention_bwd_f32: cannot reserve %d bytes of LDS: %s", LDS_BYTES,
                      hipGetErrorString(e));
         int dev = 0, cus = 0;
@@ -322,6 +350,8 @@ int lime_token_attention_bwd_sp(const float* q, const float* k, const float* v, 
     }
     const long n_prob = (long)n_seq * n_head;
     BwdSpP p{q, k, v, ld, dout, ldo, dq, dk, dv, ldd, n_seq, S, n_head, head_dim, scale, drop};
-    attn_bwd_sp_kernel<<<(unsigned)(n_prob < n_cu ? n_prob : n_cu), 512, LDS_BYTES, s>>>(p);
+    const unsigned grid = (unsigned)(n_prob < n_cu ? n_prob : n_cu);             // persistent: one workgroup per CU
+    if (S == SPB) attn_bwd_sp_kernel<true><<<grid, 512, LDS_BYTES, s>>>(p);
+    else attn_bwd_sp_kernel<false><<<grid, 512, LDS_BYTES, s>>>(p);
     return lime_check_launch("attn_bwd_sp_kernel");
 }
