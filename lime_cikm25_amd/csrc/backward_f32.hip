@@ -1294,32 +1294,39 @@ __global__ __launch_bounds__(512) void attn_bwd_long_kernel(const float* __restr
     }
 }
 
-// The blocked backward with Q K^T and dO V^T as split products on the bf16 matrix cores (lime_set_split_gemm(1), the default): the
-// key block's K and V are staged once as three bf16 images each (split_mfma.h), the wave's Q / dO rows are split in registers, a
-// 16 x 16 tile of S or dP costs six 16x16x32 MFMAs (96 cycles) instead of eight fp32 ones (256); dV, dK and dQ -- whose P / dS
-// operand would have to be split per use -- stay on the fp32 MFMA.  The images take 60 KB, so the query side goes in blocks of 64
-// rows (P / dS image 33 KB): phase 1 wave w = query tile w & 3 x key half w >> 2; dV / dK wave w = keys 16 w .. 16 w + 15 as in
-// attn_bwd_long_kernel; dQ wave w = query tile w & 3 x head-dim half w >> 2.  Same slabs, same reduction order over key blocks.
-constexpr int LQ = 64;
-template <int SP_LDP, int SP_AB>
-__global__ __launch_bounds__(512) void attn_bwd_long_sp_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                                const float* __restrict__ v, long ld, const float* __restrict__ dout,
-                                                                long ldo, const float* __restrict__ stats, float* __restrict__ dq,
-                                                                float* __restrict__ dk, float* __restrict__ dv, long ldd, int S,
-                                                                int n_head, int head_dim, int head_stride, float scale, int n_blk,
-                                                                LimeDropout drop, float* __restrict__ dq_slabs, long n_tok) {
+// The blocked backward with all five products as split products on the bf16 matrix cores (lime_set_split_gemm(1), the default;
+// split_mfma.h: six 16x16x32 MFMAs per 16 x 16 x 32 block, 96 matrix cycles against the 256 of eight fp32 ones).  The key block's K and
+// V are staged once, the query side goes in blocks of 64 rows; K, V, Q, dO are swizzled split images that serve row reads and transposed
+// reads (split_mfma.h).  Wave w owns the keys 16 w .. 16 w + 15 of the block:
+//   S = Q K^T and dP = dO V^T for its 16 keys x the 64 queries: result tiles with the KEY on the lane and the queries on the registers --
+//   so P~ and dS are, as they stand (split in registers), the B operands of the two products that sum over the queries:
+//   dV^T[d, j] += sum_i dO^T[d, i] P~[i, j],  dK^T[d, j] += sum_i Q^T[d, i] dS[i, j]   (dO^T / Q^T: ds_read_b64_tr_b16 block reads),
+//   accumulated in registers over the query blocks, no P image, no barrier between the score products and these.
+//   dQ sums over the keys -- the other orientation: dS goes through an fp32 image once ([query][key], 528-byte rows); wave w = query tile
+//   w & 3 x head-dim half w >> 2 reads its queries' rows back as B operands (two ds_read_b128 per step, split in registers) against K^T
+//   (transposed block reads of the K image): dQ^T[d, i] = sum_j K^T[d, j] dS^T[j, i].  Slabs per key block and the reduction order over
+//   key blocks as before.
+// FOUR-wave workgroups, TWO per CU (77 KB of LDS each): the phases of a query block are short and separated by barriers, so one lock-step
+// workgroup per CU left the matrix pipe, the VALU and the LDS each 25-40 % busy one after the other (profiles/r03_attn_bwd_sp_counters.txt);
+// two independent workgroups overlap them.  Wave w owns the keys 32 w .. 32 w + 31 (two 16-key tiles), the query side goes in blocks
+// of 32 rows.  Three barriers per query block, 960 matrix cycles per wave and block (dV / dK / dQ on the fp32 MFMA: 3072).
+constexpr int LQ = 32;
+template <int SP_LDP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_long_sp_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                   const float* __restrict__ v, long ld, const float* __restrict__ dout,
+                                                                   long ldo, const float* __restrict__ stats, float* __restrict__ dq,
+                                                                   float* __restrict__ dk, float* __restrict__ dv, long ldd, int S,
+                                                                   int n_head, int head_dim, int head_stride, float scale, int n_blk,
+                                                                   LimeDropout drop, float* __restrict__ dq_slabs, long n_tok) {
     using namespace lime_dev;
-    // LDS pitches (template parameters for A/B runs): 48 % of this kernel's LDS cycles are bank conflicts of the 16x16x4 fragment walks
-    // (profiles/r03_sp_kernel_counters.txt), but pitches that remove them (P / dS image 145 or 148 or 180 floats, operand images 48)
-    // measured 0 .. +4 % kernel time on one box (profiles/r03_notes.md): the fp32 products of dV / dK / dQ bound it, not the LDS.
-    constexpr int LDP = SP_LDP, AB = SP_AB, TS = LB * SPLIT_PITCH;
+    constexpr int LDP = SP_LDP, KT = LB * SWZ_ROW, QT = LQ * SWZ_ROW;
+    static_assert(LDP % 4 == 0, "16-byte aligned dS rows");
     extern __shared__ float smem[];
-    unsigned short* const Kt = reinterpret_cast<unsigned short*>(smem);       // three bf16 images of the K block
-    unsigned short* const Vt = Kt + 3 * TS;
-    float* const Ks = smem + 3 * TS;             // (2 x 3 TS bf16 = 3 TS floats) the K block in fp32: the B operand of dQ
-    float* const Qs = Ks + LB * AB;           // [LQ][AB]
-    float* const Os = Qs + LQ * AB;
-    float* const Ps = Os + LQ * AB;           // [LQ][LDP]: P, then dS
+    unsigned short* const Kt = reinterpret_cast<unsigned short*>(smem);       // three swizzled bf16 images of the K block, [LB][32]
+    unsigned short* const Vt = Kt + 3 * KT;
+    unsigned short* const Qi = Vt + 3 * KT;      // ... of the query block's Q rows, [LQ][32]
+    unsigned short* const Oi = Qi + 3 * QT;      // ... and of its dO rows
+    float* const Ps = smem + 3 * KT + 3 * QT;    // (2 x 3 KT + 2 x 3 QT bf16) [LQ][LDP]: dS
     float* const Ls = Ps + LQ * LDP;
     float* const Ds = Ls + LQ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, kg = lane >> 4;
@@ -1328,26 +1335,29 @@ __global__ __launch_bounds__(512) void attn_bwd_long_sp_kernel(const float* __re
     const int seq = (int)(prob / n_head), head = (int)(prob % n_head);
     const long row_base = (long)seq * S;
     const int k0 = kb * LB, k_valid = min(LB, S - k0);
-    const int R0 = 16 * wave, qi = wave & 3, hh = wave >> 2;
-    for (int e = tid; e < LB * 32; e += 512) {      // the fp32 K block, pitch AB
-        const int r = e >> 5, c = e & 31;
-        Ks[r * AB + c] = (r < k_valid && c < head_dim) ? k[(row_base + k0 + r) * ld + head * head_stride + c] : 0.f;
+    const int R0 = 32 * wave, qi = wave & 1, hh = wave >> 1;
+    for (int e = tid; e < LB * 16; e += 256) {      // K and V rows -> split images (zero outside the valid rows / columns)
+        const int r = e >> 4, c = (e & 15) * 2;
+        const bool ok0 = r < k_valid && c < head_dim, ok1 = r < k_valid && c + 1 < head_dim;
+        const long g = (row_base + k0 + (r < k_valid ? r : 0)) * ld + head * head_stride + c;
+        swz_store2(Kt, KT, r, c, ok0 ? k[g] : 0.f, ok1 ? k[g + 1] : 0.f);
+        swz_store2(Vt, KT, r, c, ok0 ? v[g] : 0.f, ok1 ? v[g + 1] : 0.f);
     }
-    stage_rows_split(Kt, k, ld, row_base + k0, k_valid, head * head_stride, head_dim, tid);
-    stage_rows_split(Vt, v, ld, row_base + k0, k_valid, head * head_stride, head_dim, tid);
-    f32x4 av0 = {0.f, 0.f, 0.f, 0.f}, av1 = av0, ak0 = av0, ak1 = av0;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 av[2][2] = {{z4, z4}, {z4, z4}}, ak[2][2] = {{z4, z4}, {z4, z4}};   // dV^T / dK^T of key tile u: [head dim 16 c + 4 kg + r][key R0 + 16 u + fi]
     const int n_qblk = (S + LQ - 1) / LQ;
-    // the NEXT query block's Q / dO rows (4 + 4 floats per thread) and statistics wait in registers while the current block is
-    // computed: one workgroup per CU (132 KB of LDS), so nothing else would cover the global latency of the staging
+    // the NEXT query block's Q / dO rows (two pairs each per thread) and statistics wait in registers while the current block is computed
     float pq[4], po[4], pl = INFINITY, pd = 0.f;
     auto fetch_q = [&](int qb) {
         const int q0 = qb * LQ, q_valid = min(LQ, S - q0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = tid + 512 * u, r = e >> 5, c = e & 31;
-            const bool ok = r < q_valid && c < head_dim;
-            pq[u] = ok ? q[(row_base + q0 + r) * ld + head * head_stride + c] : 0.f;
-            po[u] = ok ? dout[(row_base + q0 + r) * ldo + head * head_dim + c] : 0.f;
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 256 * u, r = e >> 4, c = (e & 15) * 2;
+            const bool ok0 = r < q_valid && c < head_dim, ok1 = r < q_valid && c + 1 < head_dim;
+            const float* const qs = q + (row_base + q0 + (r < q_valid ? r : 0)) * ld + head * head_stride + c;
+            const float* const os = dout + (row_base + q0 + (r < q_valid ? r : 0)) * ldo + head * head_dim + c;
+            pq[2 * u] = ok0 ? qs[0] : 0.f; pq[2 * u + 1] = ok1 ? qs[1] : 0.f;
+            po[2 * u] = ok0 ? os[0] : 0.f; po[2 * u + 1] = ok1 ? os[1] : 0.f;
         }
         if (tid < LQ) {
             const bool ok = tid < q_valid;
@@ -1357,100 +1367,109 @@ __global__ __launch_bounds__(512) void attn_bwd_long_sp_kernel(const float* __re
         }
     };
     fetch_q(0);
+    __syncthreads();                            // the K / V images are complete
+    SplitFrag kB[2];                            // this wave's keys: every query block (the V fragments are re-read per block: registers)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) kB[u] = swz_row_load(Kt, KT, R0 + 16 * u + fi, kg);
+    const float c2 = scale * LOG2E;
     for (int qb = 0; qb < n_qblk; ++qb) {
         const int q0 = qb * LQ, q_valid = min(LQ, S - q0);
         __syncthreads();                        // the previous block's images are no longer read
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = tid + 512 * u, r = e >> 5, c = e & 31;
-            Qs[r * AB + c] = pq[u];
-            Os[r * AB + c] = po[u];
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 256 * u, r = e >> 4, c = (e & 15) * 2;
+            swz_store2(Qi, QT, r, c, pq[2 * u], pq[2 * u + 1]);
+            swz_store2(Oi, QT, r, c, po[2 * u], po[2 * u + 1]);
         }
         if (tid < LQ) { Ls[tid] = pl; Ds[tid] = pd; }
         __syncthreads();
         if (qb + 1 < n_qblk) fetch_q(qb + 1);
-        // ---- phase 1: S and dP of query tile qi x key tiles 4 hh .. 4 hh + 3 ----------------------------------------------
-        f32x4 p[4], dp[4];
+        // ---- S and dP of this wave's two key tiles x the two query tiles, then P~ and dS in place -----------------------------
+        f32x4 p[2][2], dp[2][2];                // [key tile u][query tile t]: [query 16 t + 4 kg + r][key R0 + 16 u + fi]
+        const SplitFrag vB[2] = {swz_row_load(Vt, KT, R0 + fi, kg), swz_row_load(Vt, KT, R0 + 16 + fi, kg)};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const SplitFrag qA = swz_row_load(Qi, QT, 16 * t + fi, kg), oA = swz_row_load(Oi, QT, 16 * t + fi, kg);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                p[u][t] = split_mfma16(qA, kB[u], z4);
+                dp[u][t] = split_mfma16(oA, vB[u], z4);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 lse4 = *reinterpret_cast<const f32x4*>(Ls + 16 * t + 4 * kg);
+            const f32x4 dl4 = *reinterpret_cast<const f32x4*>(Ds + 16 * t + 4 * kg);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int col = R0 + 16 * u + fi;
+                const bool key_ok = col < k_valid;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * t + 4 * kg + r;
+                    const float pv = key_ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(p[u][t][r], c2, -lse4[r])) : 0.f;
+                    float f = 1.f;
+                    if (drop.thresh != 0)
+                        f = lime_keep(drop, ((uint64_t)prob * S + (uint64_t)(q0 + row)) * (uint64_t)S + (uint64_t)(k0 + col)) ? drop.scale : 0.f;
+                    p[u][t][r] = pv * f;                                    // what the dV product needs
+                    const float dsv = scale * pv * (dp[u][t][r] * f - dl4[r]);
+                    dp[u][t][r] = dsv;
+                    Ps[row * LDP + col] = dsv;                              // for dQ (the other orientation)
+                }
+            }
+        }
+        // ---- dV^T += dO^T P~, dK^T += Q^T dS: the result registers of the two query tiles are the eight k values of the B operand ----
         {
-            float xq[8], xo[8];
+            const SplitFrag o0 = swz_tr_load(Oi, QT, 0, 0, fi, kg), o1 = swz_tr_load(Oi, QT, 0, 1, fi, kg);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                xq[j] = Qs[(16 * qi + fi) * AB + 8 * kg + j];
-                xo[j] = Os[(16 * qi + fi) * AB + 8 * kg + j];
-            }
-            const SplitFrag qs = split_frag(xq), os = split_frag(xo);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int ct = 4 * hh + c;
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                p[c] = split_mfma16(qs, split_load(Kt, TS, 16 * ct + fi, kg), z);
-                dp[c] = split_mfma16(os, split_load(Vt, TS, 16 * ct + fi, kg), z);
+            for (int u = 0; u < 2; ++u) {
+                const SplitFrag bp = split_frag(p[u][0], p[u][1]);
+                av[u][0] = split_mfma16(o0, bp, av[u][0]);
+                av[u][1] = split_mfma16(o1, bp, av[u][1]);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);      // (one pair of transposed fragments at a time: registers)
+        {
+            const SplitFrag q0f = swz_tr_load(Qi, QT, 0, 0, fi, kg), q1f = swz_tr_load(Qi, QT, 0, 1, fi, kg);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * qi + 4 * kg + r;
-            const float lse = Ls[row], dl = Ds[row];
-            const uint64_t mrow = ((uint64_t)prob * S + (uint64_t)(q0 + row)) * (uint64_t)S + (uint64_t)k0;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int col = 16 * (4 * hh + c) + fi;
-                const float pv = (col < k_valid) ? __builtin_amdgcn_exp2f(p[c][r] * (scale * LOG2E) - lse) : 0.f;
-                const float f = (drop.thresh == 0 || lime_keep(drop, mrow + (uint64_t)col)) ? drop.scale : 0.f;
-                p[c][r] = pv * f;                                    // what the dV product needs
-                dp[c][r] = scale * pv * (dp[c][r] * f - dl);         // dS
+            for (int u = 0; u < 2; ++u) {
+                const SplitFrag bd = split_frag(dp[u][0], dp[u][1]);
+                ak[u][0] = split_mfma16(q0f, bd, ak[u][0]);
+                ak[u][1] = split_mfma16(q1f, bd, ak[u][1]);
             }
         }
+        __syncthreads();                        // the dS image is complete
+        // ---- this key block's share of dQ^T (head dims 16 hh .. 16 hh + 15 x query tile qi): the k values of a step are the keys
+        // 16 t0 + 4 kg + {0..3} and 16 (t0 + 1) + 4 kg + {0..3} (the order swz_tr_load delivers K^T in) ------------------------------
+        f32x4 aq = z4;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Ps[(16 * qi + 4 * kg + r) * LDP + 16 * (4 * hh + c) + fi] = p[c][r];
-        __syncthreads();
-        // ---- phase 2: dV[j, d] += sum_i P[i, j] dO[i, d], keys R0 .. R0 + 15 ------------------------------------------------
-#pragma unroll 8
-        for (int t = 0; t < LQ / 4; ++t) {
-            const int i = 4 * t + kg;
-            const float a = Ps[i * LDP + R0 + fi];
-            av0 = mfma16(a, Os[i * AB + fi], av0);
-            av1 = mfma16(a, Os[i * AB + 16 + fi], av1);
+        for (int s4 = 0; s4 < LB / 32; ++s4) {
+            const float* const pr = Ps + (16 * qi + fi) * LDP + 32 * s4 + 4 * kg;
+            const SplitFrag b = split_frag(*reinterpret_cast<const f32x4*>(pr), *reinterpret_cast<const f32x4*>(pr + 16));
+            aq = split_mfma16(swz_tr_load(Kt, KT, 2 * s4, hh, fi, kg), b, aq);
         }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Ps[(16 * qi + 4 * kg + r) * LDP + 16 * (4 * hh + c) + fi] = dp[c][r];
-        __syncthreads();
-        // ---- phase 3: dK (keys R0 ..) and this key block's share of dQ (query tile qi, head dims 16 hh .. 16 hh + 15) -----------
-#pragma unroll 8
-        for (int t = 0; t < LQ / 4; ++t) {
-            const int j = 4 * t + kg;
-            const float ds_col = Ps[j * LDP + R0 + fi];
-            ak0 = mfma16(ds_col, Qs[j * AB + fi], ak0);
-            ak1 = mfma16(ds_col, Qs[j * AB + 16 + fi], ak1);
-        }
-        f32x4 aq = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-        for (int t = 0; t < LB / 4; ++t) {
-            const int j = 4 * t + kg;
-            aq = mfma16(Ps[(16 * qi + fi) * LDP + j], Ks[j * AB + 16 * hh + fi], aq);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * qi + 4 * kg + r;
-            if (row < q_valid && 16 * hh + fi < head_stride) {
+        {
+            const int row = 16 * qi + fi;       // aq[r] = dQ[query row][head dim 16 hh + 4 kg + r]
+            if (row < q_valid) {
                 float* d = kb == 0 ? dq + (row_base + q0 + row) * ldd + (long)head * head_stride
                                    : dq_slabs + ((long)(kb - 1) * n_tok + row_base + q0 + row) * ((long)n_head * 32) + (long)head * 32;
-                d[16 * hh + fi] = aq[r];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (16 * hh + 4 * kg + r < head_stride) d[16 * hh + 4 * kg + r] = aq[r];
             }
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = R0 + 4 * kg + r;
-        if (row < k_valid) {
-            const long o = (row_base + k0 + row) * ldd + (long)head * head_stride;
-            if (fi < head_stride) { dv[o + fi] = av0[r]; dk[o + fi] = ak0[r]; }
-            if (16 + fi < head_stride) { dv[o + 16 + fi] = av1[r]; dk[o + 16 + fi] = ak1[r]; }
+    for (int u = 0; u < 2; ++u) {
+        const int col = R0 + 16 * u + fi;
+        if (col < k_valid) {
+            const long o = (row_base + k0 + col) * ldd + (long)head * head_stride;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d0 = 4 * kg + r;
+                if (d0 < head_stride) { dv[o + d0] = av[u][0][r]; dk[o + d0] = ak[u][0][r]; }
+                if (16 + d0 < head_stride) { dv[o + 16 + d0] = av[u][1][r]; dk[o + 16 + d0] = ak[u][1][r]; }
+            }
         }
     }
 }
@@ -2008,19 +2027,19 @@ static int attention_bwd(const float* q, const float* k, const float* v, int64_t
     int st = lime_check_launch("attn_stats_kernel");
     if (st != LIME_OK) return st;
     if (spx) {
-        constexpr int SP_LDP = LB + 2, SP_AB = AB_LD;
-        constexpr int BYTES_SP = (3 * LB * lime_dev::SPLIT_PITCH + LB * SP_AB + 2 * LQ * SP_AB + LQ * SP_LDP + 2 * LQ) * 4;
-        static_assert(BYTES_SP <= 163840, "LDS budget");
+        constexpr int SP_LDP = LB + 4;
+        constexpr int BYTES_SP = (3 * LB * lime_dev::SWZ_ROW + 3 * LQ * lime_dev::SWZ_ROW + LQ * SP_LDP + 2 * LQ) * 4;
+        static_assert(2 * BYTES_SP <= 163840, "LDS budget: two workgroups per CU");
         static bool configured_sp = false;
         if (!configured_sp) {
-            e = hipFuncSetAttribute((const void*)attn_bwd_long_sp_kernel<SP_LDP, SP_AB>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES_SP);
+            e = hipFuncSetAttribute((const void*)attn_bwd_long_sp_kernel<SP_LDP>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES_SP);
             LIME_REQUIRE(e == hipSuccess, LIME_ERR_LAUNCH, "lime_token_attention_bwd_f32: cannot reserve %d bytes of LDS: %s", BYTES_SP,
                          hipGetErrorString(e));
             configured_sp = true;
         }
-        attn_bwd_long_sp_kernel<SP_LDP, SP_AB><<<(unsigned)(n_prob * n_blk), 512, BYTES_SP, s>>>(q, k, v, ld_qkv, dout, ldo, workspace, dq, dk, dv,
-                                                                                                ld_dqkv, S, n_head, head_dim, head_stride, scale,
-                                                                                                n_blk, drop, dq_slabs, n_tok);
+        attn_bwd_long_sp_kernel<SP_LDP><<<(unsigned)(n_prob * n_blk), 256, BYTES_SP, s>>>(q, k, v, ld_qkv, dout, ldo, workspace, dq, dk, dv,
+                                                                                         ld_dqkv, S, n_head, head_dim, head_stride, scale,
+                                                                                         n_blk, drop, dq_slabs, n_tok);
         st = lime_check_launch("attn_bwd_long_sp_kernel");
         if (st != LIME_OK || n_blk == 1) return st;
         const long total_sp = n_tok * n_head * head_stride;

@@ -33,14 +33,11 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int SPB = 128;                              // rows per image
-constexpr int ROW = 32;                               // image rows: 32 bf16 = 64 bytes = four 16-byte chunks
-constexpr int TERM = SPB * ROW;                       // one bf16 image (unsigned shorts)
+constexpr int TERM = SPB * SWZ_ROW;                   // one bf16 image (unsigned shorts): 64-byte rows
+static_assert(SWZ_ROW == 32, "images hold 32 head dims per row");
 constexpr int IMG = 3 * TERM;                         // the three terms of one operand
 constexpr int LDS_BYTES = 4 * IMG * 2 + 3 * SPB * 4;  // Q, K, V, dO + the row statistics
 
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
 struct BwdSpP {
     const float* q; const float* k; const float* v; long ld;
@@ -50,40 +47,9 @@ struct BwdSpP {
     LimeDropout drop;
 };
 
-// Image layout: row r = 64 bytes, its 16-byte chunk ch at position ch ^ swz(r), swz(r) = 2 * bit 2 of r + bit 3 of r.  Rows 4 apart
-// share their banks (64-byte rows, 64 banks): bit 2 moves them to the other half of the bank group, bit 3 to the other chunk of the
-// half -- the row reads (ds_read_b128: 16 lanes = 16 rows, one chunk), the transposed block reads (a 32-lane half = 8 consecutive
-// rows x 32 bytes) and the 8-byte staging writes are all conflict free.
-__device__ __forceinline__ int swz(int r) { return ((r >> 1) & 2) | ((r >> 3) & 1); }
-__device__ __forceinline__ int img_off(int r, int c) { return r * ROW + (((c >> 3) ^ swz(r)) << 3) + (c & 7); }
-
-// the fragment of row r, k values 8 kg .. 8 kg + 7 (one chunk)
-__device__ __forceinline__ SplitFrag row_load(const unsigned short* img, int r, int kg) {
-    const unsigned short* const p = img + r * ROW + ((kg ^ swz(r)) << 3);
-    SplitFrag f;
-    f.h = *reinterpret_cast<const bf16x8*>(p);
-    f.m = *reinterpret_cast<const bf16x8*>(p + TERM);
-    f.l = *reinterpret_cast<const bf16x8*>(p + 2 * TERM);
-    return f;
-}
-
-// the A operand (rows = head dims 16 c + fi) of a product that sums over token rows: k values = rows 16 t0 + 4 kg + {0..3} and
-// 16 (t0 + 1) + 4 kg + {0..3} of the row-major image -- two transposed block reads per term (ds_read_b64_tr_b16: lane 4 q + p of a
-// 16-lane group supplies the address of row q, columns 4 p .. 4 p + 3 of the block and receives column (lane & 15) of its four rows).
-// The swizzle is the same for the rows of a block and for rows 16 apart.  EXEC is all ones at every call.
-__device__ __forceinline__ bf16x8 tr_pair(const unsigned short* p0) {
-    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0));
-    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p0 + 16 * ROW));
-    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
-}
-__device__ __forceinline__ SplitFrag tr_load(const unsigned short* img, int t0, int c, int fi, int kg) {
-    const unsigned short* const p0 = img + img_off(16 * t0 + 4 * kg + (fi >> 2), 16 * c + 4 * (fi & 3));
-    SplitFrag f;
-    f.h = tr_pair(p0);
-    f.m = tr_pair(p0 + TERM);
-    f.l = tr_pair(p0 + 2 * TERM);
-    return f;
-}
+// Image layout and its readers (swz_row_load, swz_tr_load, swz_store*): split_mfma.h.
+__device__ __forceinline__ SplitFrag row_load(const unsigned short* img, int r, int kg) { return swz_row_load(img, TERM, r, kg); }
+__device__ __forceinline__ SplitFrag tr_load(const unsigned short* img, int t0, int c, int fi, int kg) { return swz_tr_load(img, TERM, t0, c, fi, kg); }
 
 template <bool FULL>      // S == 128: no rows beyond S to mask
 __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const BwdSpP p) {
@@ -136,23 +102,14 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const BwdSpP p) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = tid + 512 * u, r = e >> 3, c = (e & 7) * 4;
-            u32x2 h, m, l;
-            split_quad(rq[u][0], rq[u][1], rq[u][2], rq[u][3], h, m, l);
-            unsigned short* d = Qi + img_off(r, c);
-            *reinterpret_cast<u32x2*>(d) = h; *reinterpret_cast<u32x2*>(d + TERM) = m; *reinterpret_cast<u32x2*>(d + 2 * TERM) = l;
-            split_quad(rk[u][0], rk[u][1], rk[u][2], rk[u][3], h, m, l);
-            d = Ki + img_off(r, c);
-            *reinterpret_cast<u32x2*>(d) = h; *reinterpret_cast<u32x2*>(d + TERM) = m; *reinterpret_cast<u32x2*>(d + 2 * TERM) = l;
-            split_quad(rv[u][0], rv[u][1], rv[u][2], rv[u][3], h, m, l);
-            d = Vi + img_off(r, c);
-            *reinterpret_cast<u32x2*>(d) = h; *reinterpret_cast<u32x2*>(d + TERM) = m; *reinterpret_cast<u32x2*>(d + 2 * TERM) = l;
+            swz_store4(Qi, TERM, r, c, rq[u][0], rq[u][1], rq[u][2], rq[u][3]);
+            swz_store4(Ki, TERM, r, c, rk[u][0], rk[u][1], rk[u][2], rk[u][3]);
+            swz_store4(Vi, TERM, r, c, rv[u][0], rv[u][1], rv[u][2], rv[u][3]);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = tid + 512 * u, r = e >> 4, c = (e & 15) * 2;
-            const SplitPair t = split_pair(ro[u][0], ro[u][1]);
-            unsigned short* const d = Oi + img_off(r, c);
-            *reinterpret_cast<unsigned*>(d) = t.h; *reinterpret_cast<unsigned*>(d + TERM) = t.m; *reinterpret_cast<unsigned*>(d + 2 * TERM) = t.l;
+            swz_store2(Oi, TERM, r, c, ro[u][0], ro[u][1]);
         }
     };
 
