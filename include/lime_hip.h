@@ -572,7 +572,8 @@ int lime_layernorm_bwd_f32(const float* dy, int64_t lddy, int32_t dy_div, float 
                            int64_t workspace_floats, void* stream);
 /* The same with a second result dz_drop[r, c] = keep(r * E + c) ? dz[r, c] / (1 - p) : 0 -- the gradient through the dropout that sits in
  * front of the residual add (dropout1 / dropout2 of the encoder layer, newsEncoders.py:244-247) with the forward's (p, seed, site) --
- * written in the same pass instead of a lime_dropout_f32 pass over dz.  16-byte friendly operands only. */
+ * written in the same pass instead of a lime_dropout_f32 pass over dz; `dzsum` is then the column sums of dz_drop (the bias gradient of
+ * the linear in front of that dropout), not of dz.  16-byte friendly operands only. */
 int lime_layernorm_bwd_dropout_f32(const float* dy, int64_t lddy, int32_t dy_div, float dy_scale, const float* y, int64_t ldy,
                                    const float* gamma, const float* beta, const float* rstd, float* dz, int64_t lddz, int32_t M, int32_t E,
                                    float* dgamma, float* dbeta, float* dzsum, int32_t accumulate, float* workspace,

@@ -541,16 +541,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
             f32x4v v = (d[j] * *reinterpret_cast<const f32x4v*>(&gs[c]) - s1 - xh[j] * s2) * rs;
             if (!ok) v = zero;
             if (ok) *reinterpret_cast<f32x4v*>(dz + r * lddz + c) = v;
+            f32x4v t = v;
             if (dz_drop != nullptr && ok) {            // the gradient through the dropout in front of the residual add, written alongside
                 const unsigned keep = lime_keep4(drop, ((uint64_t)r * (uint64_t)E + (uint64_t)c) >> 2);
-                f32x4v t;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) t[e] = (keep >> e) & 1u ? v[e] * drop.scale : 0.f;
                 *reinterpret_cast<f32x4v*>(dz_drop + r * lddd + c) = t;
             }
             sg[j] += d[j] * xh[j];
             sb[j] += d[j];
-            sz[j] += v;
+            sz[j] += t;                                // column sums of what goes on to the linear in front: its bias gradient
         }
     }
     // the four row groups of the wave, then the four waves

@@ -1097,7 +1097,8 @@ def colsum(x, out=None, accumulate=False):
 
 def layernorm_bwd(dy, y, gamma, beta, rstd, dy_div=1, dy_scale=1.0, want_dzsum=True, dropout=None):
     """Backward of y = LayerNorm(z): returns (dz [M, E], dgamma, dbeta, dzsum or None).  dy: [ceil(M / dy_div), E].
-    ``dropout`` = (p, seed, site): a fifth result, dropout(dz) under that site's mask, written in the same pass."""
+    ``dropout`` = (p, seed, site): a fifth result, dropout(dz) under that site's mask, written in the same pass; dzsum is then the
+    column sums of THAT (the bias gradient of the linear in front of the dropout)."""
     lib = _lib.load()
     _mat(dy, 'dy')
     _mat(y, 'y')
@@ -1115,8 +1116,9 @@ def layernorm_bwd(dy, y, gamma, beta, rstd, dy_div=1, dy_scale=1.0, want_dzsum=T
     ws = _workspace(dev, lib.lime_layernorm_bwd_workspace(M, E))
     if dropout is not None:
         if E % 4 or _ld(dy) % 4 or _ld(y) % 4:           # the fused copy needs 16-byte rows: otherwise a dropout pass of its own
-            res = layernorm_bwd(dy, y, gamma, beta, rstd, dy_div, dy_scale, want_dzsum)
-            return res + (globals()['dropout'](res[0], *dropout),)
+            res = layernorm_bwd(dy, y, gamma, beta, rstd, dy_div, dy_scale, False)
+            dt = globals()['dropout'](res[0], *dropout)
+            return res[:3] + (colsum(dt) if want_dzsum else None, dt)
         dt = torch.empty((M, E), dtype=torch.float32, device=dev)
         check(lib.lime_layernorm_bwd_dropout_f32(_p(dy), _ld(dy), dy_div, dy_scale, _p(y), _ld(y), _p(gamma), _p(beta), _p(rstd), _p(dz),
                                                  _ld(dz), M, E, _p(dgamma), _p(dbeta), _p(dzsum), 0, _p(ws), ws.numel(), _p(dt), _ld(dt),

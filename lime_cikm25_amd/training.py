@@ -330,16 +330,13 @@ class _TokenEncoder(torch.autograd.Function):
         dpooled = dpooled.contiguous()
         # norm2 <- mean pool: every token of a sequence receives dpooled / S
         if drop:                                                                   # dt2: the branch through dropout2 into linear2, same pass
-            dz2, dn2_w, dn2_b, dl2_b, dt2 = ops.layernorm_bwd(dpooled, y, n2_w, n2_b, rstd2, dy_div=S, dy_scale=1.0 / S, want_dzsum=False,
-                                                             dropout=(p, seed, _SITE_DROP2))
+            dz2, dn2_w, dn2_b, dl2_b, dt2 = ops.layernorm_bwd(dpooled, y, n2_w, n2_b, rstd2, dy_div=S, dy_scale=1.0 / S,
+                                                             dropout=(p, seed, _SITE_DROP2))            # dl2_b: column sums of dt2
         else:
             dz2, dn2_w, dn2_b, dl2_b = ops.layernorm_bwd(dpooled, y, n2_w, n2_b, rstd2, dy_div=S, dy_scale=1.0 / S)
             dt2 = dz2
         del y
-        if drop:
-            dl2_w, dl2_b = ops.linear_wgrad(dt2, h, want_bias=True)
-        else:
-            dl2_w = ops.linear_wgrad(dt2, h)
+        dl2_w = ops.linear_wgrad(dt2, h)
         # dH = dT2 W2 with the ReLU (and dropout) gradient in the GEMM's epilogue: h > 0 <=> ReLU passed and the mask kept
         dh = ops.linear(dt2, l2_w.t().contiguous(), None, act='relu_grad', res=h, act_scale=keep_scale)
         del h, dt2
@@ -347,15 +344,12 @@ class _TokenEncoder(torch.autograd.Function):
         dx1 = ops.linear(dh, l1_w.t().contiguous(), None, res=dz2)                 # through linear1 + the residual branch
         del dh, dz2
         if drop:
-            dz1, dn1_w, dn1_b, dout_b, dt1 = ops.layernorm_bwd(dx1, x1, n1_w, n1_b, rstd1, want_dzsum=False, dropout=(p, seed, _SITE_DROP1))
+            dz1, dn1_w, dn1_b, dout_b, dt1 = ops.layernorm_bwd(dx1, x1, n1_w, n1_b, rstd1, dropout=(p, seed, _SITE_DROP1))
         else:
             dz1, dn1_w, dn1_b, dout_b = ops.layernorm_bwd(dx1, x1, n1_w, n1_b, rstd1)
             dt1 = dz1
         del dx1, x1
-        if drop:
-            dout_w, dout_b = ops.linear_wgrad(dt1, ao, want_bias=True)
-        else:
-            dout_w = ops.linear_wgrad(dt1, ao)
+        dout_w = ops.linear_wgrad(dt1, ao)
         dao = ops.linear(dt1, out_w.t().contiguous(), None)
         dqkv = ops.token_attention_bwd(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], dao, M, S, nhead, hd, 1.0 / math.sqrt(hd),
                                        head_stride=hs, out=ao, dropout=(p, seed, _SITE_ATTN) if drop else None, lse=ctx.lse)
@@ -452,30 +446,23 @@ class _EncoderLayer(torch.autograd.Function):
         drop = p > 0
         keep_scale = 1.0 / (1.0 - p) if drop else 1.0
         if drop:                                                                   # dt2: the branch through dropout2 into linear2, same pass
-            dz2, dn2_w, dn2_b, dl2_b, dt2 = ops.layernorm_bwd(dy.contiguous(), y, n2_w, n2_b, rstd2, want_dzsum=False,
-                                                             dropout=(p, seed, _SITE_DROP2))
+            dz2, dn2_w, dn2_b, dl2_b, dt2 = ops.layernorm_bwd(dy.contiguous(), y, n2_w, n2_b, rstd2, dropout=(p, seed, _SITE_DROP2))
         else:
             dz2, dn2_w, dn2_b, dl2_b = ops.layernorm_bwd(dy.contiguous(), y, n2_w, n2_b, rstd2)
             dt2 = dz2
-        if drop:
-            dl2_w, dl2_b = ops.linear_wgrad(dt2, h, want_bias=True)
-        else:
-            dl2_w = ops.linear_wgrad(dt2, h)
+        dl2_w = ops.linear_wgrad(dt2, h)
         # dH = dT2 W2 with the ReLU (and dropout) gradient in the GEMM's epilogue: h > 0 <=> ReLU passed and the mask kept
         dh = ops.linear(dt2, l2_w.t().contiguous(), None, act='relu_grad', res=h, act_scale=keep_scale)
         dl1_w, dl1_b = ops.linear_wgrad(dh, x1, want_bias=True)
         dx1 = ops.linear(dh, l1_w.t().contiguous(), None, res=dz2)                 # through linear1 + the residual branch
         del dh, dz2
         if drop:
-            dz1, dn1_w, dn1_b, dout_b, dt1 = ops.layernorm_bwd(dx1, x1, n1_w, n1_b, rstd1, want_dzsum=False, dropout=(p, seed, _SITE_DROP1))
+            dz1, dn1_w, dn1_b, dout_b, dt1 = ops.layernorm_bwd(dx1, x1, n1_w, n1_b, rstd1, dropout=(p, seed, _SITE_DROP1))
         else:
             dz1, dn1_w, dn1_b, dout_b = ops.layernorm_bwd(dx1, x1, n1_w, n1_b, rstd1)
             dt1 = dz1
         del dx1
-        if drop:
-            dout_w, dout_b = ops.linear_wgrad(dt1, ao, want_bias=True)
-        else:
-            dout_w = ops.linear_wgrad(dt1, ao)
+        dout_w = ops.linear_wgrad(dt1, ao)
         dao = ops.linear(dt1, out_w.t().contiguous(), None)
         dqkv = ops.token_attention_bwd(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], dao, M, S, nhead, hd, 1.0 / math.sqrt(hd),
                                        head_stride=hs, out=ao, dropout=(p, seed, _SITE_ATTN) if drop else None, lse=ctx.lse)

@@ -158,8 +158,11 @@ def test_fused_dropout_passes_equal_the_separate_ones():
     rstd = 1.0 / torch.sqrt(z.var(dim=1, unbiased=False) + 1e-5)
     dz, dg, db, dzs = ops.layernorm_bwd(dy, y, gamma, beta, rstd)
     dz2, dg2, db2, dzs2, dt = ops.layernorm_bwd(dy, y, gamma, beta, rstd, dropout=(p, seed, 5))
-    assert torch.equal(dz, dz2) and torch.equal(dg, dg2) and torch.equal(db, db2) and torch.equal(dzs, dzs2)
+    assert torch.equal(dz, dz2) and torch.equal(dg, dg2) and torch.equal(db, db2)
     assert torch.equal(dt, ops.dropout(dz, p, seed, 5))
+    want = dt.double().sum(dim=0)                                                  # dzsum of the fused form: column sums of the DROPPED gradient
+    assert float((dzs2.double() - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max()))
+    assert not torch.equal(dzs, dzs2)
     assert 0.15 < float((dt == 0).float().mean()) < 0.25
     x = (torch.rand(M, E, generator=g) * 2 - 1).cuda()
     assert torch.equal(ops.dropout2(x, p, seed, 1, 0), ops.dropout(ops.dropout(x, p, seed, 1), p, seed, 0))
