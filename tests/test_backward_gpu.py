@@ -430,3 +430,32 @@ def test_training_forward_over_live_tokens_equals_the_dense_one(ops):
     for n in names:
         scale = float(res[0][1][n].abs().max())
         assert float((res[1][1][n] - res[0][1][n]).abs().max()) <= 2e-5 * max(scale, 1e-6), n
+
+
+@pytest.mark.parametrize('n_seq,S,nh', [(3, 68, 4), (2, 96, 10), (30, 128, 10), (2, 200, 3), (1, 512, 4)])
+def test_token_attention_bwd_dropout_split_equals_fp32(ops, n_seq, S, nh):
+    """Attention-probability dropout in the backward: the split-product kernels (one-pass for 64 < S <= 128 -- phase A hashes four
+    consecutive keys per lane, phase B shares four hashes over a quad by DPP -- and the blocked kernel for S > 128) regenerate the
+    same mask as the fp32-MFMA kernels: the two builds agree to fp32 rounding on the same (p, seed, site)."""
+    hd, hs = 30, 32
+    tok, W = n_seq * S, nh * hs
+    qkv = torch.zeros(tok, 3 * W)
+    qkv.view(tok, 3, nh, hs)[..., :hd] = rnd(tok, 3, nh, hd, seed=5)
+    g = qkv.cuda()
+    dout = rnd(tok, nh * hd, seed=6).cuda()
+    scale = 1.0 / math.sqrt(hd)
+    drop = (0.2, 424242, 2)
+    res = {}
+    for split in (True, False):
+        prev = ops.set_split_gemm(split)
+        try:
+            out = ops.token_attention_dropout(g[:, :W], g[:, W:2 * W], g[:, 2 * W:], n_seq, S, nh, hd, scale, *drop, head_stride=hs)
+            res[split] = (out, ops.token_attention_bwd(g[:, :W], g[:, W:2 * W], g[:, 2 * W:], dout, n_seq, S, nh, hd, scale, head_stride=hs,
+                                                        out=out, dropout=drop))
+        finally:
+            ops.set_split_gemm(prev)
+    for a, b, what in ((res[True][0], res[False][0], 'forward'), (res[True][1], res[False][1], 'dqkv')):
+        err = float((a - b).abs().max()) / float(b.abs().max())
+        assert err < 2e-5, '%s: split and fp32 kernels differ by %.2e' % (what, err)
+    dropped = float((res[False][1] != 0).float().mean())
+    assert dropped > 0.5                                                          # a real gradient, not zeros
