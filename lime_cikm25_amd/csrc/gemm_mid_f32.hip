@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int MB = 64, NB = 64, KB = 16, NS = 6;
+constexpr int MB = 64, NB = 64, KB = 16, NS = 6;       // MB x NB: the largest tile (LDS is sized for it); KB-deep chunks, NS stages
 constexpr unsigned OOB = 0x80000000u;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -28,6 +28,7 @@ struct MidP {
     const float* w; long ldw; const float* bias;
     const float* res; long ldr; int res_div, res_mod; const int* res_ids;
     float* c; long ldc; int M, N, K, act, n_col_blocks;
+    int shape;           // tile shape of this problem: 0 = 64 x 64, 1 = 32 x 64, 2 = 32 x 32 (mid_params)
     const int* m_dev;    // optional device-side row count (min(*m_dev, M) rows; workgroups of tiles beyond it exit)
 };
 
@@ -48,15 +49,26 @@ __device__ __forceinline__ float act_fn(float v, int act) {
     return v;
 }
 
-constexpr int A_ST = MB * KB, STAGE = (MB + NB) * KB;               // floats
+constexpr int STAGE_MAX = (MB + NB) * KB;                            // floats
 
-// one 64 x 64 tile of problem p (tile index inside the problem); lds: the workgroup's NS * STAGE floats
+// One TM x TN tile of problem p (tile index inside the problem); lds: the workgroup's NS * STAGE_MAX floats.  The tile shape is chosen
+// per problem (MidP.shape): a launch whose 64 x 64 tiles leave workgroup slots empty is bound by ONE tile's k loop -- 16 MFMAs of 32
+// cycles per wave and chunk, one wave per SIMD -- so the same problem in 32 x 64 or 32 x 32 tiles (8 / 4 MFMAs per wave and chunk,
+// two or four times the workgroups) finishes sooner.  Every output element sees the same k order in all three: the results are
+// bit-identical.  Waves: TM / 16 row groups x 4 / (TM / 16) column groups of TN / (column groups) columns.
+template <int TM, int TN>
 __device__ __forceinline__ void mid_tile(const MidP& p, const int tile, float* const lds) {
+    constexpr int WR = TM / 16, WC = 4 / WR, NT = TN / (16 * WC);     // row groups, column groups, 16-column MFMA tiles per wave
+    constexpr int NA = TM / 16, NW = TN / 16;                          // 16-row DMA groups of A and of W per chunk
+    constexpr int DPW = (NA + NW + 3) / 4;                             // DMA instructions per wave and chunk (2, 2, 1)
+    constexpr int A_ST = TM * KB, STAGE = (TM + TN) * KB;
+    static_assert(WR * WC == 4 && NT >= 1 && STAGE <= STAGE_MAX, "tile shape");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave % WR, wc = wave / WR;
     const int fi = lane & 15, kg = lane >> 4;
     const int rb = tile / p.n_col_blocks;
-    const int row0 = rb * MB, col0 = (tile - rb * p.n_col_blocks) * NB;
+    const int row0 = rb * TM, col0 = (tile - rb * p.n_col_blocks) * TN;
     int M = p.M;
     if (p.m_dev) {
         const int m = __builtin_amdgcn_readfirstlane(*p.m_dev);
@@ -64,54 +76,70 @@ __device__ __forceinline__ void mid_tile(const MidP& p, const int tile, float* c
     }
     if (row0 >= M) return;                           // (uniform per workgroup: nothing was issued yet)
 
-    // ---- loader: this wave stages A rows 16 wave .. + 15 and W rows 16 wave .. + 15 of every chunk (one 1 KB DMA each) ----
+    // ---- loader: the NA + NW 16-row groups of a chunk (1 KB DMA each) are dealt to the waves, DPW per wave (a wave without a group
+    // in a round issues an out-of-bounds piece: the counted waits below assume DPW instructions per wave and chunk) ---------------
     const int srow = lane >> 2;
     const int lseg = (lane & 3) ^ swz4((lane >> 4) & 3);
     const int lda4 = (int)p.lda * 4, ldw4 = (int)p.ldw * 4;
     const bool gather = p.a_ids != nullptr;
     const __amdgpu_buffer_rsrc_t rs_a = mk_rsrc(gather ? (const char*)p.a : (const char*)p.a + (long)row0 * p.lda * 4);
     const __amdgpu_buffer_rsrc_t rs_w = mk_rsrc((const char*)p.w + (long)col0 * p.ldw * 4);
-    unsigned a_voff, w_voff;
-    {
-        const int rl = 16 * wave + srow;
-        unsigned rowsel = (unsigned)rl;
-        if (gather && row0 + rl < M) rowsel = (unsigned)p.a_ids[row0 + rl];
-        a_voff = (row0 + rl < M) ? rowsel * (unsigned)lda4 + (unsigned)lseg * 16u : OOB;
-        w_voff = (col0 + rl < p.N) ? (unsigned)rl * (unsigned)ldw4 + (unsigned)lseg * 16u : OOB;
+    unsigned g_voff[DPW];                           // group wave + 4 d: A group (< NA), W group (- NA) or none
+    int g_lds[DPW], g_kind[DPW];                    // kind 0: A, 1: W, 2: none (its piece is zeros into a dump area behind the stages)
+#pragma unroll
+    for (int d = 0; d < DPW; ++d) {
+        const int g = wave + 4 * d;
+        unsigned vo = OOB;
+        if (g < NA) {
+            const int rl = 16 * g + srow;
+            unsigned rowsel = (unsigned)rl;
+            if (gather && row0 + rl < M) rowsel = (unsigned)p.a_ids[row0 + rl];
+            if (row0 + rl < M) vo = rowsel * (unsigned)lda4 + (unsigned)lseg * 16u;
+            g_lds[d] = g * 256; g_kind[d] = 0;
+        } else if (g < NA + NW) {
+            const int rl = 16 * (g - NA) + srow;
+            if (col0 + rl < p.N) vo = (unsigned)rl * (unsigned)ldw4 + (unsigned)lseg * 16u;
+            g_lds[d] = A_ST + (g - NA) * 256; g_kind[d] = 1;
+        } else {
+            static_assert(NS * STAGE + 4 * 256 <= NS * STAGE_MAX || (NA + NW) % 4 == 0, "room for the dump area");
+            g_lds[d] = NS * STAGE + wave * 256; g_kind[d] = 2;
+        }
+        g_voff[d] = vo;
     }
     const int nchunk = (p.K + KB - 1) / KB;
     auto issue = [&](int c) {                       // chunk c -> stage c % NS; beyond K (or beyond the last chunk): zeros
         const bool kin = c * KB + lseg * 4 < p.K;
         float* const sb = lds + (c % NS) * STAGE;
-        dma16(rs_a, sb + wave * 256, kin ? a_voff : OOB, c * 64);
-        dma16(rs_w, sb + A_ST + wave * 256, kin ? w_voff : OOB, c * 64);
+#pragma unroll
+        for (int d = 0; d < DPW; ++d)               // exactly DPW instructions per wave and chunk: the counted waits below rely on it
+            dma16(g_kind[d] == 0 ? rs_a : rs_w, g_kind[d] == 2 ? lds + g_lds[d] : sb + g_lds[d], kin ? g_voff[d] : OOB, c * 64);
     };
 
-    // ---- compute: wave owns output rows 16 wave .. + 15 x the tile's 64 columns (4 MFMA column tiles) ----------------------
+    // ---- compute: wave (wr, wc) owns output rows 16 wr .. + 15 x columns 16 NT wc .. of the tile (NT MFMA column tiles) ---------
     const int pseg = (kg ^ swz4((fi >> 2) & 3)) * 4;
-    const int a_off = (16 * wave + fi) * KB + pseg, w_off = A_ST + fi * KB + pseg;
-    f32x4 acc[4];
+    const int a_off = (16 * wr + fi) * KB + pseg, w_off = A_ST + (16 * NT * wc + fi) * KB + pseg;
+    f32x4 acc[NT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
     for (int c = 0; c < NS - 1; ++c) issue(c);
     // Software pipeline by one chunk: iteration c waits for chunk c + 1, reads ITS fragments into registers and issues the
-    // MFMAs of chunk c behind those reads, so the LDS round trip of a chunk's five ds_read_b128 hides under the previous chunk's
-    // sixteen MFMAs (the exposed read + barrier + issue were ~0.2 us of every 0.4 us chunk).
-    auto read_frags = [&](int c, f32x4& af, f32x4 (&wf)[4]) {
+    // MFMAs of chunk c behind those reads, so the LDS round trip of a chunk's ds_read_b128 hides under the previous chunk's
+    // MFMAs (the exposed read + barrier + issue were ~0.2 us of every 0.4 us chunk).
+    auto read_frags = [&](int c, f32x4& af, f32x4 (&wf)[NT]) {
         const float* sb = lds + (c % NS) * STAGE;
         af = *reinterpret_cast<const f32x4*>(sb + a_off);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const f32x4*>(sb + w_off + t * 16 * KB);
+        for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const f32x4*>(sb + w_off + t * 16 * KB);
     };
-    f32x4 af, wf[4], afn, wfn[4];
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NS - 2)) : "memory");      // chunk 0: this wave's pieces ...
+    f32x4 af, wf[NT], afn, wfn[NT];
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW * (NS - 2)) : "memory");    // chunk 0: this wave's pieces ...
     lds_barrier();                                                            // ... and everyone's
     read_frags(0, af, wf);
     for (int c = 0; c < nchunk; ++c) {
-        // chunk c + 1 has landed when at most the 2 (NS - 3) younger DMA instructions of this wave are outstanding
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NS - 3)) : "memory");
+        // chunk c + 1 has landed when at most the DPW (NS - 3) younger DMA instructions of this wave are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW * (NS - 3)) : "memory");
         lds_barrier();                              // everyone's pieces of chunk c + 1; and every wave has READ stage c % NS
         __builtin_amdgcn_sched_barrier(0);
         issue(c + NS - 1);                          // into stage (c - 1) % NS, whose fragments were read an iteration ago
@@ -120,16 +148,16 @@ __device__ __forceinline__ void mid_tile(const MidP& p, const int tile, float* c
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][q], af[q], acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][q], af[q], acc[t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         af = afn;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) wf[t] = wfn[t];
+        for (int t = 0; t < NT; ++t) wf[t] = wfn[t];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs issued past the last chunk must land before the LDS is released
 
-    // ---- epilogue: lane (fi, kg) holds row 16 wave + fi, columns 16 t + 4 kg .. + 3 -------------------------------------------
-    const int row = row0 + 16 * wave + fi;
+    // ---- epilogue: lane (fi, kg) holds row 16 wr + fi, columns 16 (NT wc + t) + 4 kg .. + 3 ---------------------------------------
+    const int row = row0 + 16 * wr + fi;
     if (row >= M) return;
     long rrow = -1;
     if (p.res) {
@@ -139,8 +167,8 @@ __device__ __forceinline__ void mid_tile(const MidP& p, const int tile, float* c
     }
     float* const crow = p.c + (long)row * p.ldc;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int col = col0 + 16 * t + 4 * kg;
+    for (int t = 0; t < NT; ++t) {
+        const int col = col0 + 16 * (NT * wc + t) + 4 * kg;
         if (col >= p.N) continue;                   // N % 4 == 0: a group of four is in or out as a whole
         f32x4 v = acc[t];
         if (p.bias) {
@@ -154,9 +182,16 @@ __device__ __forceinline__ void mid_tile(const MidP& p, const int tile, float* c
     }
 }
 
+// shape 0: 64 x 64, 1: 32 x 64, 2: 32 x 32 (uniform per workgroup)
+__device__ __forceinline__ void mid_tile_any(const MidP& p, const int tile, float* const lds) {
+    if (p.shape == 2) mid_tile<32, 32>(p, tile, lds);
+    else if (p.shape == 1) mid_tile<32, 64>(p, tile, lds);
+    else mid_tile<64, 64>(p, tile, lds);
+}
+
 __global__ __launch_bounds__(256, 3) void gemm_mid_kernel(const MidP p) {
-    __shared__ __attribute__((aligned(16))) float lds[NS * STAGE];
-    mid_tile(p, (int)blockIdx.x, lds);
+    __shared__ __attribute__((aligned(16))) float lds[NS * STAGE_MAX];
+    mid_tile_any(p, (int)blockIdx.x, lds);
 }
 
 // Several INDEPENDENT problems in one launch: the launches around the encoders are latency bound (one tile's k loop, >= 10 us each
@@ -169,10 +204,20 @@ struct MidGroup {
 };
 
 __global__ __launch_bounds__(256, 3) void gemm_mid_group_kernel(const MidGroup g) {
-    __shared__ __attribute__((aligned(16))) float lds[NS * STAGE];
+    __shared__ __attribute__((aligned(16))) float lds[NS * STAGE_MAX];
     int k = 0;
     while (k + 1 < g.n && (int)blockIdx.x >= g.first[k + 1]) ++k;        // uniform: scalar loads and compares
-    mid_tile(g.p[k], (int)blockIdx.x - g.first[k], lds);
+    mid_tile_any(g.p[k], (int)blockIdx.x - g.first[k], lds);
+}
+
+int mid_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) n = cus;
+        else n = 256;
+    }
+    return n;
 }
 
 inline bool al16(const void* ptr, long ld) { return ptr == nullptr || (((uintptr_t)ptr % 16) == 0 && (ld % 4) == 0); }
@@ -191,9 +236,16 @@ static bool mid_params(const lime_linear_args* a, MidP& p, long& ntiles) {
     p.res = a->res; p.ldr = a->ldr; p.res_div = a->res_div > 0 ? a->res_div : 1; p.res_ids = a->res_ids;
     p.res_mod = (a->res && !a->res_ids && a->res_mod > 0) ? a->res_mod : 0;
     p.c = a->c; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K; p.act = a->act; p.m_dev = a->m_dev;
-    const long n_row_blocks = (a->M + MB - 1) / MB;
-    p.n_col_blocks = (a->N + NB - 1) / NB;
-    ntiles = n_row_blocks * p.n_col_blocks;
+    // the smallest tiles whose workgroups still run in ONE round (three workgroups per CU): the launch is then one tile's k loop long
+    static const long slots = 3L * mid_cus();
+    const long t64 = (long)((a->M + 63) / 64) * ((a->N + 63) / 64), t3264 = (long)((a->M + 31) / 32) * ((a->N + 63) / 64),
+               t32 = (long)((a->M + 31) / 32) * ((a->N + 31) / 32);
+    static const char* const force = getenv("LIME_MID_SHAPE");               // A/B switch for tools/, not a product option
+    p.shape = force ? atoi(force) : (t32 <= slots ? 2 : (t3264 <= slots ? 1 : 0));
+    const int tm = p.shape == 0 ? 64 : 32, tn = p.shape == 2 ? 32 : 64;
+    p.n_col_blocks = (a->N + tn - 1) / tn;
+    ntiles = p.shape == 2 ? t32 : (p.shape == 1 ? t3264 : t64);
+    (void)tm;
     return ntiles <= 0x3FFFFFFFL;
 }
 

@@ -940,3 +940,21 @@ def test_mean_pool_counted(ops, S):
         assert bool((out[k:] == -7.0).all())
     with pytest.raises(Exception):
         ops.mean_pool(dev(rnd(4 * 32, 300, seed=1)), 4, 32, n_seq_dev=torch.tensor([2], dtype=torch.int32, device='cuda'))
+
+
+def test_linear_mid_tile_shapes_agree_bitwise(ops):
+    """gemm_mid_kernel picks its tile shape by the problem's tile count (32 x 32 while those fit one round of workgroups, 32 x 64, 64 x 64);
+    an output element sees the same k order in all three, so a row's result does not depend on how many rows the launch has."""
+    import ctypes
+    from lime_cikm25_amd import _lib
+    N, K = 400, 400
+    a = dev(rnd(9000, K, seed=1))
+    w, b = dev(rnd(N, K, seed=2, scale=0.05)), dev(rnd(N, seed=3))
+    outs = {}
+    for M in (40, 1700, 3000, 9000):                 # 32 x 32 (26 and 689 tiles), 32 x 64 (658), 64 x 64 (987)
+        outs[M] = ops.linear(a[:M], w, b, act='tanh')
+        assert ctypes.string_at(_lib.load().lime_last_linear_kernel()).decode() == 'gemm_mid_kernel'
+    want = torch.tanh(a.double() @ w.double().t() + b.double())
+    check(outs[9000], want.float().cpu(), what='64 x 64 tiles')
+    for M in (40, 1700, 3000):
+        assert torch.equal(outs[M], outs[9000][:M]), 'M = %d differs from the rows of the M = 9000 launch' % M
