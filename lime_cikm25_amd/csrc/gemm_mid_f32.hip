@@ -241,11 +241,10 @@ static bool mid_params(const lime_linear_args* a, MidP& p, long& ntiles) {
     const long t64 = (long)((a->M + 63) / 64) * ((a->N + 63) / 64), t3264 = (long)((a->M + 31) / 32) * ((a->N + 63) / 64),
                t32 = (long)((a->M + 31) / 32) * ((a->N + 31) / 32);
     static const char* const force = getenv("LIME_MID_SHAPE");               // A/B switch for tools/, not a product option
-    p.shape = force ? atoi(force) : (t32 <= slots ? 2 : (t3264 <= slots ? 1 : 0));
-    const int tm = p.shape == 0 ? 64 : 32, tn = p.shape == 2 ? 32 : 64;
+    p.shape = force ? (atoi(force) == 2 ? 2 : (atoi(force) == 1 ? 1 : 0)) : (t32 <= slots ? 2 : (t3264 <= slots ? 1 : 0));
+    const int tn = p.shape == 2 ? 32 : 64;
     p.n_col_blocks = (a->N + tn - 1) / tn;
     ntiles = p.shape == 2 ? t32 : (p.shape == 1 ? t3264 : t64);
-    (void)tm;
     return ntiles <= 0x3FFFFFFFL;
 }
 
