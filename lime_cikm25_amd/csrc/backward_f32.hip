@@ -1306,12 +1306,14 @@ __global__ __launch_bounds__(512) void attn_bwd_long_kernel(const float* __restr
 //   w & 3 x head-dim half w >> 2 reads its queries' rows back as B operands (two ds_read_b128 per step, split in registers) against K^T
 //   (transposed block reads of the K image): dQ^T[d, i] = sum_j K^T[d, j] dS^T[j, i].  Slabs per key block and the reduction order over
 //   key blocks as before.
-// FOUR-wave workgroups, TWO per CU (77 KB of LDS each): the phases of a query block are short and separated by barriers, so one lock-step
+// FOUR-wave workgroups, TWO per CU (60 KB of LDS each): the phases of a query block are short and separated by barriers, so one lock-step
 // workgroup per CU left the matrix pipe, the VALU and the LDS each 25-40 % busy one after the other (profiles/r03_attn_bwd_sp_counters.txt);
-// two independent workgroups overlap them.  Wave w owns the keys 32 w .. 32 w + 31 (two 16-key tiles), the query side goes in blocks
-// of 32 rows.  Three barriers per query block, 960 matrix cycles per wave and block (dV / dK / dQ on the fp32 MFMA: 3072).
+// two independent workgroups overlap them.  Wave w owns the keys 32 w .. 32 w + 31 (two 16-key tiles; their K and V fragments stay in
+// registers for the whole key block, V never goes to LDS), the query side goes in blocks of 32 rows.  dS reaches the dQ product as a
+// split image [key][query] (the producer writes the three terms it has split for dK anyway, four consecutive queries = 8 bytes per
+// term), read back TRANSPOSED: no second split.  Three barriers per query block, 960 matrix cycles per wave and block (dV / dK / dQ on
+// the fp32 MFMA: 3072).
 constexpr int LQ = 32;
-template <int SP_LDP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_long_sp_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                                    const float* __restrict__ v, long ld, const float* __restrict__ dout,
                                                                    long ldo, const float* __restrict__ stats, float* __restrict__ dq,
@@ -1319,15 +1321,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_sp_kernel(const float* _
                                                                    int n_head, int head_dim, int head_stride, float scale, int n_blk,
                                                                    LimeDropout drop, float* __restrict__ dq_slabs, long n_tok) {
     using namespace lime_dev;
-    constexpr int LDP = SP_LDP, KT = LB * SWZ_ROW, QT = LQ * SWZ_ROW;
-    static_assert(LDP % 4 == 0, "16-byte aligned dS rows");
+    constexpr int KT = LB * SWZ_ROW, QT = LQ * SWZ_ROW;
+    static_assert(LQ == SWZ_ROW, "the dS image has one row per key and LQ queries per row");
     extern __shared__ float smem[];
     unsigned short* const Kt = reinterpret_cast<unsigned short*>(smem);       // three swizzled bf16 images of the K block, [LB][32]
-    unsigned short* const Vt = Kt + 3 * KT;
-    unsigned short* const Qi = Vt + 3 * KT;      // ... of the query block's Q rows, [LQ][32]
+    unsigned short* const Di = Kt + 3 * KT;      // ... of dS^T: [LB keys][LQ queries]
+    unsigned short* const Qi = Di + 3 * KT;      // ... of the query block's Q rows, [LQ][32]
     unsigned short* const Oi = Qi + 3 * QT;      // ... and of its dO rows
-    float* const Ps = smem + 3 * KT + 3 * QT;    // (2 x 3 KT + 2 x 3 QT bf16) [LQ][LDP]: dS
-    float* const Ls = Ps + LQ * LDP;
+    float* const Ls = smem + 3 * KT + 3 * QT;    // (2 x 3 KT + 2 x 3 QT bf16)
     float* const Ds = Ls + LQ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, kg = lane >> 4;
     const int kb = blockIdx.x % n_blk;
@@ -1336,12 +1337,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_sp_kernel(const float* _
     const long row_base = (long)seq * S;
     const int k0 = kb * LB, k_valid = min(LB, S - k0);
     const int R0 = 32 * wave, qi = wave & 1, hh = wave >> 1;
-    for (int e = tid; e < LB * 16; e += 256) {      // K and V rows -> split images (zero outside the valid rows / columns)
+    for (int e = tid; e < LB * 16; e += 256) {      // K rows -> split images (zero outside the valid rows / columns)
         const int r = e >> 4, c = (e & 15) * 2;
         const bool ok0 = r < k_valid && c < head_dim, ok1 = r < k_valid && c + 1 < head_dim;
         const long g = (row_base + k0 + (r < k_valid ? r : 0)) * ld + head * head_stride + c;
         swz_store2(Kt, KT, r, c, ok0 ? k[g] : 0.f, ok1 ? k[g + 1] : 0.f);
-        swz_store2(Vt, KT, r, c, ok0 ? v[g] : 0.f, ok1 ? v[g + 1] : 0.f);
     }
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 av[2][2] = {{z4, z4}, {z4, z4}}, ak[2][2] = {{z4, z4}, {z4, z4}};   // dV^T / dK^T of key tile u: [head dim 16 c + 4 kg + r][key R0 + 16 u + fi]
@@ -1367,8 +1367,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_sp_kernel(const float* _
         }
     };
     fetch_q(0);
-    __syncthreads();                            // the K / V images are complete
-    SplitFrag kB[2];                            // this wave's keys: every query block (the V fragments are re-read per block: registers)
+    // this wave's V rows straight from global memory into split fragments (lane: key R0 + 16 u + fi, head dims 8 kg .. 8 kg + 7)
+    SplitFrag kB[2], vB[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int r = R0 + 16 * u + fi;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 8 * kg + e;
+            x[e] = (r < k_valid && c < head_dim) ? v[(row_base + k0 + r) * ld + head * head_stride + c] : 0.f;
+        }
+        vB[u] = split_frag(x);
+    }
+    __syncthreads();                            // the K image is complete
 #pragma unroll
     for (int u = 0; u < 2; ++u) kB[u] = swz_row_load(Kt, KT, R0 + 16 * u + fi, kg);
     const float c2 = scale * LOG2E;
@@ -1386,7 +1398,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_sp_kernel(const float* _
         if (qb + 1 < n_qblk) fetch_q(qb + 1);
         // ---- S and dP of this wave's two key tiles x the two query tiles, then P~ and dS in place -----------------------------
         f32x4 p[2][2], dp[2][2];                // [key tile u][query tile t]: [query 16 t + 4 kg + r][key R0 + 16 u + fi]
-        const SplitFrag vB[2] = {swz_row_load(Vt, KT, R0 + fi, kg), swz_row_load(Vt, KT, R0 + 16 + fi, kg)};
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const SplitFrag qA = swz_row_load(Qi, QT, 16 * t + fi, kg), oA = swz_row_load(Oi, QT, 16 * t + fi, kg);
@@ -1412,13 +1423,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_sp_kernel(const float* _
                     if (drop.thresh != 0)
                         f = lime_keep(drop, ((uint64_t)prob * S + (uint64_t)(q0 + row)) * (uint64_t)S + (uint64_t)(k0 + col)) ? drop.scale : 0.f;
                     p[u][t][r] = pv * f;                                    // what the dV product needs
-                    const float dsv = scale * pv * (dp[u][t][r] * f - dl4[r]);
-                    dp[u][t][r] = dsv;
-                    Ps[row * LDP + col] = dsv;                              // for dQ (the other orientation)
+                    dp[u][t][r] = scale * pv * (dp[u][t][r] * f - dl4[r]);  // dS
                 }
             }
         }
-        // ---- dV^T += dO^T P~, dK^T += Q^T dS: the result registers of the two query tiles are the eight k values of the B operand ----
+        // ---- dV^T += dO^T P~: the result registers of the two query tiles are the eight k values of the B operand ---------------------
         {
             const SplitFrag o0 = swz_tr_load(Oi, QT, 0, 0, fi, kg), o1 = swz_tr_load(Oi, QT, 0, 1, fi, kg);
 #pragma unroll
@@ -1429,25 +1438,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_sp_kernel(const float* _
             }
         }
         __builtin_amdgcn_sched_barrier(0);      // (one pair of transposed fragments at a time: registers)
+        // ---- dK^T += Q^T dS; the same three terms of dS go to the [key][query] image the dQ product reads (8 bytes per tile and term) ----
         {
             const SplitFrag q0f = swz_tr_load(Qi, QT, 0, 0, fi, kg), q1f = swz_tr_load(Qi, QT, 0, 1, fi, kg);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const SplitFrag bd = split_frag(dp[u][0], dp[u][1]);
+                const u32x4 bh = __builtin_bit_cast(u32x4, bd.h), bm = __builtin_bit_cast(u32x4, bd.m), bl = __builtin_bit_cast(u32x4, bd.l);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {   // elements 4 t .. 4 t + 3 of the fragment: queries 16 t + 4 kg .. + 3 of key R0 + 16 u + fi
+                    unsigned short* const d = Di + swz_off(R0 + 16 * u + fi, 16 * t + 4 * kg);
+                    *reinterpret_cast<u32x2*>(d) = u32x2{bh[2 * t], bh[2 * t + 1]};
+                    *reinterpret_cast<u32x2*>(d + KT) = u32x2{bm[2 * t], bm[2 * t + 1]};
+                    *reinterpret_cast<u32x2*>(d + 2 * KT) = u32x2{bl[2 * t], bl[2 * t + 1]};
+                }
                 ak[u][0] = split_mfma16(q0f, bd, ak[u][0]);
                 ak[u][1] = split_mfma16(q1f, bd, ak[u][1]);
             }
         }
         __syncthreads();                        // the dS image is complete
-        // ---- this key block's share of dQ^T (head dims 16 hh .. 16 hh + 15 x query tile qi): the k values of a step are the keys
-        // 16 t0 + 4 kg + {0..3} and 16 (t0 + 1) + 4 kg + {0..3} (the order swz_tr_load delivers K^T in) ------------------------------
+        // ---- this key block's share of dQ^T (head dims 16 hh .. 16 hh + 15 x query tile qi) = K^T dS^T: both operands by transposed
+        // block reads, k values = keys 16 t0 + 4 kg + {0..3} and 16 (t0 + 1) + 4 kg + {0..3} ------------------------------------------
         f32x4 aq = z4;
 #pragma unroll
-        for (int s4 = 0; s4 < LB / 32; ++s4) {
-            const float* const pr = Ps + (16 * qi + fi) * LDP + 32 * s4 + 4 * kg;
-            const SplitFrag b = split_frag(*reinterpret_cast<const f32x4*>(pr), *reinterpret_cast<const f32x4*>(pr + 16));
-            aq = split_mfma16(swz_tr_load(Kt, KT, 2 * s4, hh, fi, kg), b, aq);
-        }
+        for (int s4 = 0; s4 < LB / 32; ++s4)
+            aq = split_mfma16(swz_tr_load(Kt, KT, 2 * s4, hh, fi, kg), swz_tr_load(Di, KT, 2 * s4, qi, fi, kg), aq);
         {
             const int row = 16 * qi + fi;       // aq[r] = dQ[query row][head dim 16 hh + 4 kg + r]
             if (row < q_valid) {
@@ -2027,19 +2042,18 @@ static int attention_bwd(const float* q, const float* k, const float* v, int64_t
     int st = lime_check_launch("attn_stats_kernel");
     if (st != LIME_OK) return st;
     if (spx) {
-        constexpr int SP_LDP = LB + 4;
-        constexpr int BYTES_SP = (3 * LB * lime_dev::SWZ_ROW + 3 * LQ * lime_dev::SWZ_ROW + LQ * SP_LDP + 2 * LQ) * 4;
+        constexpr int BYTES_SP = (3 * LB * lime_dev::SWZ_ROW + 3 * LQ * lime_dev::SWZ_ROW + 2 * LQ) * 4;
         static_assert(2 * BYTES_SP <= 163840, "LDS budget: two workgroups per CU");
         static bool configured_sp = false;
         if (!configured_sp) {
-            e = hipFuncSetAttribute((const void*)attn_bwd_long_sp_kernel<SP_LDP>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES_SP);
+            e = hipFuncSetAttribute((const void*)attn_bwd_long_sp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES_SP);
             LIME_REQUIRE(e == hipSuccess, LIME_ERR_LAUNCH, "lime_token_attention_bwd_f32: cannot reserve %d bytes of LDS: %s", BYTES_SP,
                          hipGetErrorString(e));
             configured_sp = true;
         }
-        attn_bwd_long_sp_kernel<SP_LDP><<<(unsigned)(n_prob * n_blk), 256, BYTES_SP, s>>>(q, k, v, ld_qkv, dout, ldo, workspace, dq, dk, dv,
-                                                                                         ld_dqkv, S, n_head, head_dim, head_stride, scale,
-                                                                                         n_blk, drop, dq_slabs, n_tok);
+        attn_bwd_long_sp_kernel<<<(unsigned)(n_prob * n_blk), 256, BYTES_SP, s>>>(q, k, v, ld_qkv, dout, ldo, workspace, dq, dk, dv,
+                                                                                 ld_dqkv, S, n_head, head_dim, head_stride, scale,
+                                                                                 n_blk, drop, dq_slabs, n_tok);
         st = lime_check_launch("attn_bwd_long_sp_kernel");
         if (st != LIME_OK || n_blk == 1) return st;
         const long total_sp = n_tok * n_head * head_stride;
