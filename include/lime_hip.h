@@ -123,7 +123,9 @@ int lime_linear_group_f32(const lime_linear_args* args, int32_t n, void* stream)
  * as rocprofv3 names it: lets a profiler harness match its own event timings to the kernel trace. */
 const char* lime_last_linear_kernel(void);
 
-/* Which kernels take the large 16-byte-aligned problems of lime_linear_f32 (M x N tiles >= 96 of 256 x 320):
+/* Which kernels take the large 16-byte-aligned problems of lime_linear_f32 (M x N tiles >= 96 of 256 x 320) -- and, with the same bit 0, of
+ * lime_linear_wgrad_f32 (M >= 4096), the unmasked padded-head lime_token_attention*_f32 (S = 32 ... 512) and lime_token_attention_bwd*_f32
+ * (S > 64, no key mask):
  *   1 (default): csrc/gemm_sp_f32.hip -- fp32 operands split in registers into three bf16 terms each, six bf16 MFMAs per product
  *                block with fp32 accumulation: the error of one fp32 rounding per product (the same bound as the fp32 MFMA), fp32's
  *                exponent range, 2.7x the fp32 matrix rate;
