@@ -15,8 +15,8 @@
 //       dV^T[d, j] = sum_i dO^T[d, i] P~[i, j],   dK^T[d, j] = sum_i Q^T[d, i] dS[i, j]
 // Seven products instead of five, all at the split rate (56 blocks x 96 cycles per wave against 40 x 256), ONE barrier between
 // the phases, no P image.  Q, K, V, dO are split once per (sequence, head) on their way into LDS: three bf16 images [128][32]
-// each (64-byte rows, chunks swizzled: below).  The row-major image serves both operand kinds: as rows (ds_read_b128: eight consecutive head dims of one
-// token) for the score products, and TRANSPOSED for the gradient products through ds_read_b64_tr_b16 -- per 16-lane group a block
+// each (64-byte rows with swizzled 16-byte chunks: split_mfma.h).  The row-major image serves both operand kinds: as rows (ds_read_b128:
+// eight consecutive head dims of one token) for the score products, and TRANSPOSED for the gradient products through ds_read_b64_tr_b16 -- per 16-lane group a block
 // of four token rows x 16 head dims, delivered column-major: lane fi gets head dim fi of rows 4 kg .. 4 kg + 3 of a 16-row tile,
 // which is exactly the k order the result registers carry.  The results come out transposed (head dims on the registers): a lane
 // stores four consecutive head dims of its token, 16 bytes.
@@ -37,7 +37,6 @@ constexpr int TERM = SPB * SWZ_ROW;                   // one bf16 image (unsigne
 static_assert(SWZ_ROW == 32, "images hold 32 head dims per row");
 constexpr int IMG = 3 * TERM;                         // the three terms of one operand
 constexpr int LDS_BYTES = 4 * IMG * 2 + 3 * SPB * 4;  // Q, K, V, dO + the row statistics
-
 
 struct BwdSpP {
     const float* q; const float* k; const float* v; long ld;
