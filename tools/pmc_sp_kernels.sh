@@ -17,7 +17,7 @@ python - <<'PY' > $O/${R}_sp_kernel_counters.txt
 import csv, collections, re
 def short(n):
     return re.sub(r'\(.*$', '', n.replace('(anonymous namespace)::', '').replace('void ', ''))[:70]
-KEEP = ('gemm_sp_kernel', 'wgrad_sp_kernel', 'token_attn_sp', 'attn_bwd_long_sp', 'attn_stats', 'token_attn_bwd_kernel', 'gemm_pp_kernel', 'wgrad_dma')
+KEEP = ('gemm_sp_kernel', 'wgrad_sp_kernel', 'token_attn_sp', 'attn_bwd_long_sp', 'attn_bwd_sp_kernel', 'attn_stats', 'token_attn_bwd_kernel', 'gemm_pp_kernel', 'wgrad_dma')
 print('# rocprofv3 --pmc (two passes per workload) of bench.py --plain --workload train2b / train4: mean per dispatch of every launch of the kernel in the run;')
 print('# SQ_* cycle counters are summed over the waves / SIMDs of the chip.  MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs /')
 print('# (GRBM_GUI_ACTIVE / 8 XCDs); LDS conflicts = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.')
